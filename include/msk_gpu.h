@@ -1,0 +1,225 @@
+/*
+ * msk_gpu.h — C ABI of the MI355X path-tracing back end for misaki-render.
+ *
+ * This is the drop-in boundary for ONE hot path of the reference:
+ *
+ *   SamplingIntegrator::render          src/librender/integrator.cpp:31-80
+ *     -> render_block / render_sample   src/librender/integrator.cpp:82-126
+ *     -> PathTracer::sample             src/librender/integrators/path.cpp:23-125
+ *     -> Scene::ray_intersect/ray_test  src/librender/scene.cpp:216-273 (Embree3)
+ *     -> ImageBlock::put / Film::put    src/librender/imageblock.cpp:36-114
+ *
+ * The reference has no FFI of its own (it is one C++ shared library); the entry
+ * points below are what its `"path"` Integrator plugin
+ * (include/misaki/render/integrator.h:9-17, integrators/path.cpp:139-140)
+ * binds instead of running the Embree3+TBB tile loop.  INTEGRATION.md shows the
+ * plugin-side stub.  Plain pointers and sizes only — no C++ or torch types.
+ *
+ * Conventions
+ *   - every function returns MSK_OK (0) or a negative MSK_ERR_* code; the text
+ *     of the last error is available from msk_gpu_last_error().  No exception
+ *     crosses this boundary (the plugin turns a non-zero code into the
+ *     reference's `Throw`, include/misaki/core/logger.h:81-88).
+ *   - the caller owns every host array for the duration of the call that takes
+ *     it; the library copies what it needs into HBM.
+ *   - handles are opaque and destroyed explicitly.
+ *   - one host thread per msk_ctx (the reference calls render() from a single
+ *     worker thread, src/apps/main.cpp:37).
+ */
+#ifndef MSK_GPU_H
+#define MSK_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSK_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+#define MSK_OK                 0
+#define MSK_ERR_INVALID_ARG   (-1)
+#define MSK_ERR_NO_DEVICE     (-2)
+#define MSK_ERR_HIP           (-3)
+#define MSK_ERR_OOM           (-4)
+#define MSK_ERR_UNSUPPORTED   (-5)
+
+/* ---- plugin type tags (the reference's registered plugin names) --------- */
+#define MSK_BSDF_DIFFUSE       0   /* "diffuse"  bsdfs/diffuse.cpp:73          */
+#define MSK_EMITTER_AREA       0   /* "area"     emitters/area.cpp:61          */
+
+/* RNG semantics (the reference's own seeding is not reproducible) */
+#define MSK_RNG_PCG_BLOCK      0   /* one PCG32 stream per 32x32 block; CPU oracle only */
+#define MSK_RNG_COUNTER        1   /* stateless hash of (seed,pixel,sample,dim); GPU + oracle */
+
+#define MSK_CIE_SAMPLES        95  /* include/misaki/core/spectrum.h:75        */
+#define MSK_FILTER_RESOLUTION  32  /* include/misaki/render/rfilter.h:6        */
+
+/*
+ * One triangle mesh = one reference `Mesh` (include/misaki/render/mesh.h:86-90).
+ * Vertices use the reference's interleaved layout, 8 floats per vertex
+ * [px py pz nx ny nz u v] (shapes/obj.cpp:137-142), already in world space
+ * (obj.cpp:90,102).  Faces are 3 uint32 per triangle, local to the mesh.
+ * Mesh order == the reference's m_shapes order == Embree geomID (scene.cpp:235-240).
+ */
+typedef struct msk_mesh_desc {
+    uint32_t first_vertex;   /* offset into msk_scene_desc.vertices, in vertices */
+    uint32_t vertex_count;
+    uint32_t first_face;     /* offset into msk_scene_desc.faces, in triangles  */
+    uint32_t face_count;
+    int32_t  bsdf_id;        /* index into bsdfs[]                              */
+    int32_t  emitter_id;     /* index into emitters[], -1 = not an emitter      */
+    uint32_t has_normals;    /* Mesh::has_vertex_normals()  (mesh.h:66)         */
+    uint32_t has_texcoords;  /* Mesh::has_vertex_texcoords() (mesh.h:67)        */
+} msk_mesh_desc;
+
+/*
+ * BSDF parameters.  For MSK_BSDF_DIFFUSE `reflectance` holds the three
+ * sigmoid-polynomial coefficients srgb_model_fetch() returned for the RGB
+ * reflectance (spectra/srgb.cpp:13-19, srgb.cpp:11-28).
+ */
+typedef struct msk_bsdf_desc {
+    int32_t type;
+    float   reflectance[3];
+    float   params[12];      /* reserved for the rough BSDF rows  */
+} msk_bsdf_desc;
+
+/*
+ * Area emitter (emitters/area.cpp) with an `srgb_d65` radiance
+ * (spectra/srgb_d65.cpp:13-36): radiance(l) = d65(l) * d65_scale * S(coeff, l),
+ * d65_scale = scale * 2*max(rgb) / 10568 (srgb_d65.cpp:18-26, d65.cpp:33-34).
+ */
+typedef struct msk_emitter_desc {
+    int32_t type;
+    int32_t mesh_id;         /* the shape this emitter is attached to          */
+    float   radiance[3];     /* sigmoid-polynomial coefficients                */
+    float   d65_scale;
+} msk_emitter_desc;
+
+/* PerspectiveCamera (sensors/perspective.cpp:8-42); matrices are row-major 4x4. */
+typedef struct msk_camera_desc {
+    float sample_to_camera[16];  /* m_sample_to_camera, sample space in PIXELS */
+    float to_world[16];          /* m_world_transform                          */
+    float near_clip, far_clip;
+} msk_camera_desc;
+
+/* Film::size() (film.cpp:10) + ReconstructionFilter discretisation (rfilter.cpp:12-27). */
+typedef struct msk_film_desc {
+    int32_t width, height;
+    float   filter_radius;                       /* m_radius                    */
+    float   filter_lut[MSK_FILTER_RESOLUTION + 1]; /* m_values, [32] == 0       */
+} msk_film_desc;
+
+typedef struct msk_scene_desc {
+    uint32_t abi_version;       /* MSK_ABI_VERSION                             */
+    uint32_t n_meshes, n_bsdfs, n_emitters;
+    const msk_mesh_desc    *meshes;
+    const msk_bsdf_desc    *bsdfs;
+    const msk_emitter_desc *emitters;
+    const float    *vertices;   /* n_vertices * 8 floats                       */
+    const uint32_t *faces;      /* n_faces * 3                                 */
+    uint32_t n_vertices, n_faces;
+    msk_camera_desc camera;
+    msk_film_desc   film;
+    /* spectral tables owned by the host side of the reference
+       (spectrum.cpp:8-111: x,y,z each 95 samples 360..830 nm; d65.cpp:12-27) */
+    const float *cie1931_xyz;   /* 3 * MSK_CIE_SAMPLES                         */
+    const float *d65;           /* MSK_CIE_SAMPLES                             */
+} msk_scene_desc;
+
+/*
+ * Render parameters = the integrator/sampler properties of the reference
+ * (integrator.cpp:20-23,130-136; sampler.cpp:8-9) plus the shard selectors.
+ * Defaults that reproduce the reference's effective behaviour:
+ * rr_depth 5, max_depth -1, hide_emitters 0, block_size 32.
+ */
+typedef struct msk_render_params {
+    uint32_t spp;            /* sampler sample_count                           */
+    uint64_t seed;           /* sampler base_seed                              */
+    int32_t  rng_mode;       /* MSK_RNG_*                                      */
+    int32_t  rr_depth;
+    int32_t  max_depth;
+    int32_t  hide_emitters;
+    int32_t  block_size;     /* MSK_BLOCK_SIZE = 32 (imageblock.h:8)           */
+    /* shard: this call renders the spiral blocks id with
+       id % block_stride == block_first (imageblock.cpp:187-247 order) ...     */
+    uint32_t block_first, block_stride;
+    /* ... and of every pixel the sample indices s with
+       s % sample_stride == sample_first.  (0,1) = everything.                 */
+    uint32_t sample_first, sample_stride;
+} msk_render_params;
+
+typedef struct msk_stats {
+    uint64_t samples;        /* camera samples traced                          */
+    uint64_t segments;       /* closest-hit rays (path segments)               */
+    uint64_t shadow_rays;    /* occlusion rays                                 */
+    uint32_t iterations;     /* wavefront iterations                           */
+    uint32_t passes;         /* block groups (record-buffer passes)            */
+    float    ms_total;       /* device time of the whole call                  */
+    float    ms_generate, ms_trace, ms_shade, ms_resolve; /* per-kernel sums   */
+    uint32_t n_trace_launches, n_shade_launches;
+} msk_stats;
+
+typedef struct msk_ctx   msk_ctx;
+typedef struct msk_scene msk_scene;
+
+/* ---- lifetime ------------------------------------------------------------ */
+/* device_ids: HIP ordinals; n must be 1 in this version (one process per GPU,
+   multi-GPU is one msk_ctx per rank + a film reduce). */
+int  msk_gpu_init(const int *device_ids, int n, msk_ctx **out_ctx);
+void msk_gpu_shutdown(msk_ctx *ctx);
+const char *msk_gpu_last_error(const msk_ctx *ctx); /* ctx may be NULL */
+
+/* replaces Scene::accel_init (scene.cpp:201-212): upload geometry, build BVH,
+   area-light tables (mesh.cpp:39-48) */
+int  msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *desc, msk_scene **out_scene);
+void msk_gpu_scene_destroy(msk_scene *scene);
+
+/* ---- the hot path --------------------------------------------------------- */
+/*
+ * Replaces the body of SamplingIntegrator::render between film->prepare() and
+ * the last film->put() (integrator.cpp:48-76).  Writes the film's weighted sums
+ * {X,Y,Z,A,W} per pixel, row-major height*width*5 floats, exactly what
+ * HDRFilm's storage ImageBlock holds after the last put (hdrfilm.cpp:43-46).
+ * film_xyzaw: host memory, caller-owned.  stats may be NULL.
+ */
+int  msk_gpu_render(msk_scene *scene, const msk_render_params *params,
+                    float *film_xyzaw, msk_stats *stats);
+
+/* Same, but the film stays in HBM: d_film_xyzaw is a device pointer on the
+   ctx's device (e.g. a torch tensor's data_ptr, reduced over RCCL afterwards).
+   hip_stream: a hipStream_t or NULL for the library's own stream; the call
+   returns after the work is complete on that stream. */
+int  msk_gpu_render_device(msk_scene *scene, const msk_render_params *params,
+                           float *d_film_xyzaw, void *hip_stream, msk_stats *stats);
+
+/* ---- sub-stage entry points (parity tests bind these) ---------------------- */
+/*
+ * Scene::ray_intersect / Scene::ray_test (scene.cpp:216-273) on a batch of
+ * rays.  rays: n * 8 floats {ox,oy,oz,tmin, dx,dy,dz,tmax}.
+ * closest: out_hit n * 4 floats {t,u,v, bitcast(prim)} with t = +inf on a
+ * miss; prim is the scene-global triangle index (mesh.first_face + primID).
+ * any: out_occluded n bytes (0/1).  Host pointers.
+ */
+int  msk_gpu_trace_closest(msk_scene *scene, uint64_t n, const float *rays, float *out_hit);
+int  msk_gpu_trace_any(msk_scene *scene, uint64_t n, const float *rays, uint8_t *out_occluded);
+
+/*
+ * render_sample (integrator.cpp:103-126) for every sample of the listed
+ * pixels, WITHOUT the film splat: out_xyz = n_pixels * spp * 3 floats, the
+ * {X,Y,Z} that render_sample hands to ImageBlock::put, out_pos (may be NULL)
+ * = n_pixels * spp * 2 floats position_sample.  pixels: n_pixels * 2 int32
+ * (x,y).  counter RNG only.  Host pointers.
+ */
+int  msk_gpu_sample_pixels(msk_scene *scene, const msk_render_params *params,
+                           uint64_t n_pixels, const int32_t *pixels,
+                           float *out_xyz, float *out_pos);
+
+/* device + build information for logs: fills a NUL-terminated string */
+int  msk_gpu_describe(const msk_ctx *ctx, char *buf, uint64_t buf_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSK_GPU_H */

@@ -1,0 +1,281 @@
+"""Python mirror of the reference's HOST side of the hot path (setup only, no per-sample work).
+
+What the reference's host does before SamplingIntegrator::render runs, restated so that
+Python callers (tests, bench.py, smoke) can build the flattened `msk_scene_desc` the C ABI takes:
+
+  * synthetic Cornell-box meshes (the reference ships none) and the
+    OBJ loader's quad split + vertex layout (src/librender/shapes/obj.cpp:104-142)
+  * PerspectiveCamera matrices (sensors/perspective.cpp:11-19, core/transform.h:169-187)
+  * Gaussian reconstruction filter LUT (filters/gaussian.cpp:10-20, rfilter.cpp:12-27)
+  * srgb / srgb_d65 texture parameters (spectra/srgb.cpp:13-19, srgb_d65.cpp:13-31) through
+    this package's own Jakob-Hanika style spectral upsampling (rgb2spec.py)
+  * HDRFilm::image() develop step (films/hdrfilm.cpp:48-90)
+
+The C++ host library (misaki-render_amd/host/) provides the same through the reference's
+plugin/Properties/XML interface; this module is the scripting-side equivalent.
+"""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+
+from . import abi
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+
+
+def cie_tables():
+    """(cie1931_xyz float32[3*95], d65 float32[95]) — the tables the host hands to the back end."""
+    d = json.load(open(os.path.join(_PKG, "data", "cie_tables.json")))
+    xyz = np.array(d["cie1931_x"] + d["cie1931_y"] + d["cie1931_z"], np.float32)
+    return xyz, np.array(d["d65"], np.float32)
+
+
+# ----------------------------------------------------------------------------- filter
+def gaussian_filter(stddev=0.5):
+    """GaussianFilter ctor + ReconstructionFilter::init_discretization in fp32.
+
+    Returns (radius, lut[33]).  gaussian.cpp:10-20, rfilter.cpp:12-27.
+    """
+    f = np.float32
+    stddev = f(stddev)
+    radius = f(4) * stddev
+    alpha = f(-1.0) / (f(2.0) * stddev * stddev)
+    bias = f(math.exp(float(alpha * radius * radius)))   # std::exp(float) -> expf
+    bias = np.exp(alpha * radius * radius, dtype=np.float32)
+    vals = np.zeros(abi.MSK_FILTER_RESOLUTION + 1, np.float32)
+    s = f(0)
+    for i in range(abi.MSK_FILTER_RESOLUTION):
+        x = f(radius * f(i)) / f(abi.MSK_FILTER_RESOLUTION)
+        vals[i] = max(f(0), np.exp(alpha * x * x, dtype=np.float32) - bias)
+        s = f(s + vals[i])
+    s = f(s * (f(2) * radius / f(abi.MSK_FILTER_RESOLUTION)))
+    norm = f(1.0) / s
+    vals[:abi.MSK_FILTER_RESOLUTION] *= norm
+    return float(radius), vals
+
+
+# ----------------------------------------------------------------------------- camera
+def perspective_camera(fov, near, far, width, height, origin, target, up):
+    """-> (sample_to_camera[16], to_world[16]) row-major float32; sample space is in pixels.
+
+    perspective.cpp:11-19: camera_to_sample = S(w,h,1) S(-.5,-.5a,1) T(-1,-1/a,0) P(fov,near,far);
+    the inverse is formed analytically in float64 and rounded once.
+    """
+    aspect = width / float(height)
+    recip = 1.0 / (float(far) - float(near))
+    cot = 1.0 / math.tan(math.radians(float(np.float32(fov) / np.float32(2.0))))
+    A, B = far * recip, -near * far * recip
+    p_inv = np.array([[1 / cot, 0, 0, 0], [0, 1 / cot, 0, 0], [0, 0, 0, 1], [0, 0, 1 / B, -A / B]], np.float64)
+    sx, sy = 1.0 / width / -0.5, 1.0 / height / (-0.5 * aspect)
+    m = np.array([[sx, 0, 0, 1], [0, sy, 0, 1 / aspect], [0, 0, 1, 0], [0, 0, 0, 1]], np.float64)
+    s2c = (p_inv @ m).astype(np.float32)
+    o, t, u = (np.asarray(v, np.float64) for v in (origin, target, up))
+    d = (t - o) / np.linalg.norm(t - o)
+    left = np.cross(u / np.linalg.norm(u), d)
+    left /= np.linalg.norm(left)
+    new_up = np.cross(d, left)
+    new_up /= np.linalg.norm(new_up)
+    tw = np.eye(4)
+    tw[:3, 0], tw[:3, 1], tw[:3, 2], tw[:3, 3] = left, new_up, d, np.asarray(origin, np.float32)
+    return s2c.reshape(16), tw.astype(np.float32).reshape(16)
+
+
+# ----------------------------------------------------------------------------- meshes
+class MeshSpec:
+    """One <shape type="obj"> of the scene: faces as 3- or 4-tuples of 3D points."""
+
+    def __init__(self, name, faces, reflectance, radiance=None, translate=(0, 0, 0), normals=None):
+        self.name, self.faces, self.reflectance, self.radiance = name, faces, reflectance, radiance
+        self.translate, self.normals = translate, normals
+
+
+def triangulate(mesh):
+    """OBJ loader semantics: 8 floats per vertex, quad (v0,v1,v2,v3) -> (v0,v1,v2),(v3,v0,v2)
+    (obj.cpp:104-133); `to_world` translate applied to positions at load (obj.cpp:90)."""
+    verts, faces = [], []
+    tr = np.asarray(mesh.translate, np.float32)
+    for f in mesh.faces:
+        base = len(verts)
+        for p in f:
+            # Transform4f::apply_point with a pure translation: p + t in fp32
+            q = np.asarray(p, np.float32) + tr
+            verts.append([q[0], q[1], q[2], 0, 0, 0, 0, 0])
+        if len(f) == 3:
+            faces.append([base, base + 1, base + 2])
+        else:
+            faces.append([base, base + 1, base + 2])
+            faces.append([base + 3, base, base + 2])
+    return np.array(verts, np.float32), np.array(faces, np.uint32)
+
+
+def write_obj(mesh, path):
+    """The same geometry as an OBJ file the reference's loader (and the C++ host) can read."""
+    with open(path, "w") as fh:
+        fh.write(f"# {mesh.name}: synthetic Cornell-box mesh (classic Cornell data)\n")
+        n = 0
+        for f in mesh.faces:
+            for p in f:
+                fh.write("v %.9g %.9g %.9g\n" % tuple(float(np.float32(c)) for c in p))
+            fh.write("f " + " ".join(str(n + i + 1) for i in range(len(f))) + "\n")
+            n += len(f)
+
+
+WHITE = (0.885809, 0.698859, 0.666422)
+GREEN = (0.105421, 0.37798, 0.076425)
+RED = (0.570068, 0.0430135, 0.0443706)
+BOX = (0.45, 0.30, 0.90)
+LUMINAIRE = (0.936461, 0.740433, 0.705267)
+
+
+def cbox_meshes():
+    """The 8 shapes of results/Figure_1_Pathtrace/scene.xml:33-103 in XML order (= geomID order),
+    geometry from the classic Cornell measurements."""
+    q = lambda *p: tuple(p)
+    return [
+        MeshSpec("cbox_luminaire", [q((343, 548.8, 227), (343, 548.8, 332), (213, 548.8, 332), (213, 548.8, 227))],
+                 LUMINAIRE, radiance=(40, 40, 40), translate=(0, -0.5, 0)),
+        MeshSpec("cbox_floor", [q((552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2))], WHITE),
+        MeshSpec("cbox_ceiling", [q((556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0))], WHITE),
+        MeshSpec("cbox_back", [q((549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2))], WHITE),
+        MeshSpec("cbox_greenwall", [q((0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2))], GREEN),
+        MeshSpec("cbox_redwall", [q((552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0))], RED),
+        MeshSpec("cbox_smallbox", [
+            q((130, 165, 65), (82, 165, 225), (240, 165, 272), (290, 165, 114)),
+            q((290, 0, 114), (290, 165, 114), (240, 165, 272), (240, 0, 272)),
+            q((130, 0, 65), (130, 165, 65), (290, 165, 114), (290, 0, 114)),
+            q((82, 0, 225), (82, 165, 225), (130, 165, 65), (130, 0, 65)),
+            q((240, 0, 272), (240, 165, 272), (82, 165, 225), (82, 0, 225))], BOX),
+        MeshSpec("cbox_largebox", [
+            q((423, 330, 247), (265, 330, 296), (314, 330, 456), (472, 330, 406)),
+            q((423, 0, 247), (423, 330, 247), (472, 330, 406), (472, 0, 406)),
+            q((472, 0, 406), (472, 330, 406), (314, 330, 456), (314, 0, 456)),
+            q((314, 0, 456), (314, 330, 456), (265, 330, 296), (265, 0, 296)),
+            q((265, 0, 296), (265, 330, 296), (423, 330, 247), (423, 0, 247))], BOX),
+    ]
+
+
+CBOX_CAMERA = dict(fov=49.3077, near=10.0, far=2800.0, origin=(278, 273, -800), target=(278, 273, -799),
+                   up=(0, 1, 0))
+
+
+def blob_mesh(name, center, radius, n_theta, n_phi, reflectance, seed=1, bump=0.15):
+    """A closed, bumpy, outward-wound triangle mesh (bunny/teapot-class stand-in):
+    a UV sphere displaced by a few low-frequency sinusoids.  ~2*n_theta*n_phi triangles."""
+    rng = np.random.RandomState(seed)
+    k = rng.uniform(1, 4, (4, 2)).round()
+    ph = rng.uniform(0, 2 * np.pi, 4)
+
+    def point(i, j):
+        th = np.pi * i / n_theta
+        p = 2 * np.pi * (j % n_phi) / n_phi
+        r = 1.0
+        if 0 < i < n_theta:
+            for a in range(4):
+                r += bump / 4 * np.sin(k[a, 0] * th * 2 + ph[a]) * np.cos(k[a, 1] * p + ph[a])
+        d = np.array([np.sin(th) * np.cos(p), np.cos(th), np.sin(th) * np.sin(p)])
+        return tuple(np.asarray(center, np.float64) + radius * r * d)
+
+    faces = []
+    for i in range(n_theta):
+        for j in range(n_phi):
+            a, b, c, d = point(i, j), point(i + 1, j), point(i + 1, j + 1), point(i, j + 1)
+            if i == 0:
+                faces.append((a, c, b))
+            elif i == n_theta - 1:
+                faces.append((a, d, b))
+            else:
+                faces.append((a, d, c))
+                faces.append((a, c, b))
+    return MeshSpec(name, faces, reflectance)
+
+
+# ----------------------------------------------------------------------------- flatten
+class FlatScene:
+    """Owns the numpy arrays an msk_scene_desc points into."""
+
+    def __init__(self):
+        self.desc = abi.SceneDesc()
+        self.keep = []
+
+
+def flatten(meshes, width, height, camera=None, filter_stddev=0.5, coeff_lookup=None):
+    """Scene -> msk_scene_desc, the step the `"path"` plugin's render() performs before calling
+    the C ABI.  coeff_lookup(rgb)->(c0,c1,c2) overrides the spectral upsampling
+    (tests pass the reference's own rgb2spec_fetch results); default = this package's rgb2spec."""
+    from . import rgb2spec
+    fetch = coeff_lookup or rgb2spec.srgb_model_fetch
+    camera = camera or CBOX_CAMERA
+    fs = FlatScene()
+    all_v, all_f, md, bd, ed = [], [], [], [], []
+    nv = nf = 0
+    for i, m in enumerate(meshes):
+        v, f = triangulate(m)
+        c = fetch(tuple(m.reflectance))
+        b = abi.BsdfDesc(abi.MSK_BSDF_DIFFUSE, (C.c_float * 3)(*c), (C.c_float * 12)())
+        bd.append(b)
+        eid = -1
+        if m.radiance is not None:
+            # spectra/srgb_d65.cpp:13-31: scale = 2*max(rgb); color /= scale; d65 scale *= scale;
+            # d65.cpp:33-34: m_scale *= 1/10568
+            rad = np.asarray(m.radiance, np.float32)
+            scale = np.float32(rad.max() * np.float32(2.0))
+            col = rad / scale if scale != 0 else rad
+            ce = fetch(tuple(float(x) for x in col))
+            d65_scale = np.float32(np.float32(1.0) * scale) * (np.float32(1.0) / np.float32(10568.0))
+            ed.append(abi.EmitterDesc(abi.MSK_EMITTER_AREA, i, (C.c_float * 3)(*ce), float(d65_scale)))
+            eid = len(ed) - 1
+        md.append(abi.MeshDesc(nv, len(v), nf, len(f), i, eid, 0, 0))
+        all_v.append(v)
+        all_f.append(f)
+        nv += len(v)
+        nf += len(f)
+    verts = np.ascontiguousarray(np.concatenate(all_v), np.float32)
+    faces = np.ascontiguousarray(np.concatenate(all_f), np.uint32)
+    cie, d65 = cie_tables()
+    meshes_a = (abi.MeshDesc * len(md))(*md)
+    bsdfs_a = (abi.BsdfDesc * len(bd))(*bd)
+    emit_a = (abi.EmitterDesc * max(1, len(ed)))(*ed)
+    fs.keep += [verts, faces, cie, d65, meshes_a, bsdfs_a, emit_a]
+    d = fs.desc
+    d.abi_version = abi.MSK_ABI_VERSION
+    d.n_meshes, d.n_bsdfs, d.n_emitters = len(md), len(bd), len(ed)
+    d.meshes, d.bsdfs, d.emitters = meshes_a, bsdfs_a, emit_a
+    d.vertices = verts.ctypes.data_as(C.POINTER(C.c_float))
+    d.faces = faces.ctypes.data_as(C.POINTER(C.c_uint32))
+    d.n_vertices, d.n_faces = nv, nf
+    s2c, tw = perspective_camera(camera["fov"], camera["near"], camera["far"], width, height,
+                                 camera["origin"], camera["target"], camera["up"])
+    d.camera.sample_to_camera[:] = s2c.tolist()
+    d.camera.to_world[:] = tw.tolist()
+    d.camera.near_clip, d.camera.far_clip = camera["near"], camera["far"]
+    radius, lut = gaussian_filter(filter_stddev)
+    d.film.width, d.film.height, d.film.filter_radius = width, height, radius
+    d.film.filter_lut[:] = lut.tolist()
+    d.cie1931_xyz = cie.ctypes.data_as(C.POINTER(C.c_float))
+    d.d65 = d65.ctypes.data_as(C.POINTER(C.c_float))
+    fs.vertices, fs.faces = verts, faces
+    return fs
+
+
+def cbox_scene(width, height, coeff_lookup=None, extra_meshes=()):
+    return flatten(cbox_meshes() + list(extra_meshes), width, height, coeff_lookup=coeff_lookup)
+
+
+# ----------------------------------------------------------------------------- develop
+_XYZ_TO_SRGB = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556],
+                         [0.055648, -0.204043, 1.057311]], np.float32)
+
+
+def develop(film_xyzaw):
+    """HDRFilm::image() (hdrfilm.cpp:48-90): rgb = xyz_to_srgb(XYZ) / W, alpha = A / W -> float32[H,W,4]."""
+    f = np.asarray(film_xyzaw, np.float32)
+    xyz = f[..., :3]
+    # Eigen 3x3 * vec3 row reduction, a0 + (a1 + a2)
+    rgb = np.stack([_XYZ_TO_SRGB[r, 0] * xyz[..., 0] + (_XYZ_TO_SRGB[r, 1] * xyz[..., 1] +
+                                                        _XYZ_TO_SRGB[r, 2] * xyz[..., 2]) for r in range(3)], -1)
+    w = f[..., 4]
+    inv = np.where(w != 0, np.float32(1.0) / np.where(w != 0, w, 1), np.float32(0)).astype(np.float32)
+    return np.concatenate([rgb * inv[..., None], (f[..., 3] * inv)[..., None]], -1).astype(np.float32)
