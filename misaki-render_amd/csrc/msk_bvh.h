@@ -1,0 +1,165 @@
+// msk_bvh.h — host-side BVH2 builder (binned SAH) producing the flattened layout the
+// traversal kernels read.  Replaces rtcCommitScene (reference: src/librender/scene.cpp:201-212).
+//
+// Layout (all float4, 16-byte aligned, 64 B per record so one record = one half cache line):
+//   node  n : [lo0.xyz, hi0.x] [hi0.yz, lo1.xy] [lo1.z, hi1.xyz] [c0, c1, -, - (uint bits)]
+//             child ref c: 0x80000000 | first_tri << 5 | count for a leaf (count <= 8),
+//             otherwise the index of an inner node.
+//   tri   t : [v0.xyz, prim (uint bits)] [e1.xyz, 0] [e2.xyz, 0] [Ng.xyz, 0]
+//             in LEAF order; e1 = v0 - v1, e2 = v2 - v0, Ng = e2 x e1 — the precomputed form of
+//             Embree 3's TriangleM / Moeller-Trumbore test; prim = scene-global triangle index.
+// Child boxes are padded by 1e-4 of the scene diagonal so the slab test can never cull a
+// triangle the (differently rounded) triangle test accepts: hit selection is by (t, prim) and
+// therefore independent of the tree.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace mskbvh {
+
+struct V3 { float x, y, z; };
+static inline V3 vmin(V3 a, V3 b) { return {std::min(a.x, b.x), std::min(a.y, b.y), std::min(a.z, b.z)}; }
+static inline V3 vmax(V3 a, V3 b) { return {std::max(a.x, b.x), std::max(a.y, b.y), std::max(a.z, b.z)}; }
+struct Box {
+    V3 lo{INFINITY, INFINITY, INFINITY}, hi{-INFINITY, -INFINITY, -INFINITY};
+    void grow(V3 p) { lo = vmin(lo, p); hi = vmax(hi, p); }
+    void grow(const Box &b) { lo = vmin(lo, b.lo); hi = vmax(hi, b.hi); }
+    float area() const {
+        float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+        return (dx < 0) ? 0.f : 2.f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+static inline float axis_of(V3 v, int a) { return a == 0 ? v.x : a == 1 ? v.y : v.z; }
+
+struct Built {
+    std::vector<float> nodes;   // 16 floats per node
+    std::vector<float> tris;    // 16 floats per triangle, leaf order
+    uint32_t root_ref = 0;      // packed child ref of the root
+    int max_depth = 0;
+};
+
+struct Builder {
+    const float *pos;           // 9 floats per triangle: p0 p1 p2 (scene-global order)
+    uint32_t n;
+    std::vector<Box> tb;
+    std::vector<V3> tc;
+    std::vector<uint32_t> order;
+    std::vector<uint32_t> leaf_order;
+    float pad = 0;
+    static constexpr int kLeaf = 4, kBins = 16;
+    struct Child { int ref; int count; Box box; };
+    std::vector<float> nodes;
+    int max_depth = 0;
+
+    Box range_box(uint32_t first, uint32_t count) const {
+        Box b; for (uint32_t i = first; i < first + count; ++i) b.grow(tb[order[i]]); return b;
+    }
+    Child make_leaf(uint32_t first, uint32_t count) {
+        Child c; c.ref = (int) leaf_order.size(); c.count = (int) count; c.box = range_box(first, count);
+        for (uint32_t i = first; i < first + count; ++i) leaf_order.push_back(order[i]);
+        return c;
+    }
+    Child build(uint32_t first, uint32_t count, int depth) {
+        max_depth = std::max(max_depth, depth);
+        if (count <= (uint32_t) kLeaf) return make_leaf(first, count);
+        Box cb; for (uint32_t i = first; i < first + count; ++i) { V3 c = tc[order[i]]; cb.grow(c); }
+        Box nb = range_box(first, count);
+        int best_axis = -1, best_bin = -1; float best_cost = INFINITY;
+        for (int a = 0; a < 3; ++a) {
+            float lo = axis_of(cb.lo, a), hi = axis_of(cb.hi, a);
+            if (!(hi > lo)) continue;
+            Box bins[kBins]; uint32_t cnt[kBins] = {0};
+            float sc = kBins / (hi - lo);
+            for (uint32_t i = first; i < first + count; ++i) {
+                int b = std::min(kBins - 1, std::max(0, (int) ((axis_of(tc[order[i]], a) - lo) * sc)));
+                bins[b].grow(tb[order[i]]); cnt[b]++;
+            }
+            float right_area[kBins]; uint32_t right_cnt[kBins];
+            Box acc; uint32_t c = 0;
+            for (int b = kBins - 1; b > 0; --b) { acc.grow(bins[b]); c += cnt[b]; right_area[b] = acc.area(); right_cnt[b] = c; }
+            acc = Box(); c = 0;
+            for (int b = 0; b < kBins - 1; ++b) {
+                acc.grow(bins[b]); c += cnt[b];
+                if (c == 0 || right_cnt[b + 1] == 0) continue;
+                float cost = acc.area() * c + right_area[b + 1] * right_cnt[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+            }
+        }
+        uint32_t mid;
+        if (best_axis < 0) {
+            mid = first + count / 2;   // all centroids coincide: split in the middle
+        } else {
+            float lo = axis_of(cb.lo, best_axis), hi = axis_of(cb.hi, best_axis), sc = kBins / (hi - lo);
+            auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
+                int b = std::min(kBins - 1, std::max(0, (int) ((axis_of(tc[t], best_axis) - lo) * sc)));
+                return b <= best_bin;
+            });
+            mid = (uint32_t) (it - order.begin());
+            if (mid == first || mid == first + count) mid = first + count / 2;
+        }
+        (void) nb;
+        int me = (int) (nodes.size() / 16);
+        nodes.resize(nodes.size() + 16, 0.f);
+        Child l = build(first, mid - first, depth + 1);
+        Child r = build(mid, first + count - mid, depth + 1);
+        write_node(me, l, r);
+        Child c; c.ref = me; c.count = 0; c.box = l.box; c.box.grow(r.box);
+        return c;
+    }
+    static uint32_t pack(const Child &c) {
+        return c.count > 0 ? (0x80000000u | ((uint32_t) c.ref << 5) | (uint32_t) c.count) : (uint32_t) c.ref;
+    }
+    void write_node(int idx, const Child &l, const Child &r) {
+        float *n = &nodes[(size_t) idx * 16];
+        Box a = l.box, b = r.box;
+        a.lo = {a.lo.x - pad, a.lo.y - pad, a.lo.z - pad}; a.hi = {a.hi.x + pad, a.hi.y + pad, a.hi.z + pad};
+        b.lo = {b.lo.x - pad, b.lo.y - pad, b.lo.z - pad}; b.hi = {b.hi.x + pad, b.hi.y + pad, b.hi.z + pad};
+        n[0] = a.lo.x; n[1] = a.lo.y; n[2] = a.lo.z; n[3] = a.hi.x;
+        n[4] = a.hi.y; n[5] = a.hi.z; n[6] = b.lo.x; n[7] = b.lo.y;
+        n[8] = b.lo.z; n[9] = b.hi.x; n[10] = b.hi.y; n[11] = b.hi.z;
+        uint32_t meta[4] = {pack(l), pack(r), 0u, 0u};
+        std::memcpy(&n[12], meta, 16);
+    }
+};
+
+// pos: 9 floats per triangle.  fp32 edge/normal precomputation uses one rounded operation per
+// arithmetic op (this TU is compiled with -ffp-contract=off), the same values a per-ray
+// evaluation of e1, e2, Ng would produce.
+static inline Built build(const float *pos, uint32_t n) {
+    Built out;
+    Builder b; b.pos = pos; b.n = n;
+    b.tb.resize(n); b.tc.resize(n); b.order.resize(n);
+    Box all;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *p = pos + (size_t) i * 9;
+        Box bx; bx.grow(V3{p[0], p[1], p[2]}); bx.grow(V3{p[3], p[4], p[5]}); bx.grow(V3{p[6], p[7], p[8]});
+        b.tb[i] = bx; b.tc[i] = {0.5f * (bx.lo.x + bx.hi.x), 0.5f * (bx.lo.y + bx.hi.y), 0.5f * (bx.lo.z + bx.hi.z)};
+        b.order[i] = i; all.grow(bx);
+    }
+    float dx = all.hi.x - all.lo.x, dy = all.hi.y - all.lo.y, dz = all.hi.z - all.lo.z;
+    b.pad = n ? 1e-4f * std::sqrt(dx * dx + dy * dy + dz * dz) : 0.f;
+    if (n == 0) return out;
+    Builder::Child root = b.build(0, n, 0);
+    out.root_ref = Builder::pack(root);
+    out.nodes = std::move(b.nodes);
+    out.max_depth = b.max_depth;
+    out.tris.resize((size_t) n * 16);
+    for (uint32_t k = 0; k < n; ++k) {
+        uint32_t prim = b.leaf_order[k];
+        const float *p = pos + (size_t) prim * 9;
+        float *t = &out.tris[(size_t) k * 16];
+        float e1[3] = {p[0] - p[3], p[1] - p[4], p[2] - p[5]};        // v0 - v1
+        float e2[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};        // v2 - v0
+        float ng[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0]};
+        t[0] = p[0]; t[1] = p[1]; t[2] = p[2]; std::memcpy(&t[3], &prim, 4);
+        t[4] = e1[0]; t[5] = e1[1]; t[6] = e1[2]; t[7] = 0;
+        t[8] = e2[0]; t[9] = e2[1]; t[10] = e2[2]; t[11] = 0;
+        t[12] = ng[0]; t[13] = ng[1]; t[14] = ng[2]; t[15] = 0;
+    }
+    return out;
+}
+
+}  // namespace mskbvh

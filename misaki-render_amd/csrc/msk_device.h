@@ -1,0 +1,272 @@
+// msk_device.h — fp32 math core of the wavefront path tracer, device side (gfx950).
+//
+// Numerical contract: every fp32 operation below is a single IEEE-754
+// binary32 operation — the library is compiled with -ffp-contract=off, divides and square
+// roots are correctly rounded (hipcc default) — and reductions use the association the
+// reference's Eigen expressions have (3-vectors a0+(a1+a2); 4-wide spectra (a0+a2)+(a1+a3)).
+// Transcendentals on the per-sample path are the det_* fp64 polynomials, rounded once.
+// Reference file:line citations are relative to the misaki-render checkout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MSK_DEV __device__ __forceinline__
+
+namespace msk {
+
+struct f3 { float x, y, z; };
+struct f2 { float x, y; };
+struct spec { float v[4]; };   // Spectrum / Wavelength (core/fwd.h:40-41)
+
+MSK_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+MSK_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+MSK_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+MSK_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+MSK_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+MSK_DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+MSK_DEV float dot(f3 a, f3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+MSK_DEV f3 cross(f3 a, f3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+MSK_DEV float fmin_std(float a, float b) { return (b < a) ? b : a; }   // std::min
+MSK_DEV float fmax_std(float a, float b) { return (a < b) ? b : a; }   // std::max
+MSK_DEV f3 normalized(f3 a) {            // Eigen MatrixBase::normalized()
+    float z = dot(a, a);
+    return z > 0.f ? a / __builtin_sqrtf(z) : a;
+}
+MSK_DEV float max_abs(f3 a) { return fmax_std(fabsf(a.x), fmax_std(fabsf(a.y), fabsf(a.z))); }
+
+MSK_DEV spec splat(float c) { spec r; r.v[0] = r.v[1] = r.v[2] = r.v[3] = c; return r; }
+MSK_DEV spec from4(float4 a) { spec r; r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; return r; }
+MSK_DEV float4 to4(spec a) { return make_float4(a.v[0], a.v[1], a.v[2], a.v[3]); }
+#define MSK_SPEC_OP(op)                                                                         \
+    MSK_DEV spec operator op(spec a, spec b) { spec r;                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) r.v[i] = a.v[i] op b.v[i]; return r; }    \
+    MSK_DEV spec operator op(spec a, float b) { spec r;                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) r.v[i] = a.v[i] op b; return r; }
+MSK_SPEC_OP(+) MSK_SPEC_OP(-) MSK_SPEC_OP(*) MSK_SPEC_OP(/)
+#undef MSK_SPEC_OP
+MSK_DEV float mean4(spec a) { return ((a.v[0] + a.v[2]) + (a.v[1] + a.v[3])) / 4.f; }
+MSK_DEV float max4(spec a) { return fmax_std(fmax_std(a.v[0], a.v[1]), fmax_std(a.v[2], a.v[3])); }
+MSK_DEV bool any_nonzero(spec a) { return a.v[0] != 0.f || a.v[1] != 0.f || a.v[2] != 0.f || a.v[3] != 0.f; }
+
+// core/mathutils.h:10-20
+#define MSK_PI_F        3.14159274101257324f      /* float(3.14159265358979323846) */
+#define MSK_INV_PI_F    0.318309873342514038f     /* float(0.31830988618379067154) */
+#define MSK_EPSILON_F   5.9604644775390625e-08f
+#define MSK_RAY_EPS_F   (MSK_EPSILON_F * 1500)
+#define MSK_SHADOW_EPS_F (MSK_RAY_EPS_F * 10)
+#define MSK_INF_F       __builtin_inff()
+
+// ------------------------------------------------------------------ det_* transcendentals
+MSK_DEV double det_sin_poly(double y) {
+    double z = y * y;
+    double p = -1.0 / 355687428096000.0;
+    p = p * z + 1.0 / 1307674368000.0;
+    p = p * z - 1.0 / 6227020800.0;
+    p = p * z + 1.0 / 39916800.0;
+    p = p * z - 1.0 / 362880.0;
+    p = p * z + 1.0 / 5040.0;
+    p = p * z - 1.0 / 120.0;
+    p = p * z + 1.0 / 6.0;
+    return y - y * z * p;
+}
+MSK_DEV double det_cos_poly(double y) {
+    double z = y * y;
+    double p = 1.0 / 20922789888000.0;
+    p = p * z - 1.0 / 87178291200.0;
+    p = p * z + 1.0 / 479001600.0;
+    p = p * z - 1.0 / 3628800.0;
+    p = p * z + 1.0 / 40320.0;
+    p = p * z - 1.0 / 720.0;
+    p = p * z + 1.0 / 24.0;
+    p = p * z - 0.5;
+    return 1.0 + z * p;
+}
+MSK_DEV void det_sincos(float phi, float *s, float *c) {
+    const double two_over_pi = 0.63661977236758134308;
+    const double pio2_hi = 1.57079632679489655800e+00;
+    const double pio2_lo = 6.12323399573676603587e-17;
+    double x = (double) phi;
+    double k = __builtin_rint(x * two_over_pi);
+    double y = (x - k * pio2_hi) - k * pio2_lo;
+    int q = (int) ((long long) k & 3);
+    double sy = det_sin_poly(y), cy = det_cos_poly(y);
+    double sv = (q & 1) ? cy : sy, cv = (q & 1) ? sy : cy;
+    if (q == 1 || q == 2) cv = -cv;
+    if (q >= 2) sv = -sv;
+    *s = (float) sv; *c = (float) cv;
+}
+MSK_DEV double det_log(double x) {
+    uint64_t b = (uint64_t) __double_as_longlong(x);
+    int e = (int) ((b >> 52) & 0x7ff) - 1023;
+    b = (b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = __longlong_as_double((long long) b);
+    if (m > 1.41421356237309514547) { m = m * 0.5; e += 1; }
+    double s = (m - 1.0) / (m + 1.0), z = s * s;
+    double p = 1.0 / 21.0;
+    p = p * z + 1.0 / 19.0;
+    p = p * z + 1.0 / 17.0;
+    p = p * z + 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z + 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z + 1.0 / 3.0;
+    p = p * z + 1.0;
+    return (double) e * 0.69314718055994528623 + 2.0 * s * p;
+}
+MSK_DEV double det_exp(double y) {
+    const double inv_ln2 = 1.44269504088896338700;
+    const double ln2_hi = 6.93147180369123816490e-01;
+    const double ln2_lo = 1.90821492927058770002e-10;
+    double k = __builtin_rint(y * inv_ln2);
+    double r = (y - k * ln2_hi) - k * ln2_lo;
+    double p = 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    uint64_t b = (uint64_t) ((long long) k + 1023) << 52;
+    return p * __longlong_as_double((long long) b);
+}
+MSK_DEV float det_atanh(float x) {
+    double xd = (double) x;
+    return (float) (0.5 * det_log((1.0 + xd) / (1.0 - xd)));
+}
+MSK_DEV float det_cosh(float x) {
+    double e = det_exp((double) x);
+    return (float) (0.5 * (e + 1.0 / e));
+}
+
+// ------------------------------------------------------------------ counter RNG
+MSK_DEV uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+MSK_DEV uint64_t counter_key(uint64_t seed, uint32_t pixel_index, uint32_t sample_index) {
+    uint64_t id = ((uint64_t) pixel_index << 32) | (uint64_t) sample_index;
+    return mix64(id + 0x9e3779b97f4a7c15ULL * (seed + 1));
+}
+MSK_DEV float u32_to_float01(uint32_t u) {     // core/mathutils.h:111-121
+    return __uint_as_float((u >> 9) | 0x3f800000u) - 1.0f;
+}
+MSK_DEV f2 counter_pair(uint64_t key, uint32_t pair) {
+    uint64_t r = mix64(key + 0x9e3779b97f4a7c15ULL * (uint64_t) (pair + 1));
+    f2 o; o.x = u32_to_float01((uint32_t) (r >> 32)); o.y = u32_to_float01((uint32_t) r);
+    return o;
+}
+
+// ------------------------------------------------------------------ core/mathutils.h:196-203
+MSK_DEV void coordinate_system(f3 n, f3 *s, f3 *t) {
+    float sign = __builtin_copysignf(1.f, n.z);
+    const float a = -1.f / (sign + n.z);
+    const float b = n.x * n.y * a;
+    *s = mk3(1.f + sign * n.x * n.x * a, sign * b, -sign * n.x);
+    *t = mk3(b, sign + n.y * n.y * a, -n.y);
+}
+struct frame3 {                                  // core/frame.h:11-24
+    f3 s, t, n;
+    MSK_DEV f3 to_local(f3 v) const { return mk3(dot(v, s), dot(v, t), dot(v, n)); }
+    MSK_DEV f3 to_world(f3 v) const { return s * v.x + t * v.y + n * v.z; }
+};
+
+MSK_DEV float safe_sqrt(float a) { return __builtin_sqrtf(fmax_std(a, 0.f)); }
+MSK_DEV f2 square_to_uniform_triangle(f2 sample) {          // core/warp.h:11-15
+    float t = safe_sqrt(1.f - sample.x);
+    f2 r; r.x = 1.f - t; r.y = t * sample.y; return r;
+}
+MSK_DEV f2 square_to_uniform_disk_concentric(f2 sample) {   // core/warp.h:17-32
+    float x = 2.f * sample.x - 1.f;
+    float y = 2.f * sample.y - 1.f;
+    float phi, r;
+    if (x == 0 && y == 0) {
+        r = phi = 0;
+    } else if (x * x > y * y) {
+        r = x;
+        phi = (MSK_PI_F / 4.f) * (y / x);
+    } else {
+        r = y;
+        phi = (MSK_PI_F / 2.f) - (x / y) * (MSK_PI_F / 4.f);
+    }
+    float s, c;
+    det_sincos(phi, &s, &c);
+    f2 o; o.x = r * c; o.y = r * s; return o;
+}
+MSK_DEV f3 square_to_cosine_hemisphere(f2 sample) {         // core/warp.h:34-43
+    f2 p = square_to_uniform_disk_concentric(sample);
+    float z = safe_sqrt(1.f - (p.x * p.x + p.y * p.y));
+    return mk3(p.x, p.y, z);
+}
+
+// core/spectrum.h:152-181, core/mathutils.h:166-182
+MSK_DEV float wavelength_of(float sample, int i) {
+    float shift = (float) i / 4.f;
+    float value = sample + shift;
+    float u = (value <= 1.f) ? value : value - 1.f;
+    return 538.f - det_atanh(0.8569106254698279f - 1.8275019724092267f * u) * 138.88888888888889f;
+}
+MSK_DEV float wavelength_weight(float lam) {
+    float tmp = det_cosh(0.0072f * (lam - 538.f));
+    return 253.82f * tmp * tmp;
+}
+
+// render/srgb.h:8-19
+MSK_DEV spec srgb_model_eval(float c0, float c1, float c2, spec wl) {
+    if (__builtin_isinf(c2)) return splat(__builtin_copysignf(1.f, c2) * .5f + .5f);
+    spec r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = (c0 * wl.v[i] + c1) * wl.v[i] + c2;
+        float rsqrt = 1.f / __builtin_sqrtf(v * v + 1.f);
+        r.v[i] = fmax_std(.5f * v * rsqrt + .5f, 0.f);
+    }
+    return r;
+}
+// spectra/regular.cpp:73-91 on a 95-entry table over [360,830]
+MSK_DEV spec regular_eval(const float *tbl, spec wl) {
+    spec r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float x = (wl.v[i] - 360.f) * 0.2f;
+        uint32_t idx = (uint32_t) x;
+        idx = idx < 93u ? idx : 93u;
+        float y0 = tbl[idx], y1 = tbl[idx + 1];
+        float w1 = x - (float) idx, w0 = 1.f - w1;
+        r.v[i] = w0 * y0 + w1 * y1;
+    }
+    return r;
+}
+// core/spectrum.h:82-115; cie = x[95] y[95] z[95]
+MSK_DEV void spectrum_to_xyz(const float *cie, spec value, spec wl, float *X, float *Y, float *Z) {
+    spec cx, cy, cz;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float t = (wl.v[s] - 360.f) * (94 / (830.f - 360.f));
+        uint32_t i0 = (uint32_t) t;
+        i0 = i0 < 93u ? i0 : 93u;
+        float w1 = t - (float) i0, w0 = 1.f - w1;
+        cx.v[s] = w0 * cie[i0] + w1 * cie[i0 + 1];
+        cy.v[s] = w0 * cie[95 + i0] + w1 * cie[95 + i0 + 1];
+        cz.v[s] = w0 * cie[190 + i0] + w1 * cie[190 + i0 + 1];
+    }
+    *X = mean4(cx * value); *Y = mean4(cy * value); *Z = mean4(cz * value);
+}
+
+MSK_DEV float mis_weight(float pdf_a, float pdf_b) {        // integrators/path.cpp:127-131
+    pdf_a *= pdf_a; pdf_b *= pdf_b;
+    return pdf_a > 0.f ? pdf_a / (pdf_a + pdf_b) : 0.f;
+}
+
+}  // namespace msk

@@ -1,0 +1,616 @@
+// msk_gpu.hip — implementation of the C ABI in include/msk_gpu.h (MI355X / gfx950 only).
+//
+// Host responsibilities of this file: scene upload + BVH build (replaces Scene::accel_init,
+// src/librender/scene.cpp:201-212), area-light tables (mesh.cpp:39-48), the spiral block
+// schedule (imageblock.cpp:176-247), the wavefront iteration loop, and the ordered film
+// resolve.  Everything per-sample runs in the kernels of msk_kernels.h.
+#include "msk_kernels.h"
+#include "msk_bvh.h"
+#include "../../include/msk_gpu.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace msk;
+
+static thread_local std::string g_last_error;
+
+struct msk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    std::string last_error;
+    Ctrl *h_ctrl = nullptr;            // pinned
+    std::vector<hipEvent_t> events;
+};
+
+static int fail(msk_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_last_error = buf;
+    if (ctx) ctx->last_error = buf;
+    return code;
+}
+#define HIP_TRY(ctx, expr)                                                                       \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess)                                          \
+        return fail(ctx, e_ == hipErrorOutOfMemory ? MSK_ERR_OOM : MSK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                    hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    ~DevBuf() { if (p) (void) hipFree(p); }
+    hipError_t alloc(size_t n) { if (p) (void) hipFree(p); p = nullptr; bytes = n; return n ? hipMalloc(&p, n) : hipSuccess; }
+    template <typename T> hipError_t upload(const std::vector<T> &v) {
+        hipError_t e = alloc(std::max<size_t>(v.size() * sizeof(T), 16));
+        if (e != hipSuccess) return e;
+        return v.empty() ? hipSuccess : hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    template <typename T> T *as() const { return (T *) p; }
+};
+
+struct msk_scene {
+    msk_ctx *ctx = nullptr;
+    DeviceScene dev;
+    DevBuf nodes, tris, tri_verts, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
+    bool lds_scene = false;
+    size_t trace_lds_bytes = 0;
+    int bvh_depth = 0;
+    uint32_t n_tris = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+extern "C" const char *msk_gpu_last_error(const msk_ctx *ctx) {
+    return ctx ? ctx->last_error.c_str() : g_last_error.c_str();
+}
+
+extern "C" int msk_gpu_init(const int *device_ids, int n, msk_ctx **out_ctx) {
+    if (!out_ctx) return fail(nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_init: out_ctx is NULL");
+    *out_ctx = nullptr;
+    if (n != 1 || !device_ids)
+        return fail(nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_init: exactly one device per context (got n=%d)", n);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail(nullptr, MSK_ERR_NO_DEVICE, "msk_gpu_init: no HIP device visible");
+    if (device_ids[0] < 0 || device_ids[0] >= count)
+        return fail(nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_init: device %d out of range (0..%d)", device_ids[0], count - 1);
+    msk_ctx *ctx = new msk_ctx();
+    ctx->device = device_ids[0];
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, ctx->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **) &ctx->h_ctrl, sizeof(Ctrl), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, MSK_ERR_HIP, "msk_gpu_init: %s", hipGetErrorString(e));
+        delete ctx;
+        return rc;
+    }
+    if (std::string(ctx->prop.gcnArchName).find("gfx950") == std::string::npos &&
+        !getenv("MSK_ALLOW_ANY_ARCH")) {
+        int rc = fail(nullptr, MSK_ERR_UNSUPPORTED, "msk_gpu_init: device is %s, this library is built for gfx950 only",
+                      ctx->prop.gcnArchName);
+        msk_gpu_shutdown(ctx);
+        return rc;
+    }
+    *out_ctx = ctx;
+    return MSK_OK;
+}
+
+extern "C" void msk_gpu_shutdown(msk_ctx *ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    for (auto ev : ctx->events) (void) hipEventDestroy(ev);
+    if (ctx->h_ctrl) (void) hipHostFree(ctx->h_ctrl);
+    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int msk_gpu_describe(const msk_ctx *ctx, char *buf, uint64_t buf_size) {
+    if (!ctx || !buf || !buf_size) return fail(nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_describe: bad argument");
+    snprintf(buf, (size_t) buf_size, "%s (%s), %d CUs, %.1f GiB HBM, LDS/block %zu KiB; libmsk_gpu ABI %d, fp-contract off",
+             ctx->prop.name, ctx->prop.gcnArchName, ctx->prop.multiProcessorCount,
+             ctx->prop.totalGlobalMem / 1073741824.0, ctx->prop.sharedMemPerBlock / 1024, MSK_ABI_VERSION);
+    return MSK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// scene
+// ------------------------------------------------------------------------------------------
+static inline float h_dot(const float *a, const float *b) { return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]); }
+
+extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_scene **out) {
+    if (!ctx || !d || !out) return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: NULL argument");
+    *out = nullptr;
+    if (d->abi_version != MSK_ABI_VERSION)
+        return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: abi_version %u != %u", d->abi_version, MSK_ABI_VERSION);
+    if (d->film.width <= 0 || d->film.height <= 0 || !(d->film.filter_radius > 0.f))
+        return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: invalid film %dx%d radius %g", d->film.width,
+                    d->film.height, d->film.filter_radius);
+    if (!d->cie1931_xyz || !d->d65) return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: spectral tables missing");
+    if ((d->n_faces && (!d->vertices || !d->faces)) || (d->n_meshes && !d->meshes))
+        return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: geometry arrays missing");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    // ---- validate + gather per-triangle data (operand shapes are checked here, on the host,
+    //      before any kernel can index with them)
+    std::vector<float> pos((size_t) d->n_faces * 9);
+    std::vector<float> tv((size_t) d->n_faces * 12), tn, tuv;
+    std::vector<int32_t> mesh_info((size_t) std::max(1u, d->n_meshes) * 4, 0);
+    bool any_normals = false, any_uvs = false;
+    for (uint32_t m = 0; m < d->n_meshes; ++m) {
+        const msk_mesh_desc &md = d->meshes[m];
+        if ((uint64_t) md.first_vertex + md.vertex_count > d->n_vertices || (uint64_t) md.first_face + md.face_count > d->n_faces)
+            return fail(ctx, MSK_ERR_INVALID_ARG, "mesh %u: vertex/face range exceeds the arrays", m);
+        if (md.bsdf_id < 0 || (uint32_t) md.bsdf_id >= d->n_bsdfs)
+            return fail(ctx, MSK_ERR_INVALID_ARG, "mesh %u: bsdf_id %d out of range", m, md.bsdf_id);
+        if (md.emitter_id >= (int32_t) d->n_emitters)
+            return fail(ctx, MSK_ERR_INVALID_ARG, "mesh %u: emitter_id %d out of range", m, md.emitter_id);
+        any_normals |= md.has_normals != 0; any_uvs |= md.has_texcoords != 0;
+    }
+    if (any_normals) tn.assign((size_t) d->n_faces * 12, 0.f);
+    if (any_uvs) tuv.assign((size_t) d->n_faces * 8, 0.f);
+    std::vector<uint8_t> covered(d->n_faces, 0);
+    std::vector<float> mesh_area(d->n_meshes, 0.f);
+    std::vector<std::vector<float>> mesh_cdf(d->n_meshes);
+    for (uint32_t m = 0; m < d->n_meshes; ++m) {
+        const msk_mesh_desc &md = d->meshes[m];
+        mesh_info[m * 4 + 0] = md.bsdf_id; mesh_info[m * 4 + 1] = md.emitter_id;
+        mesh_info[m * 4 + 2] = (md.has_normals ? 1 : 0) | (md.has_texcoords ? 2 : 0);
+        mesh_info[m * 4 + 3] = (int32_t) md.first_face;
+        // mesh.cpp:39-48 area_distr_build + core/distribution.h:88-96 (fp32, started from 0)
+        float surface_area = 0.f, run = 0.f;
+        std::vector<float> &cdf = mesh_cdf[m];
+        cdf.push_back(0.f);
+        for (uint32_t f = 0; f < md.face_count; ++f) {
+            const uint32_t g = md.first_face + f;
+            if (covered[g]) return fail(ctx, MSK_ERR_INVALID_ARG, "face %u belongs to two meshes", g);
+            covered[g] = 1;
+            const uint32_t *fi = d->faces + (size_t) g * 3;
+            const float *v[3];
+            for (int k = 0; k < 3; ++k) {
+                if (fi[k] >= md.vertex_count) return fail(ctx, MSK_ERR_INVALID_ARG, "mesh %u face %u: vertex index %u out of range", m, f, fi[k]);
+                v[k] = d->vertices + (size_t) (md.first_vertex + fi[k]) * 8;
+                for (int c = 0; c < 3; ++c) { pos[(size_t) g * 9 + k * 3 + c] = v[k][c]; tv[(size_t) g * 12 + k * 4 + c] = v[k][c]; }
+                if (any_normals) for (int c = 0; c < 3; ++c) tn[(size_t) g * 12 + k * 4 + c] = v[k][3 + c];
+            }
+            uint32_t mb = m; std::memcpy(&tv[(size_t) g * 12 + 3], &mb, 4);
+            if (any_uvs) {
+                float *u = &tuv[(size_t) g * 8];
+                u[0] = v[0][6]; u[1] = v[0][7]; u[2] = v[1][6]; u[3] = v[1][7]; u[4] = v[2][6]; u[5] = v[2][7];
+            }
+            // mesh.h:54-61 face_area = 0.5 * |(p1-p0) x (p2-p0)|
+            const float a[3] = {v[1][0] - v[0][0], v[1][1] - v[0][1], v[1][2] - v[0][2]};
+            const float b[3] = {v[2][0] - v[0][0], v[2][1] - v[0][1], v[2][2] - v[0][2]};
+            const float cr[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+            const float area = 0.5f * std::sqrt(h_dot(cr, cr));
+            surface_area += area;
+            run = (f == 0) ? area : run + area;
+            cdf.push_back(run);
+        }
+        if (md.face_count) { const float inv_sum = 1.f / cdf.back(); for (auto &c : cdf) c *= inv_sum; }
+        mesh_area[m] = surface_area;
+    }
+    for (uint32_t g = 0; g < d->n_faces; ++g)
+        if (!covered[g]) return fail(ctx, MSK_ERR_INVALID_ARG, "face %u belongs to no mesh", g);
+
+    std::vector<float> bsdfs((size_t) std::max(1u, d->n_bsdfs) * 4, 0.f);
+    for (uint32_t b = 0; b < d->n_bsdfs; ++b) {
+        if (d->bsdfs[b].type != MSK_BSDF_DIFFUSE)
+            return fail(ctx, MSK_ERR_UNSUPPORTED, "bsdf %u: type %d is not supported by this back end (diffuse only)", b, d->bsdfs[b].type);
+        for (int c = 0; c < 3; ++c) bsdfs[b * 4 + c] = d->bsdfs[b].reflectance[c];
+    }
+    std::vector<float> emitters((size_t) std::max(1u, d->n_emitters) * 8, 0.f), d65((size_t) std::max(1u, d->n_emitters) * 95, 0.f), cdf_all;
+    for (uint32_t e = 0; e < d->n_emitters; ++e) {
+        const msk_emitter_desc &ed = d->emitters[e];
+        if (ed.type != MSK_EMITTER_AREA) return fail(ctx, MSK_ERR_UNSUPPORTED, "emitter %u: type %d is not supported", e, ed.type);
+        if (ed.mesh_id < 0 || (uint32_t) ed.mesh_id >= d->n_meshes || d->meshes[ed.mesh_id].emitter_id != (int32_t) e)
+            return fail(ctx, MSK_ERR_INVALID_ARG, "emitter %u: mesh_id %d does not point back at it", e, ed.mesh_id);
+        const msk_mesh_desc &md = d->meshes[ed.mesh_id];
+        if (md.face_count == 0) return fail(ctx, MSK_ERR_INVALID_ARG, "emitter %u: its mesh has no faces", e);
+        float *o = &emitters[e * 8];
+        o[0] = ed.radiance[0]; o[1] = ed.radiance[1]; o[2] = ed.radiance[2];
+        o[3] = 1.f / mesh_area[ed.mesh_id];                               // mesh.cpp:129 ps.pdf
+        uint32_t meta[4] = {(uint32_t) ed.mesh_id, md.first_face, md.face_count, (uint32_t) cdf_all.size()};
+        std::memcpy(&o[4], meta, 16);
+        cdf_all.insert(cdf_all.end(), mesh_cdf[ed.mesh_id].begin(), mesh_cdf[ed.mesh_id].end());
+        for (int i = 0; i < 95; ++i) d65[e * 95 + i] = d->d65[i] * ed.d65_scale;   // d65.cpp:41-42
+    }
+    if (cdf_all.empty()) cdf_all.push_back(0.f);
+
+    mskbvh::Built bvh = mskbvh::build(pos.data(), d->n_faces);
+
+    msk_scene *s = new msk_scene();
+    s->ctx = ctx; s->n_tris = d->n_faces; s->bvh_depth = bvh.max_depth;
+    std::vector<float> cie(d->cie1931_xyz, d->cie1931_xyz + 3 * MSK_CIE_SAMPLES);
+    hipError_t e = hipSuccess;
+    auto up = [&](DevBuf &b, const std::vector<float> &v) { if (e == hipSuccess) e = b.upload(v); };
+    up(s->nodes, bvh.nodes); up(s->tris, bvh.tris); up(s->tri_verts, tv); up(s->tri_normals, tn); up(s->tri_uvs, tuv);
+    up(s->bsdfs, bsdfs); up(s->emitters, emitters); up(s->emitter_d65, d65); up(s->cdf, cdf_all); up(s->cie, cie);
+    if (e == hipSuccess) e = s->mesh_info.upload(mesh_info);
+    if (e != hipSuccess) { delete s; return fail(ctx, e == hipErrorOutOfMemory ? MSK_ERR_OOM : MSK_ERR_HIP, "scene upload: %s", hipGetErrorString(e)); }
+
+    DeviceScene &ds = s->dev;
+    std::memset(&ds, 0, sizeof ds);
+    ds.nodes = s->nodes.as<float4>(); ds.tris = s->tris.as<float4>(); ds.tri_verts = s->tri_verts.as<float4>();
+    ds.tri_normals = any_normals ? s->tri_normals.as<float4>() : nullptr;
+    ds.tri_uvs = any_uvs ? s->tri_uvs.as<float4>() : nullptr;
+    ds.mesh_info = s->mesh_info.as<int4>(); ds.bsdfs = s->bsdfs.as<float4>(); ds.emitters = s->emitters.as<float4>();
+    ds.emitter_d65 = s->emitter_d65.as<float>(); ds.cdf = s->cdf.as<float>(); ds.cie = s->cie.as<float>();
+    ds.n_nodes = (uint32_t) (bvh.nodes.size() / 16); ds.n_tris = d->n_faces; ds.n_emitters = d->n_emitters;
+    ds.root_ref = bvh.root_ref;
+    ds.stack_entries = (uint32_t) ((bvh.max_depth + 2 + 3) & ~3);
+    std::memcpy(ds.s2c, d->camera.sample_to_camera, 64); std::memcpy(ds.to_world, d->camera.to_world, 64);
+    ds.near_clip = d->camera.near_clip; ds.far_clip = d->camera.far_clip;
+    ds.width = d->film.width; ds.height = d->film.height;
+    ds.filter_radius = d->film.filter_radius;
+    ds.filter_scale = float(MSK_FILTER_RESOLUTION) / d->film.filter_radius;           // rfilter.cpp:21
+    ds.filter_border = (int) std::ceil(d->film.filter_radius - .5f);                  // rfilter.cpp:22
+    std::memcpy(ds.lut, d->film.filter_lut, sizeof ds.lut);
+    // LDS plan of k_trace: per-lane stack + (when it fits) the whole BVH
+    const size_t stack_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4;
+    const size_t scene_bytes = ((size_t) ds.n_nodes + ds.n_tris) * 64;
+    const size_t lds_cap = getenv("MSK_LDS_SCENE_KB") ? (size_t) atoi(getenv("MSK_LDS_SCENE_KB")) * 1024 : 48 * 1024;
+    s->lds_scene = scene_bytes <= lds_cap && stack_bytes + scene_bytes <= 64 * 1024;
+    s->trace_lds_bytes = stack_bytes + (s->lds_scene ? scene_bytes : 0);
+    if (s->trace_lds_bytes > ctx->prop.sharedMemPerBlock) {
+        delete s;
+        return fail(ctx, MSK_ERR_UNSUPPORTED, "BVH depth %d needs %zu B of traversal stack per block", bvh.max_depth, stack_bytes);
+    }
+    *out = s;
+    return MSK_OK;
+}
+
+extern "C" void msk_gpu_scene_destroy(msk_scene *scene) {
+    if (!scene) return;
+    (void) hipSetDevice(scene->ctx->device);
+    delete scene;
+}
+
+// ------------------------------------------------------------------------------------------
+// spiral block schedule — BlockGenerator (imageblock.cpp:176-247)
+// ------------------------------------------------------------------------------------------
+struct HostBlock { int off_x, off_y, size_x, size_y, bx, by; };
+static std::vector<HostBlock> spiral_blocks(int w, int h, int bs, int *nbx, int *nby) {
+    const int bx = (int) std::ceil(w / (float) bs), by = (int) std::ceil(h / (float) bs);
+    *nbx = bx; *nby = by;
+    const int count = bx * by;
+    std::vector<HostBlock> out;
+    out.reserve(count);
+    int dir = 0, px = bx / 2, py = by / 2, steps_left = 1, steps = 1;
+    for (int counter = 0; counter < count;) {
+        const int ox = px * bs, oy = py * bs;
+        out.push_back(HostBlock{ox, oy, std::min(w - ox, bs), std::min(h - oy, bs), px, py});
+        ++counter;
+        if (counter == count) break;
+        do {
+            switch (dir) { case 0: ++px; break; case 1: ++py; break; case 2: --px; break; default: --py; break; }
+            if (--steps_left == 0) {
+                dir = (dir + 1) % 4;
+                if (dir == 2 || dir == 0) ++steps;
+                steps_left = steps;
+            }
+        } while (px < 0 || py < 0 || px >= bx || py >= by);
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------
+// wavefront driver
+// ------------------------------------------------------------------------------------------
+struct StateBufs {
+    DevBuf id, wl, thr, res, ray_o, ray_d, sh, contrib, hit, bs_pdf, flags, counts, ctrl;
+    PathState st;
+    hipError_t alloc(size_t n, uint32_t n_regions) {
+        hipError_t e;
+#define A_(b, sz) if ((e = b.alloc(n * (sz))) != hipSuccess) return e;
+        A_(id, 8) A_(wl, 16) A_(thr, 16) A_(res, 16) A_(ray_o, 16) A_(ray_d, 16) A_(sh, 16) A_(contrib, 16) A_(hit, 16)
+        A_(bs_pdf, 4) A_(flags, 4)
+#undef A_
+        if ((e = counts.alloc((size_t) n_regions * 4)) != hipSuccess) return e;
+        if ((e = ctrl.alloc(sizeof(Ctrl))) != hipSuccess) return e;
+        st.id = id.as<uint2>(); st.wl = wl.as<float4>(); st.thr = thr.as<float4>(); st.res = res.as<float4>();
+        st.ray_o = ray_o.as<float4>(); st.ray_d = ray_d.as<float4>(); st.sh = sh.as<float4>();
+        st.contrib = contrib.as<float4>(); st.hit = hit.as<float4>(); st.bs_pdf = bs_pdf.as<float>();
+        st.flags = flags.as<uint32_t>();
+        return hipSuccess;
+    }
+};
+
+static uint32_t env_u32(const char *name, uint32_t def) {
+    const char *v = getenv(name);
+    return v && *v ? (uint32_t) strtoul(v, nullptr, 10) : def;
+}
+
+struct EventPool {
+    msk_ctx *ctx; size_t next = 0;
+    hipEvent_t get() {
+        if (next == ctx->events.size()) { hipEvent_t e; (void) hipEventCreate(&e); ctx->events.push_back(e); }
+        return ctx->events[next++];
+    }
+};
+
+static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st, const PassParams &pp) {
+    const uint32_t grid = (pp.n_regions * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
+    if (sc->lds_scene) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp);
+    else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp);
+}
+
+// Renders the samples of `pix` (pass pixel table, host) into records; leaves records on device.
+static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_params *prm, uint32_t spp_owned,
+                         const uint32_t *d_pix, uint64_t n_pix, float4 *rec_a, float *rec_b, StateBufs &sb,
+                         uint32_t region_size, uint32_t n_regions, msk_stats *stats, EventPool &ev,
+                         std::vector<std::pair<hipEvent_t, hipEvent_t>> &ev_trace,
+                         std::vector<std::pair<hipEvent_t, hipEvent_t>> &ev_shade) {
+    msk_ctx *ctx = sc->ctx;
+    const unsigned long long total = (unsigned long long) n_pix * spp_owned;
+    Ctrl init; std::memset(&init, 0, sizeof init);
+    init.total_samples = total;
+    HIP_TRY(ctx, hipMemcpyAsync(sb.ctrl.p, &init, sizeof init, hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipMemsetAsync(sb.counts.p, 0, (size_t) n_regions * 4, stream));
+    PassParams pp;
+    pp.seed = prm->seed; pp.spp_owned = spp_owned; pp.sample_first = prm->sample_first;
+    pp.sample_stride = prm->sample_stride ? prm->sample_stride : 1;
+    pp.rr_depth = prm->rr_depth; pp.max_depth = prm->max_depth; pp.hide_emitters = prm->hide_emitters;
+    pp.pix_table = d_pix; pp.rec_a = rec_a; pp.rec_b = rec_b;
+    pp.region_size = region_size; pp.n_regions = n_regions; pp.counts = sb.counts.as<uint32_t>();
+    const uint32_t grid = (n_regions * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
+    const uint32_t group = env_u32("MSK_SYNC_GROUP", 8);
+    const bool timing = stats != nullptr;
+    uint32_t it = 0;
+    for (;;) {
+        for (uint32_t g = 0; g < group; ++g, ++it) {
+            hipEvent_t a = nullptr, b = nullptr, c = nullptr;
+            if (timing) { a = ev.get(); b = ev.get(); c = ev.get(); (void) hipEventRecord(a, stream); }
+            hipLaunchKernelGGL(k_shade_gen, dim3(grid), dim3(MSK_BLOCK), 0, stream, sc->dev, sb.st, pp, sb.ctrl.as<Ctrl>(), it & 1u);
+            if (timing) (void) hipEventRecord(b, stream);
+            launch_trace(sc, stream, sb.st, pp);
+            if (timing) { (void) hipEventRecord(c, stream); ev_shade.push_back({a, b}); ev_trace.push_back({b, c}); }
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctrl, sb.ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        const Ctrl &h = *ctx->h_ctrl;
+        if (h.next_sample >= total && h.live[(it - 1) & 1u] == 0) break;
+        if (it > 100000000u) return fail(ctx, MSK_ERR_HIP, "wavefront loop did not terminate");
+    }
+    if (stats) {
+        stats->samples += ctx->h_ctrl->samples_done;
+        stats->segments += ctx->h_ctrl->segments;
+        stats->shadow_rays += ctx->h_ctrl->shadow_rays;
+        stats->iterations += it;
+    }
+    if (ctx->h_ctrl->samples_done != total)
+        return fail(ctx, MSK_ERR_HIP, "internal error: %llu of %llu samples finished", ctx->h_ctrl->samples_done, total);
+    return MSK_OK;
+}
+
+static int check_params(msk_ctx *ctx, const msk_render_params *p, int block_min) {
+    if (!p) return fail(ctx, MSK_ERR_INVALID_ARG, "render params are NULL");
+    if (p->rng_mode != MSK_RNG_COUNTER)
+        return fail(ctx, MSK_ERR_UNSUPPORTED, "rng_mode %d: the GPU back end implements MSK_RNG_COUNTER only "
+                    "(a per-block PCG32 stream is sequential by construction)", p->rng_mode);
+    if (p->spp == 0) return fail(ctx, MSK_ERR_INVALID_ARG, "spp must be > 0");
+    if (p->rr_depth <= 0) return fail(ctx, MSK_ERR_INVALID_ARG, "\"rr_depth\" must be set to a value greater than zero!");
+    if (p->max_depth < 0 && p->max_depth != -1)
+        return fail(ctx, MSK_ERR_INVALID_ARG, "\"max_depth\" must be set to -1 (infinite) or a value >= 0");
+    if (p->block_size < block_min || p->block_size > 64)
+        return fail(ctx, MSK_ERR_INVALID_ARG, "block_size %d outside [%d, 64]", p->block_size, block_min);
+    const uint32_t bs = p->block_stride ? p->block_stride : 1, ss = p->sample_stride ? p->sample_stride : 1;
+    if (p->block_first >= bs || p->sample_first >= ss) return fail(ctx, MSK_ERR_INVALID_ARG, "shard selector out of range");
+    return MSK_OK;
+}
+
+static uint32_t owned_spp(const msk_render_params *p) {
+    const uint32_t ss = p->sample_stride ? p->sample_stride : 1;
+    return p->sample_first < p->spp ? (p->spp - p->sample_first + ss - 1) / ss : 0;
+}
+
+static void pool_shape(uint64_t total_samples, uint32_t *region_size, uint32_t *n_regions) {
+    uint32_t rs = env_u32("MSK_REGION_SIZE", 512), nr = env_u32("MSK_REGIONS", 4096);
+    rs = std::max(64u, (rs + 63u) & ~63u);
+    const uint64_t need = (total_samples + rs - 1) / rs;
+    if (need < nr) nr = (uint32_t) std::max<uint64_t>(need, 1);
+    nr = (nr + 3u) & ~3u;
+    *region_size = rs; *n_regions = nr;
+}
+
+static void sum_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, float *ms) {
+    for (auto &p : v) { float t = 0; if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) *ms += t; }
+}
+
+static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_film, hipStream_t user_stream, msk_stats *stats) {
+    msk_ctx *ctx = sc->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int border = sc->dev.filter_border;
+    int rc = check_params(ctx, prm, std::max(4, 2 * border));
+    if (rc) return rc;
+    hipStream_t stream = user_stream ? user_stream : ctx->stream;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    EventPool ev{ctx, 0};
+    hipEvent_t t_begin = ev.get(), t_end = ev.get();
+    (void) hipEventRecord(t_begin, stream);
+    const int W = sc->dev.width, H = sc->dev.height, bs = prm->block_size;
+    int nbx, nby;
+    std::vector<HostBlock> all = spiral_blocks(W, H, bs, &nbx, &nby);
+    const uint32_t bstride = prm->block_stride ? prm->block_stride : 1;
+    const uint32_t spp_owned = owned_spp(prm);
+    std::vector<int32_t> block_of((size_t) nbx * nby, -1);
+    std::vector<uint32_t> spiral_id((size_t) nbx * nby, 0);
+    std::vector<BlockInfo> owned;
+    std::vector<size_t> owned_all_index;
+    for (size_t id = 0; id < all.size(); ++id) {
+        spiral_id[(size_t) all[id].by * nbx + all[id].bx] = (uint32_t) id;
+        if (id % bstride != prm->block_first || spp_owned == 0) continue;
+        block_of[(size_t) all[id].by * nbx + all[id].bx] = (int32_t) owned.size();
+        owned.push_back(BlockInfo{all[id].off_x, all[id].off_y, all[id].size_x, all[id].size_y, 0u, (uint32_t) owned.size()});
+        owned_all_index.push_back(id);
+    }
+    const uint32_t per_block = (uint32_t) ((bs + 2 * border) * (bs + 2 * border));
+    const uint32_t buf_stride = per_block * 5;
+    DevBuf d_block_buf, d_blocks, d_block_of, d_spiral;
+    HIP_TRY(ctx, d_block_buf.alloc(std::max<size_t>(owned.size(), 1) * buf_stride * 4));
+    // ---- plan passes: consecutive owned blocks whose records fit the budget
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+    uint32_t region_size, n_regions;
+    uint64_t all_samples = 0;
+    for (auto &b : owned) all_samples += (uint64_t) b.size_x * b.size_y * spp_owned;
+    pool_shape(all_samples, &region_size, &n_regions);
+    const size_t n_slots = (size_t) region_size * n_regions;
+    const size_t state_bytes = n_slots * 144 + 4096;
+    size_t budget = getenv("MSK_RECORD_BUDGET_MB") ? (size_t) atoll(getenv("MSK_RECORD_BUDGET_MB")) << 20
+                                                   : (free_b > state_bytes ? (size_t) ((free_b - state_bytes) * 0.8) : 0);
+    const size_t rec_bytes_per_block_max = (size_t) bs * bs * spp_owned * 20;
+    if (!owned.empty() && budget < rec_bytes_per_block_max)
+        return fail(ctx, MSK_ERR_OOM, "not enough HBM for one block of sample records (%zu B needed, %zu B budget)",
+                    rec_bytes_per_block_max, budget);
+    std::vector<std::pair<size_t, size_t>> passes;   // [b0, b1) over `owned`
+    for (size_t b0 = 0; b0 < owned.size();) {
+        size_t b1 = b0, bytes = 0; uint32_t pixel_base = 0;
+        while (b1 < owned.size()) {
+            const size_t add = (size_t) owned[b1].size_x * owned[b1].size_y * spp_owned * 20;
+            if (b1 > b0 && bytes + add > budget) break;
+            owned[b1].pixel_base = pixel_base; pixel_base += (uint32_t) (owned[b1].size_x * owned[b1].size_y);
+            bytes += add; ++b1;
+        }
+        passes.push_back({b0, b1}); b0 = b1;
+    }
+    HIP_TRY(ctx, d_blocks.upload(owned)); HIP_TRY(ctx, d_block_of.upload(block_of)); HIP_TRY(ctx, d_spiral.upload(spiral_id));
+    StateBufs sb;
+    if (!owned.empty()) HIP_TRY(ctx, sb.alloc(n_slots, n_regions));
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_trace, ev_shade, ev_resolve;
+    DevBuf d_pix, d_rec_a, d_rec_b;
+    for (auto &ps : passes) {
+        std::vector<uint32_t> pix;
+        for (size_t b = ps.first; b < ps.second; ++b)
+            for (int y = 0; y < owned[b].size_y; ++y)
+                for (int x = 0; x < owned[b].size_x; ++x)
+                    pix.push_back((uint32_t) ((owned[b].off_y + y) * W + owned[b].off_x + x));
+        const uint64_t n_rec = (uint64_t) pix.size() * spp_owned;
+        HIP_TRY(ctx, d_pix.upload(pix));
+        if (d_rec_a.bytes < n_rec * 16) { HIP_TRY(ctx, d_rec_a.alloc(n_rec * 16)); HIP_TRY(ctx, d_rec_b.alloc(n_rec * 4)); }
+        rc = run_wavefront(sc, stream, prm, spp_owned, d_pix.as<uint32_t>(), pix.size(), d_rec_a.as<float4>(),
+                           d_rec_b.as<float>(), sb, region_size, n_regions, stats, ev, ev_trace, ev_shade);
+        if (rc) return rc;
+        const uint32_t nb = (uint32_t) (ps.second - ps.first);
+        const uint64_t threads = (uint64_t) nb * per_block;
+        hipEvent_t a = ev.get(), b = ev.get();
+        (void) hipEventRecord(a, stream);
+        hipLaunchKernelGGL(k_resolve_blocks, dim3((uint32_t) ((threads + MSK_BLOCK - 1) / MSK_BLOCK)), dim3(MSK_BLOCK), 0, stream,
+                           sc->dev, d_blocks.as<BlockInfo>() + ps.first, nb, d_rec_a.as<float4>(), d_rec_b.as<float>(),
+                           spp_owned, d_block_buf.as<float>(), buf_stride);
+        (void) hipEventRecord(b, stream);
+        ev_resolve.push_back({a, b});
+        HIP_TRY(ctx, hipStreamSynchronize(stream));   // d_pix / records are reused by the next pass
+        if (stats) stats->passes++;
+    }
+    {
+        hipEvent_t a = ev.get(), b = ev.get();
+        (void) hipEventRecord(a, stream);
+        hipLaunchKernelGGL(k_film_put, dim3((uint32_t) (((size_t) W * H + MSK_BLOCK - 1) / MSK_BLOCK)), dim3(MSK_BLOCK), 0, stream,
+                           sc->dev, d_blocks.as<BlockInfo>(), d_block_of.as<int32_t>(), d_spiral.as<uint32_t>(), nbx, nby, bs,
+                           d_block_buf.as<float>(), buf_stride, d_film);
+        (void) hipEventRecord(b, stream);
+        ev_resolve.push_back({a, b});
+    }
+    (void) hipEventRecord(t_end, stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    if (stats) {
+        (void) hipEventElapsedTime(&stats->ms_total, t_begin, t_end);
+        sum_events(ev_trace, &stats->ms_trace); sum_events(ev_shade, &stats->ms_shade); sum_events(ev_resolve, &stats->ms_resolve);
+        stats->n_trace_launches = (uint32_t) ev_trace.size(); stats->n_shade_launches = (uint32_t) ev_shade.size();
+    }
+    return MSK_OK;
+}
+
+extern "C" int msk_gpu_render_device(msk_scene *scene, const msk_render_params *params, float *d_film_xyzaw, void *hip_stream,
+                                     msk_stats *stats) {
+    if (!scene || !d_film_xyzaw) return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_render_device: NULL argument");
+    return render_impl(scene, params, d_film_xyzaw, (hipStream_t) hip_stream, stats);
+}
+
+extern "C" int msk_gpu_render(msk_scene *scene, const msk_render_params *params, float *film_xyzaw, msk_stats *stats) {
+    if (!scene || !film_xyzaw) return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_render: NULL argument");
+    msk_ctx *ctx = scene->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf film;
+    const size_t bytes = (size_t) scene->dev.width * scene->dev.height * 5 * 4;
+    HIP_TRY(ctx, film.alloc(bytes));
+    int rc = render_impl(scene, params, film.as<float>(), nullptr, stats);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(film_xyzaw, film.p, bytes, hipMemcpyDeviceToHost));
+    return MSK_OK;
+}
+
+extern "C" int msk_gpu_sample_pixels(msk_scene *scene, const msk_render_params *prm, uint64_t n_pixels, const int32_t *pixels,
+                                     float *out_xyz, float *out_pos) {
+    if (!scene || !pixels || !out_xyz) return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_sample_pixels: NULL argument");
+    msk_ctx *ctx = scene->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = check_params(ctx, prm, 1);
+    if (rc) return rc;
+    const int W = scene->dev.width, H = scene->dev.height;
+    std::vector<uint32_t> pix(n_pixels);
+    for (uint64_t i = 0; i < n_pixels; ++i) {
+        const int x = pixels[2 * i], y = pixels[2 * i + 1];
+        if (x < 0 || y < 0 || x >= W || y >= H) return fail(ctx, MSK_ERR_INVALID_ARG, "pixel (%d,%d) outside the %dx%d film", x, y, W, H);
+        pix[i] = (uint32_t) (y * W + x);
+    }
+    if (n_pixels == 0) return MSK_OK;
+    msk_render_params p = *prm; p.sample_first = 0; p.sample_stride = 1;
+    const uint64_t n_rec = n_pixels * p.spp;
+    uint32_t region_size, n_regions;
+    pool_shape(n_rec, &region_size, &n_regions);
+    StateBufs sb; DevBuf d_pix, ra, rb, ox, op;
+    HIP_TRY(ctx, sb.alloc((size_t) region_size * n_regions, n_regions));
+    HIP_TRY(ctx, d_pix.upload(pix)); HIP_TRY(ctx, ra.alloc(n_rec * 16)); HIP_TRY(ctx, rb.alloc(n_rec * 4));
+    HIP_TRY(ctx, ox.alloc(n_rec * 12)); HIP_TRY(ctx, op.alloc(n_rec * 8));
+    EventPool ev{ctx, 0};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> e1, e2;
+    rc = run_wavefront(scene, ctx->stream, &p, p.spp, d_pix.as<uint32_t>(), n_pixels, ra.as<float4>(), rb.as<float>(), sb,
+                       region_size, n_regions, nullptr, ev, e1, e2);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_export_records, dim3((uint32_t) ((n_rec + 255) / 256)), dim3(256), 0, ctx->stream, ra.as<float4>(),
+                       rb.as<float>(), n_rec, ox.as<float>(), op.as<float>());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out_xyz, ox.p, n_rec * 12, hipMemcpyDeviceToHost));
+    if (out_pos) HIP_TRY(ctx, hipMemcpy(out_pos, op.p, n_rec * 8, hipMemcpyDeviceToHost));
+    return MSK_OK;
+}
+
+static int trace_batch(msk_scene *scene, uint64_t n, const float *rays, float *out_hit, uint8_t *out_any) {
+    msk_ctx *ctx = scene->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return MSK_OK;
+    DevBuf d_rays, d_out;
+    HIP_TRY(ctx, d_rays.alloc(n * 32)); HIP_TRY(ctx, d_out.alloc(out_any ? n : n * 16));
+    HIP_TRY(ctx, hipMemcpy(d_rays.p, rays, n * 32, hipMemcpyHostToDevice));
+    const uint32_t grid = (uint32_t) std::min<uint64_t>((n + MSK_BLOCK - 1) / MSK_BLOCK, 4096);
+    float4 *oh = out_any ? nullptr : d_out.as<float4>();
+    uint8_t *oa = out_any ? d_out.as<uint8_t>() : nullptr;
+    if (scene->lds_scene)
+        hipLaunchKernelGGL(k_trace_batch<true>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
+                           d_rays.as<float4>(), n, oh, oa);
+    else
+        hipLaunchKernelGGL(k_trace_batch<false>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
+                           d_rays.as<float4>(), n, oh, oa);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out_any ? (void *) out_any : (void *) out_hit, d_out.p, out_any ? n : n * 16, hipMemcpyDeviceToHost));
+    return MSK_OK;
+}
+
+extern "C" int msk_gpu_trace_closest(msk_scene *scene, uint64_t n, const float *rays, float *out_hit) {
+    if (!scene || (n && (!rays || !out_hit))) return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_trace_closest: NULL argument");
+    return trace_batch(scene, n, rays, out_hit, nullptr);
+}
+extern "C" int msk_gpu_trace_any(msk_scene *scene, uint64_t n, const float *rays, uint8_t *out_occluded) {
+    if (!scene || (n && (!rays || !out_occluded))) return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_trace_any: NULL argument");
+    return trace_batch(scene, n, rays, nullptr, out_occluded);
+}

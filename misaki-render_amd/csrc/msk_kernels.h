@@ -1,0 +1,646 @@
+// msk_kernels.h — device data layout + the wavefront kernels (gfx950, wave64).
+//
+// Pipeline.  Path state lives in HBM as structure-of-arrays, split into
+// per-wave REGIONS of `region_size` slots.  One wavefront iteration = two launches:
+//
+//   k_shade_gen  wave w sweeps its region 64 slots at a time: finishes the previous bounce of
+//                every path (emitter hit + MIS, Russian roulette), runs the next bounce's
+//                NEE + BSDF sampling (PathTracer::sample body, path.cpp:33-123), writes a sample
+//                record for every finished path, compacts the survivors to the front of the
+//                region IN PLACE with a wave ballot + prefix popcount (no LDS, no block
+//                barrier, no global queue atomic), then refills the free tail of the region
+//                with new camera samples (render_sample, integrator.cpp:103-116) taken from
+//                one global cursor (one atomic per wave per iteration).
+//   k_trace      per live slot: the pending shadow ray (Scene::ray_test, scene.cpp:255-273) and
+//                the extension ray (Scene::ray_intersect, scene.cpp:216-253) against the
+//                flattened BVH, nodes + triangles staged in LDS when the scene is small.
+//
+// After the last iteration k_resolve_blocks / k_film_put rebuild the film from the per-sample
+// records in exactly the order ImageBlock::put / Film::put accumulate them
+// (imageblock.cpp:55-114, 133-173), so the film is bit-identical to the scalar CPU order.
+#pragma once
+#include "msk_device.h"
+
+namespace msk {
+
+#define MSK_WAVE 64
+#define MSK_BLOCK 256
+#define MSK_LEAF_BIT 0x80000000u  /* child ref: leaf = BIT | first_tri << 5 | count ; inner = node index */
+#define MSK_NO_PRIM 0xffffffffu
+#define MSK_FLAG_SHADOW 0x10000u
+#define MSK_DEPTH_MASK 0xffffu
+
+struct DeviceScene {
+    const float4 *nodes;        // 4 x float4 per node (msk_bvh.h)
+    const float4 *tris;         // 4 x float4 per triangle, leaf order
+    const float4 *tri_verts;    // 3 x float4 per triangle, scene-global order: p0|mesh p1|- p2|-
+    const float4 *tri_normals;  // 3 x float4 per triangle (n0 n1 n2) or nullptr
+    const float4 *tri_uvs;      // 2 x float4 per triangle (uv0 uv1 | uv2 -) or nullptr
+    const int4 *mesh_info;      // {bsdf_id, emitter_id, flags(1=normals,2=texcoords), first_face}
+    const float4 *bsdfs;        // per bsdf: {c0,c1,c2,type}
+    const float4 *emitters;     // 2 x float4 per emitter: {c0,c1,c2,inv_area} {mesh,first_face,face_count,cdf_off (uint bits)}
+    const float *emitter_d65;   // 95 floats per emitter (d65 * d65_scale)
+    const float *cdf;           // concatenated area CDFs (face_count+1 each)
+    const float *cie;           // 285 floats
+    uint32_t n_nodes, n_tris, n_emitters;
+    uint32_t root_ref;          // packed child ref of the root
+    uint32_t stack_entries;     // per-lane traversal stack depth (BVH depth + 2)
+    float s2c[16], to_world[16];
+    float near_clip, far_clip;
+    int32_t width, height;
+    float filter_radius, filter_scale;
+    int32_t filter_border;
+    float lut[33];
+};
+
+struct PathState {
+    uint2 *id;          // {pixel-in-pass index j, owned-sample index si}
+    float4 *wl, *thr, *res;
+    float4 *ray_o;      // o.xyz, tmin
+    float4 *ray_d;      // d.xyz, tmax
+    float4 *sh;         // shadow d.xyz, tmax
+    float4 *contrib;    // NEE contribution added when the shadow ray is unoccluded
+    float4 *hit;        // t,u,v,prim
+    float *bs_pdf;
+    uint32_t *flags;    // depth | MSK_FLAG_SHADOW
+};
+
+struct Ctrl {
+    unsigned long long next_sample, total_samples;
+    unsigned long long live[2];
+    unsigned long long segments, shadow_rays, samples_done;
+};
+
+struct PassParams {
+    uint64_t seed;
+    uint32_t spp_owned, sample_first, sample_stride;
+    int32_t rr_depth, max_depth, hide_emitters;
+    const uint32_t *pix_table;    // pass pixel j -> film linear index y*W+x
+    float4 *rec_a;                // per sample {X,Y,Z,pos.x}
+    float *rec_b;                 // per sample pos.y
+    uint32_t region_size, n_regions;
+    uint32_t *counts;             // live slots per region
+};
+
+// ------------------------------------------------------------------------------------------
+// traversal
+// ------------------------------------------------------------------------------------------
+MSK_DEV float xor_sign(float a, uint32_t s) { return __uint_as_float(__float_as_uint(a) ^ s); }
+
+// Embree 3 Moeller-Trumbore, restated (see oracle/oracle.cpp header for the derivation);
+// tmax is the ray's ORIGINAL far bound.
+MSK_DEV bool tri_test(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, float tmin, float tmax,
+                      float *t, float *u, float *v) {
+    const f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z),
+             ng = mk3(q3.x, q3.y, q3.z);
+    const f3 C = v0 - o;
+    const f3 R = cross(C, d);
+    const float den = dot(ng, d);
+    const float abs_den = fabsf(den);
+    const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
+    const float U = xor_sign(dot(R, e2), sgn);
+    const float V = xor_sign(dot(R, e1), sgn);
+    if (!(den != 0.f && U >= 0.f && V >= 0.f && U + V <= abs_den)) return false;
+    const float T = xor_sign(dot(ng, C), sgn);
+    if (!(abs_den * tmin < T && T <= abs_den * tmax)) return false;
+    const float rcp = 1.f / abs_den;
+    *t = T * rcp;
+    *u = fmin_std(U * rcp, 1.f);
+    *v = fmin_std(V * rcp, 1.f);
+    return true;
+}
+
+// conservative slab test, fma form t = b*idir - o*idir with idir clamped to +-1e25 by the caller
+// (no infinities -> no NaNs; an axis-parallel ray sees +-huge instead of +-inf)
+MSK_DEV bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 idir, f3 oi,
+                      float tmin, float tcur, float *tnear) {
+    float ax = __fmaf_rn(lox, idir.x, -oi.x), bx = __fmaf_rn(hix, idir.x, -oi.x);
+    float ay = __fmaf_rn(loy, idir.y, -oi.y), by = __fmaf_rn(hiy, idir.y, -oi.y);
+    float az = __fmaf_rn(loz, idir.z, -oi.z), bz = __fmaf_rn(hiz, idir.z, -oi.z);
+    float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tcur));
+    *tnear = t0;
+    return t0 <= t1 * 1.0000004f;
+}
+
+// ANY: returns true on the first accepted triangle.  Closest: keeps (t, prim)-minimal hit.
+// nodes/tris may point into LDS or HBM.  stack: this lane's LDS stack, stride MSK_BLOCK.
+template <bool ANY>
+MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict__ tris, uint32_t root_ref,
+                      uint32_t n_tris, f3 o, f3 d, float tmin, float tmax, uint32_t *stack, float *best_t, float *best_u,
+                      float *best_v, uint32_t *best_prim) {
+    float bt = tmax, bu = 0.f, bv = 0.f;
+    uint32_t bp = MSK_NO_PRIM;
+    if (n_tris == 0) { *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp; return false; }
+    const f3 idir = mk3(fminf(fmaxf(1.f / d.x, -1e25f), 1e25f), fminf(fmaxf(1.f / d.y, -1e25f), 1e25f),
+                        fminf(fmaxf(1.f / d.z, -1e25f), 1e25f));
+    const f3 oi = mk3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
+    int sp = 0;
+    uint32_t cur = root_ref;
+    for (;;) {
+        if (cur & MSK_LEAF_BIT) {
+            const uint32_t first = (cur & 0x7fffffffu) >> 5, cnt = cur & 31u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const float4 *q = tris + (size_t) (first + i) * 4;
+                float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                float t, u, v;
+                if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v)) {
+                    if (ANY) return true;
+                    uint32_t prim = __float_as_uint(q0.w);
+                    if (t < bt || (t == bt && prim < bp)) { bt = t; bu = u; bv = v; bp = prim; }
+                }
+            }
+        } else {
+            const float4 *n = nodes + (size_t) cur * 4;
+            float4 a = n[0], b = n[1], c = n[2], m = n[3];
+            float t0, t1;
+            bool h0 = box_test(a.x, a.y, a.z, a.w, b.x, b.y, idir, oi, tmin, bt, &t0);
+            bool h1 = box_test(b.z, b.w, c.x, c.y, c.z, c.w, idir, oi, tmin, bt, &t1);
+            const uint32_t c0 = __float_as_uint(m.x), c1 = __float_as_uint(m.y);
+            if (h0 && h1) {
+                const bool swap = t1 < t0;            // nearer child first, the other one on the stack
+                cur = swap ? c1 : c0;
+                stack[sp * MSK_BLOCK] = swap ? c0 : c1; sp += 1;
+                continue;
+            } else if (h0) { cur = c0; continue; }
+            else if (h1) { cur = c1; continue; }
+        }
+        if (sp == 0) break;
+        sp -= 1;
+        cur = stack[sp * MSK_BLOCK];
+    }
+    *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
+    return false;
+}
+
+struct TraceLds {
+    const float4 *nodes, *tris;
+};
+
+// stage nodes + triangles into dynamic LDS (all threads of the block)
+MSK_DEV TraceLds stage_scene(const DeviceScene &sc, float4 *lds, bool use_lds) {
+    TraceLds r;
+    if (!use_lds) { r.nodes = sc.nodes; r.tris = sc.tris; return r; }
+    const uint32_t nn = sc.n_nodes * 4, nt = sc.n_tris * 4;
+    for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) lds[i] = sc.nodes[i];
+    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[nn + i] = sc.tris[i];
+    __syncthreads();
+    r.nodes = lds; r.tris = lds + nn;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_trace
+// ------------------------------------------------------------------------------------------
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(MSK_BLOCK)
+k_trace(DeviceScene sc, PathState st, PassParams pp) {
+    extern __shared__ float4 lds_dyn[];
+    uint32_t *stack_base = (uint32_t *) lds_dyn;                         // stack_entries * MSK_BLOCK words
+    float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
+    TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE);
+    uint32_t *stack = stack_base + threadIdx.x;
+    const uint32_t wave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
+    const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
+    if (wave >= pp.n_regions) return;
+    const uint32_t n = pp.counts[wave];
+    const size_t base = (size_t) wave * pp.region_size;
+    for (uint32_t c = lane; c < n; c += MSK_WAVE) {
+        const size_t i = base + c;
+        const float4 ro = st.ray_o[i], rd = st.ray_d[i];
+        const uint32_t fl = st.flags[i];
+        const f3 o = mk3(ro.x, ro.y, ro.z);
+        float bt, bu, bv; uint32_t bp;
+        if (fl & MSK_FLAG_SHADOW) {
+            const float4 s = st.sh[i];
+            bool occ = traverse<true>(g.nodes, g.tris, sc.root_ref, sc.n_tris, o, mk3(s.x, s.y, s.z), ro.w, s.w,
+                                      stack, &bt, &bu, &bv, &bp);
+            if (!occ) {
+                float4 r = st.res[i], k = st.contrib[i];
+                r.x = r.x + k.x; r.y = r.y + k.y; r.z = r.z + k.z; r.w = r.w + k.w;
+                st.res[i] = r;
+            }
+        }
+        traverse<false>(g.nodes, g.tris, sc.root_ref, sc.n_tris, o, mk3(rd.x, rd.y, rd.z), ro.w, rd.w, stack,
+                        &bt, &bu, &bv, &bp);
+        const bool valid = (bp != MSK_NO_PRIM) && (bt != rd.w);           // scene.cpp:234 tfar != maxt
+        st.hit[i] = make_float4(valid ? bt : MSK_INF_F, bu, bv, __uint_as_float(valid ? bp : MSK_NO_PRIM));
+    }
+}
+
+// batch entry points for the sub-stage parity tests (msk_gpu_trace_closest / _any)
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(MSK_BLOCK)
+k_trace_batch(DeviceScene sc, const float4 *rays, uint64_t n, float4 *out_hit, uint8_t *out_any) {
+    extern __shared__ float4 lds_dyn[];
+    uint32_t *stack_base = (uint32_t *) lds_dyn;
+    float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
+    TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE);
+    uint32_t *stack = stack_base + threadIdx.x;
+    for (uint64_t i = (uint64_t) blockIdx.x * MSK_BLOCK + threadIdx.x; i < n; i += (uint64_t) gridDim.x * MSK_BLOCK) {
+        const float4 ro = rays[2 * i], rd = rays[2 * i + 1];
+        float bt, bu, bv; uint32_t bp;
+        if (out_any) {
+            out_any[i] = traverse<true>(g.nodes, g.tris, sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z),
+                                        mk3(rd.x, rd.y, rd.z), ro.w, rd.w, stack, &bt, &bu, &bv, &bp) ? 1 : 0;
+        } else {
+            traverse<false>(g.nodes, g.tris, sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z),
+                            ro.w, rd.w, stack, &bt, &bu, &bv, &bp);
+            const bool valid = (bp != MSK_NO_PRIM) && (bt != rd.w);
+            out_hit[i] = make_float4(valid ? bt : MSK_INF_F, valid ? bu : 0.f, valid ? bv : 0.f,
+                                     __uint_as_float(valid ? bp : MSK_NO_PRIM));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// shading helpers
+// ------------------------------------------------------------------------------------------
+struct Interaction {
+    f3 p, wi;
+    frame3 sh;
+    float t;
+    int bsdf_id, emitter_id;
+};
+
+// mesh.cpp:50-101 + interaction.cpp:23-37 + interaction.h:55-60
+MSK_DEV Interaction make_interaction(const DeviceScene &sc, float4 hit, f3 ray_d) {
+    Interaction si;
+    const uint32_t prim = __float_as_uint(hit.w);
+    const float4 a = sc.tri_verts[(size_t) prim * 3], b = sc.tri_verts[(size_t) prim * 3 + 1],
+                 c = sc.tri_verts[(size_t) prim * 3 + 2];
+    const int4 mi = sc.mesh_info[__float_as_uint(a.w)];
+    const f3 p0 = mk3(a.x, a.y, a.z), p1 = mk3(b.x, b.y, b.z), p2 = mk3(c.x, c.y, c.z);
+    const float b1 = hit.y, b2 = hit.z, b0 = 1.f - b1 - b2;
+    const f3 dp0 = p1 - p0, dp1 = p2 - p0;
+    si.t = hit.x;
+    si.p = p0 * b0 + p1 * b1 + p2 * b2;
+    const f3 n = normalized(cross(dp0, dp1));
+    f3 dp_du, dp_dv;
+    coordinate_system(n, &dp_du, &dp_dv);
+    if (mi.z & 2) {                                   // mesh.cpp:68-80
+        const float4 ua = sc.tri_uvs[(size_t) prim * 2], ub = sc.tri_uvs[(size_t) prim * 2 + 1];
+        const float d0x = ua.z - ua.x, d0y = ua.w - ua.y, d1x = ub.x - ua.x, d1y = ub.y - ua.y;
+        const float det = d0x * d1y - d0y * d1x, inv_det = 1.f / det;
+        if (det != 0.f) {
+            dp_du = (dp0 * d1y - dp1 * d0y) * inv_det;
+            dp_dv = (dp0 * (-d1x) + dp1 * d0x) * inv_det;
+        }
+    }
+    if (mi.z & 1) {                                   // mesh.cpp:81-96
+        const float4 na = sc.tri_normals[(size_t) prim * 3], nb = sc.tri_normals[(size_t) prim * 3 + 1],
+                     nc = sc.tri_normals[(size_t) prim * 3 + 2];
+        si.sh.n = normalized(mk3(na.x, na.y, na.z) * b0 + mk3(nb.x, nb.y, nb.z) * b1 + mk3(nc.x, nc.y, nc.z) * b2);
+    } else {
+        si.sh.n = n;
+    }
+    const f3 ff = (-si.sh.n) * dot(si.sh.n, dp_du) + dp_du;
+    si.sh.s = normalized(ff);
+    si.sh.t = cross(si.sh.n, si.sh.s);
+    si.wi = si.sh.to_local(-ray_d);
+    si.bsdf_id = mi.x; si.emitter_id = mi.y;
+    return si;
+}
+
+// spectra/srgb_d65.cpp:34-36
+MSK_DEV spec emitter_radiance(const DeviceScene &sc, int e, spec wl) {
+    const float4 c = sc.emitters[2 * e];
+    return regular_eval(sc.emitter_d65 + 95 * e, wl) * srgb_model_eval(c.x, c.y, c.z, wl);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_shade_gen
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(MSK_BLOCK)
+k_shade_gen(DeviceScene sc, PathState st, PassParams pp, Ctrl *ctrl, uint32_t parity) {
+    const uint32_t wave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
+    const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->live[parity ^ 1] = 0;   // slot the NEXT launch accumulates into
+    if (wave >= pp.n_regions) return;
+    const uint32_t n_in = pp.counts[wave];
+    const size_t base = (size_t) wave * pp.region_size;
+    const uint32_t n_em = sc.n_emitters;
+    uint32_t cursor = 0, n_shadow = 0, n_done = 0;
+
+    for (uint32_t c0 = 0; c0 < n_in; c0 += MSK_WAVE) {
+        const uint32_t c = c0 + lane;
+        const bool active = c < n_in;
+        const size_t i = base + (active ? c : 0);
+        // ---- load
+        uint2 id = st.id[i];
+        spec wl = from4(st.wl[i]), thr = from4(st.thr[i]), res = from4(st.res[i]);
+        const float4 rd4 = st.ray_d[i];
+        const float4 hit = st.hit[i];
+        float bs_pdf = st.bs_pdf[i];
+        uint32_t depth = st.flags[i] & MSK_DEPTH_MASK;
+        const f3 rd = mk3(rd4.x, rd4.y, rd4.z);
+        const uint32_t pix = pp.pix_table[id.x];
+        const uint32_t sidx = pp.sample_first + id.y * pp.sample_stride;
+        const uint64_t key = counter_key(pp.seed, pix, sidx);
+
+        bool alive = active;
+        float4 new_o = make_float4(0, 0, 0, 0), new_d = make_float4(0, 0, 0, 0), new_sh = make_float4(0, 0, 0, 0);
+        spec contrib = splat(0.f);
+        bool has_shadow = false;
+
+        if (alive && hit.x == MSK_INF_F) alive = false;                   // path.cpp:34-41 / 96-97, no environment
+        if (alive) {
+            Interaction si = make_interaction(sc, hit, rd);
+            const float4 bs = sc.bsdfs[si.bsdf_id];
+            if (depth > 1) {
+                // ---- tail of the previous bounce: emitter hit by the BSDF sample (path.cpp:82-88,103-108)
+                if (si.emitter_id >= 0) {
+                    const spec value = si.wi.z > 0.f ? emitter_radiance(sc, si.emitter_id, wl) : splat(0.f);
+                    // set_query (records.cpp:7-14) + pdf_emitter_direct (scene.cpp:105-112, shape.cpp:80-86)
+                    float pdf = sc.emitters[2 * si.emitter_id].w;
+                    const float dp = fabsf(dot(rd, si.sh.n));
+                    pdf *= (dp != 0.f) ? (si.t * si.t) / dp : 0.f;
+                    if (n_em != 1) pdf = pdf * (1.f / n_em);
+                    res = res + thr * value * mis_weight(bs_pdf, pdf);
+                }
+                // ---- Russian roulette (path.cpp:116-122); eta == 1 on this path
+                if ((int) depth >= pp.rr_depth) {
+                    const float q = fmin_std(max4(thr), 0.95f);
+                    const float u = counter_pair(key, 3 + 3 * (depth - 2) + 1).y;
+                    if (u >= q) alive = false;
+                    else thr = thr / q;
+                }
+            }
+            // loop condition of the bounce that starts now (path.cpp:33)
+            if (alive && !((int) depth <= pp.max_depth || pp.max_depth < 0)) alive = false;
+            if (alive && depth == 1 && si.emitter_id >= 0 && !pp.hide_emitters) {   // path.cpp:42-47
+                const spec le = si.wi.z > 0.f ? emitter_radiance(sc, si.emitter_id, wl) : splat(0.f);
+                res = res + thr * le;
+            }
+            if (alive && (int) depth >= pp.max_depth && pp.max_depth > 0) alive = false;   // path.cpp:48-49
+            if (alive) {
+                const uint32_t pb = 3 + 3 * (depth - 1);
+                const spec refl = srgb_model_eval(bs.x, bs.y, bs.z, wl);
+                // ---- next-event estimation (path.cpp:56-67, scene.cpp:68-103)
+                if (n_em > 0) {
+                    f2 u = counter_pair(key, pb + 0);
+                    uint32_t e = 0;
+                    float light_sel_pdf = 1.f;
+                    if (n_em > 1) {
+                        light_sel_pdf = 1.f / n_em;
+                        uint32_t index = (uint32_t) (u.x * (float) n_em);
+                        index = index < n_em - 1 ? index : n_em - 1;
+                        u.x = (u.x - index * light_sel_pdf) * n_em;
+                        e = index;
+                    }
+                    const float4 e0 = sc.emitters[2 * e], e1 = sc.emitters[2 * e + 1];
+                    const uint32_t first_face = __float_as_uint(e1.y), n_faces = __float_as_uint(e1.z);
+                    const float *cdf = sc.cdf + __float_as_uint(e1.w);
+                    // Distribution1D::sample_reuse (core/distribution.h:106-116)
+                    uint32_t lo = 0, hi = n_faces + 1;
+                    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (!(u.y < cdf[mid])) lo = mid + 1; else hi = mid; }
+                    int fidx = (int) lo - 1;
+                    fidx = fidx < 0 ? 0 : fidx; fidx = fidx > (int) n_faces - 1 ? (int) n_faces - 1 : fidx;
+                    u.y = (u.y - cdf[fidx]) / (cdf[fidx + 1] - cdf[fidx]);
+                    const uint32_t lprim = first_face + (uint32_t) fidx;
+                    const float4 la = sc.tri_verts[(size_t) lprim * 3], lb = sc.tri_verts[(size_t) lprim * 3 + 1],
+                                 lc = sc.tri_verts[(size_t) lprim * 3 + 2];
+                    const f3 p0 = mk3(la.x, la.y, la.z), p1 = mk3(lb.x, lb.y, lb.z), p2 = mk3(lc.x, lc.y, lc.z);
+                    const f3 ed0 = p1 - p0, ed1 = p2 - p0;                 // mesh.cpp:103-133
+                    const f2 bc = square_to_uniform_triangle(u);
+                    const f3 lp = p0 + ed0 * bc.x + ed1 * bc.y;
+                    f3 ln = normalized(cross(ed0, ed1));
+                    const int4 lmi = sc.mesh_info[__float_as_uint(la.w)];
+                    if (lmi.z & 1) {
+                        const float4 na = sc.tri_normals[(size_t) lprim * 3], nb = sc.tri_normals[(size_t) lprim * 3 + 1],
+                                     nc = sc.tri_normals[(size_t) lprim * 3 + 2];
+                        ln = normalized(mk3(na.x, na.y, na.z) * (1.f - bc.x - bc.y) + mk3(nb.x, nb.y, nb.z) * bc.x +
+                                        mk3(nc.x, nc.y, nc.z) * bc.y);
+                    }
+                    float pdf = e0.w;
+                    f3 d = lp - si.p;                                      // shape.cpp:64-78
+                    const float dist2 = dot(d, d);
+                    const float dist = __builtin_sqrtf(dist2);
+                    d = d / dist;
+                    const float dp = fabsf(dot(d, ln));
+                    pdf *= (dp != 0.f) ? dist2 / dp : 0.f;
+                    spec emitter_val;
+                    if (dot(d, ln) < 0.f && pdf != 0.f) {                  // area.cpp:39-44
+                        emitter_val = emitter_radiance(sc, (int) e, wl) / pdf;
+                    } else {
+                        pdf = 0.f; emitter_val = splat(0.f);
+                    }
+                    if (n_em > 1) { pdf *= light_sel_pdf; emitter_val = emitter_val * (float) n_em; }
+                    if (pdf != 0.f) {
+                        const f3 wo = si.sh.to_local(d);
+                        spec bsdf_val = splat(0.f); float bsdf_pdf = 0.f;
+                        if (si.wi.z > 0.f && wo.z > 0.f) {                 // diffuse.cpp:35-57
+                            bsdf_val = refl * MSK_INV_PI_F * wo.z;
+                            bsdf_pdf = MSK_INV_PI_F * wo.z;
+                        }
+                        const float w = mis_weight(pdf, bsdf_pdf);
+                        contrib = thr * emitter_val * bsdf_val * w;
+                        if (any_nonzero(contrib)) {
+                            has_shadow = true;                             // scene.cpp:91-95
+                            new_sh = make_float4(d.x, d.y, d.z, dist * (1.f - MSK_SHADOW_EPS_F));
+                        }
+                    }
+                }
+                // ---- BSDF sampling (path.cpp:71-80, diffuse.cpp:18-33)
+                if (!(si.wi.z > 0.f)) {
+                    alive = false;             // failed sample: zero direction, the reference's ray misses
+                } else {
+                    const f2 u2 = counter_pair(key, pb + 2);
+                    const f3 wo_l = square_to_cosine_hemisphere(u2);
+                    bs_pdf = MSK_INV_PI_F * wo_l.z;
+                    const spec bsdf_val = bs_pdf > 0.f ? refl : splat(0.f);
+                    const f3 wo = si.sh.to_world(wo_l);
+                    new_o = make_float4(si.p.x, si.p.y, si.p.z, (1.f + max_abs(si.p)) * MSK_RAY_EPS_F);
+                    new_d = make_float4(wo.x, wo.y, wo.z, MSK_INF_F);
+                    thr = thr * bsdf_val;                                  // path.cpp:99
+                    depth += 1;
+                }
+            }
+        }
+        // ---- finished paths: render_sample's tail (integrator.cpp:115-125) -> sample record
+        if (active && !alive) {
+            spec wgt;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wgt.v[k] = wavelength_weight(wl.v[k]);
+            const spec result = res * wgt;
+            float X, Y, Z;
+            spectrum_to_xyz(sc.cie, result, wl, &X, &Y, &Z);
+            const f2 jit = counter_pair(key, 0);
+            const float px = (float) (pix % (uint32_t) sc.width) + jit.x, py = (float) (pix / (uint32_t) sc.width) + jit.y;
+            const size_t r = (size_t) id.x * pp.spp_owned + id.y;
+            pp.rec_a[r] = make_float4(X, Y, Z, px);
+            pp.rec_b[r] = py;
+        }
+        // ---- in-place compaction of the survivors (wave ballot + prefix popcount)
+        const unsigned long long m = __ballot(alive);
+        const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
+        n_shadow += __popcll(__ballot(alive && has_shadow));
+        n_done += __popcll(__ballot(active && !alive));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every load of this chunk has landed before slots are overwritten
+        if (alive) {
+            const size_t o = base + cursor + off;
+            st.id[o] = id; st.wl[o] = to4(wl); st.thr[o] = to4(thr); st.res[o] = to4(res);
+            st.ray_o[o] = new_o; st.ray_d[o] = new_d; st.sh[o] = new_sh; st.contrib[o] = to4(contrib);
+            st.bs_pdf[o] = bs_pdf; st.flags[o] = depth | (has_shadow ? MSK_FLAG_SHADOW : 0u);
+        }
+        cursor += __popcll(m);
+    }
+
+    // ---- regeneration: fill the free tail with new camera samples (integrator.cpp:103-116)
+    const uint32_t n_free = pp.region_size - cursor;
+    unsigned long long first = 0; uint32_t got = 0;
+    if (lane == 0 && n_free > 0) {
+        const unsigned long long total = ctrl->total_samples;
+        // cheap pre-check keeps the cursor from running away once the samples are exhausted
+        if (__hip_atomic_load(&ctrl->next_sample, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
+            first = atomicAdd(&ctrl->next_sample, (unsigned long long) n_free);
+            if (first < total) got = (uint32_t) ((total - first < n_free) ? (total - first) : n_free);
+        }
+    }
+    first = __shfl(first, 0); got = __shfl(got, 0);
+    for (uint32_t k = lane; k < got; k += MSK_WAVE) {
+        const unsigned long long sidx_lin = first + k;
+        const uint32_t j = (uint32_t) (sidx_lin / pp.spp_owned), si = (uint32_t) (sidx_lin % pp.spp_owned);
+        const uint32_t pix = pp.pix_table[j];
+        const uint64_t key = counter_key(pp.seed, pix, pp.sample_first + si * pp.sample_stride);
+        const f2 jit = counter_pair(key, 0);
+        const float wsample = counter_pair(key, 1).x;
+        const float px = (float) (pix % (uint32_t) sc.width) + jit.x, py = (float) (pix / (uint32_t) sc.width) + jit.y;
+        spec wl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wl.v[q] = wavelength_of(wsample, q);
+        // PerspectiveCamera::sample_ray (perspective.cpp:22-42), Transform4f::apply_point/apply_vector
+        float r4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            r4[q] = ((sc.s2c[q * 4 + 0] * px + sc.s2c[q * 4 + 1] * py) + sc.s2c[q * 4 + 2] * 0.f) + sc.s2c[q * 4 + 3] * 1.f;
+        const f3 near_p = mk3(r4[0] / r4[3], r4[1] / r4[3], r4[2] / r4[3]);
+        const f3 dl = normalized(near_p);
+        const float inv_z = 1.f / dl.z;
+        float o4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            o4[q] = ((sc.to_world[q * 4 + 0] * 0.f + sc.to_world[q * 4 + 1] * 0.f) + sc.to_world[q * 4 + 2] * 0.f) +
+                    sc.to_world[q * 4 + 3] * 1.f;
+        const f3 ow = mk3(o4[0] / o4[3], o4[1] / o4[3], o4[2] / o4[3]);
+        const float *m = sc.to_world;
+        const f3 dw = mk3(m[0] * dl.x + (m[1] * dl.y + m[2] * dl.z), m[4] * dl.x + (m[5] * dl.y + m[6] * dl.z),
+                          m[8] * dl.x + (m[9] * dl.y + m[10] * dl.z));
+        const size_t o = base + cursor + k;
+        st.id[o] = make_uint2(j, si);
+        st.wl[o] = to4(wl); st.thr[o] = make_float4(1.f, 1.f, 1.f, 1.f); st.res[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.ray_o[o] = make_float4(ow.x, ow.y, ow.z, sc.near_clip * inv_z);
+        st.ray_d[o] = make_float4(dw.x, dw.y, dw.z, sc.far_clip * inv_z);
+        st.sh[o] = make_float4(0, 0, 0, 0); st.contrib[o] = make_float4(0, 0, 0, 0);
+        st.bs_pdf[o] = 0.f; st.flags[o] = 1u;
+    }
+    if (lane == 0) {
+        const uint32_t n_out = cursor + got;
+        pp.counts[wave] = n_out;
+        if (n_out) { atomicAdd(&ctrl->live[parity], (unsigned long long) n_out); atomicAdd(&ctrl->segments, (unsigned long long) n_out); }
+        if (n_shadow) atomicAdd(&ctrl->shadow_rays, (unsigned long long) n_shadow);
+        if (n_done) atomicAdd(&ctrl->samples_done, (unsigned long long) n_done);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// film: records -> per-block ImageBlocks -> film, in the reference's accumulation order
+// ------------------------------------------------------------------------------------------
+struct BlockInfo {          // one spiral block of this pass
+    int32_t off_x, off_y, size_x, size_y;
+    uint32_t pixel_base;    // first pass-pixel index of the block (row-major inside the block)
+    uint32_t slot;          // index of the block's accumulation buffer
+};
+
+// One thread per pixel of the bordered block: replays ImageBlock::put (imageblock.cpp:55-114) for
+// every sample of the block in the order render_block issues them (y, x, s — integrator.cpp:89-98)
+// and keeps only what lands on its own pixel.
+__global__ void __launch_bounds__(MSK_BLOCK)
+k_resolve_blocks(DeviceScene sc, const BlockInfo *blocks, uint32_t n_blocks, const float4 *rec_a, const float *rec_b,
+                 uint32_t spp_owned, float *block_buf, uint32_t buf_stride) {
+    const uint32_t per_block = (buf_stride / 5);
+    const uint64_t gid = (uint64_t) blockIdx.x * MSK_BLOCK + threadIdx.x;
+    const uint32_t bi = (uint32_t) (gid / per_block), t = (uint32_t) (gid % per_block);
+    if (bi >= n_blocks) return;
+    const BlockInfo b = blocks[bi];
+    const int border = sc.filter_border;
+    const int sx = b.size_x + 2 * border, sy = b.size_y + 2 * border;
+    if ((int) t >= sx * sy) return;
+    const int tx = (int) t % sx, ty = (int) t / sx;
+    const float radius = sc.filter_radius, scale = sc.filter_scale;
+    // a sample of source pixel x lands on bordered targets within border-r-.5 .. border+r+.5 of x
+    const int span = (int) ceilf(radius + 0.5f);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+    const int y_lo = max(0, ty - border - span), y_hi = min(b.size_y - 1, ty - border + span);
+    const int x_lo = max(0, tx - border - span), x_hi = min(b.size_x - 1, tx - border + span);
+    const float offx = (float) (b.off_x - border), offy = (float) (b.off_y - border);
+    for (int y = y_lo; y <= y_hi; ++y)
+        for (int x = x_lo; x <= x_hi; ++x) {
+            const size_t r0 = (size_t) (b.pixel_base + (uint32_t) (y * b.size_x + x)) * spp_owned;
+            for (uint32_t s = 0; s < spp_owned; ++s) {
+                const float4 ra = rec_a[r0 + s];
+                const float pyv = rec_b[r0 + s];
+                const float px = ra.w - 0.5f - offx, py = pyv - 0.5f - offy;
+                const int lox = max((int) ceilf(px - radius), 0), loy = max((int) ceilf(py - radius), 0);
+                const int hix = min((int) floorf(px + radius), sx - 1), hiy = min((int) floorf(py + radius), sy - 1);
+                if (tx < lox || tx > hix || ty < loy || ty > hiy) continue;
+                const float wx = sc.lut[min((int) fabsf(((float) tx - px) * scale), 32)];
+                const float wy = sc.lut[min((int) fabsf(((float) ty - py) * scale), 32)];
+                const float w = wx * wy;
+                a0 += w * ra.x; a1 += w * ra.y; a2 += w * ra.z; a3 += w * 1.f; a4 += w * 1.f;
+            }
+        }
+    float *o = block_buf + (size_t) b.slot * buf_stride + (size_t) t * 5;
+    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4;
+}
+
+// Film::put for every block in spiral order (imageblock.cpp:36-53,133-173; D6: ascending block id).
+// One thread per film pixel; block_of[by*nbx+bx] = slot of that block's buffer or -1 (not rendered
+// by this rank), spiral_id gives the order.
+__global__ void __launch_bounds__(MSK_BLOCK)
+k_film_put(DeviceScene sc, const BlockInfo *blocks, const int32_t *block_of, const uint32_t *spiral_id, int nbx, int nby,
+           int block_size, const float *block_buf, uint32_t buf_stride, float *film) {
+    const uint32_t gid = blockIdx.x * MSK_BLOCK + threadIdx.x;
+    if (gid >= (uint32_t) (sc.width * sc.height)) return;
+    const int x = (int) (gid % (uint32_t) sc.width), y = (int) (gid / (uint32_t) sc.width);
+    const int border = sc.filter_border;
+    int cand[9]; uint32_t cid[9]; int nc = 0;
+    const int bx0 = x / block_size, by0 = y / block_size;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int bx = bx0 + dx, by = by0 + dy;
+            if (bx < 0 || by < 0 || bx >= nbx || by >= nby) continue;
+            const int s = block_of[by * nbx + bx];
+            if (s < 0) continue;
+            const BlockInfo b = blocks[s];
+            const int lx = x - (b.off_x - border), ly = y - (b.off_y - border);
+            if (lx < 0 || ly < 0 || lx >= b.size_x + 2 * border || ly >= b.size_y + 2 * border) continue;
+            // insertion sort by spiral id
+            const uint32_t id = spiral_id[by * nbx + bx];
+            int k = nc++;
+            while (k > 0 && cid[k - 1] > id) { cid[k] = cid[k - 1]; cand[k] = cand[k - 1]; --k; }
+            cid[k] = id; cand[k] = s;
+        }
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nc; ++k) {
+        const BlockInfo b = blocks[cand[k]];
+        const int lx = x - (b.off_x - border), ly = y - (b.off_y - border);
+        const float *src = block_buf + (size_t) b.slot * buf_stride + (size_t) (ly * (b.size_x + 2 * border) + lx) * 5;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) acc[c] += src[c];
+    }
+    float *o = film + (size_t) gid * 5;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) o[c] = acc[c];
+}
+
+// records of listed pixels -> {X,Y,Z} + position (msk_gpu_sample_pixels)
+__global__ void k_export_records(const float4 *rec_a, const float *rec_b, uint64_t n, float *out_xyz, float *out_pos) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = rec_a[i];
+    out_xyz[i * 3] = a.x; out_xyz[i * 3 + 1] = a.y; out_xyz[i * 3 + 2] = a.z;
+    if (out_pos) { out_pos[i * 2] = a.w; out_pos[i * 2 + 1] = rec_b[i]; }
+}
+
+}  // namespace msk

@@ -606,12 +606,11 @@ static S4 path_sample(const Scene &sc, Sampler &sampler, Ray ray, S4 wl, const m
             bsdf_val = bs_pdf > 0.f ? srgb_model_eval(bsdf.reflectance, wl) : s4(0.f);
         }
         scattered |= true;   // path.cpp:73: sampled_type (0 on failure) != Null is always true
-        (void) sampled_type;
         V3 wo = si.sh.to_world(bs_wo);
         bool hit_emitter = false;
         S4 value = s4(0.f);
         ray = Ray{si.p, wo, (1.f + max_abs(si.p)) * kRayEpsilon, kInf};   // interaction.h:40-44
-        ++cnt.segments;
+        if (sampled_type) ++cnt.segments;     // statistics only: the zero-direction ray of a failed sample is not counted
         Interaction si_bsdf = compute_interaction(sc, ray, closest_hit(sc, ray));
         if (si_bsdf.valid()) {
             int em = sc.meshes[si_bsdf.mesh].emitter_id;

@@ -56,7 +56,6 @@ def main():
         "box": (0.45, 0.30, 0.90),
         "emitter_40_normalised": (0.5, 0.5, 0.5),   # srgb_d65.cpp:18-22: 40 / (2*max) = 0.5
         "grey_0.5": (0.5, 0.5, 0.5),
-        "black": (0.0, 0.0, 0.0),
         "white_1": (1.0, 1.0, 1.0),
         "primary_r": (1.0, 0.0, 0.0),
         "mid_1": (0.2, 0.7, 0.4),

@@ -1,0 +1,86 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol the header
+declares (no compute calls — there is no GPU here), struct layouts agree, host mirror sanity."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(abi):
+    import __graft_entry__ as ge
+    ge.build_gpu_library()
+    header = open(os.path.join(ROOT, "include", "msk_gpu.h")).read()
+    declared = sorted(set(re.findall(r"\b(msk_gpu_[a-z_]+)\s*\(", header)))
+    assert declared == sorted(abi.EXPORTS)
+    lib = C.CDLL(abi.LIB_PATH)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    # a HIP fat binary for gfx950 is embedded (this is the hand-written kernel build, not a stub)
+    blob = open(abi.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"k_shade_gen" in blob and b"k_trace" in blob
+
+
+def test_struct_layouts_match_the_header(abi, tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "msk_gpu.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(msk_mesh_desc),sizeof(msk_bsdf_desc),sizeof(msk_emitter_desc),sizeof(msk_camera_desc),'
+                   'sizeof(msk_film_desc),sizeof(msk_scene_desc),sizeof(msk_render_params),sizeof(msk_stats),'
+                   'offsetof(msk_scene_desc,camera),offsetof(msk_render_params,rng_mode));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(abi.MeshDesc), C.sizeof(abi.BsdfDesc), C.sizeof(abi.EmitterDesc), C.sizeof(abi.CameraDesc),
+            C.sizeof(abi.FilmDesc), C.sizeof(abi.SceneDesc), C.sizeof(abi.RenderParams), C.sizeof(abi.Stats),
+            abi.SceneDesc.camera.offset, abi.RenderParams.rng_mode.offset]
+    assert got == want
+
+
+def test_missing_library_fails_loudly(abi, tmp_path):
+    with pytest.raises(FileNotFoundError) as e:
+        abi.load_library(str(tmp_path / "libmsk_gpu.so"))
+    assert "no CPU fallback" in str(e.value).replace("NO", "no") or "fallback" in str(e.value)
+
+
+def test_flatten_cbox(hostmirror, golden_lookup):
+    fs = hostmirror.cbox_scene(512, 512, coeff_lookup=golden_lookup)
+    d = fs.desc
+    assert (d.n_meshes, d.n_bsdfs, d.n_emitters, d.n_faces, d.n_vertices) == (8, 8, 1, 32, 64)
+    assert d.meshes[0].emitter_id == 0 and d.emitters[0].mesh_id == 0
+    assert all(d.meshes[i].emitter_id == -1 for i in range(1, 8))
+    # srgb_d65.cpp:18-26 + d65.cpp:33-34: scale = 2*max(40) = 80, m_scale = 80 * (1/10568)
+    assert d.emitters[0].d65_scale == np.float32(80.0) * (np.float32(1.0) / np.float32(10568.0))
+    # quad split (obj.cpp:109-119): (v0,v1,v2) and (v3,v0,v2)
+    assert fs.faces[:2].tolist() == [[0, 1, 2], [3, 0, 2]]
+    assert d.film.filter_radius == 2.0 and d.film.filter_lut[32] == 0.0
+
+
+def test_own_rgb2spec_reproduces_the_colour(golden):
+    """The package's own upsampling returns spectra that integrate back to the requested sRGB colour
+    and stay close to the reference model's spectra (coefficients differ: direct fit vs table lookup)."""
+    import importlib
+    r2s = importlib.import_module("misaki-render_amd.rgb2spec")
+    t, tbl, _ = r2s._quadrature()
+    lam = 360.0 + 470.0 * t
+    for name in ("white", "green", "red", "box", "mid_1", "mid_2", "mid_3", "luminaire_reflectance"):
+        rgb = golden["triplets"][name]["rgb"]
+        c = r2s.srgb_model_fetch(rgb)
+        back = tbl @ r2s.eval_spectrum(c, lam)
+        assert np.allclose(back, rgb, atol=2e-3), (name, back, rgb)
+        ref = r2s.eval_spectrum(golden["triplets"][name]["coeff"], lam)
+        assert np.abs(r2s.eval_spectrum(c, lam) - ref).max() < 0.03, name
+    assert r2s.srgb_model_fetch((0.5, 0.5, 0.5)) == (0.0, 0.0, 0.0)
+    assert r2s.srgb_model_fetch((0, 0, 0))[2] == -np.inf and r2s.srgb_model_fetch((1, 1, 1))[2] == np.inf
+
+
+def test_develop_matches_hdrfilm_formula(hostmirror):
+    film = np.zeros((2, 2, 5), np.float32)
+    film[0, 0] = [2, 4, 6, 2, 2]
+    img = hostmirror.develop(film)
+    m = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]])
+    assert np.allclose(img[0, 0, :3], m @ np.array([1, 2, 3.0]), rtol=1e-6) and img[0, 0, 3] == 1.0
+    assert np.all(img[1, 1] == 0)       # weight 0 -> 0 (hdrfilm.cpp:72)

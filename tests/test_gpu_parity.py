@@ -1,0 +1,248 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle.  Need an MI355X.
+
+Bar: bit-exact for indices AND for every fp32 value (hit records, per-sample XYZ, film sums);
+the fp32 tolerance the north star allows (1e-4 per pixel) is only used for cross-shard sums.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def cbox(hostmirror, golden_lookup, w, h, extra=()):
+    def look(rgb):
+        try:
+            return golden_lookup(rgb)
+        except KeyError:
+            import importlib
+            return importlib.import_module("misaki-render_amd.rgb2spec").srgb_model_fetch(rgb)
+    return hostmirror.cbox_scene(w, h, coeff_lookup=look, extra_meshes=extra)
+
+
+@pytest.fixture(scope="module")
+def scene256(gpu_ctx, abi, hostmirror, oracle, golden_lookup):
+    flat = cbox(hostmirror, golden_lookup, 256, 256)
+    g = abi.Scene(gpu_ctx, flat)
+    o = oracle.scene(flat)
+    yield g, o, flat
+    g.close()
+    o.close()
+
+
+def random_rays(flat, n, seed):
+    rng = np.random.RandomState(seed)
+    v = flat.vertices[:, :3]
+    lo, hi = v.min(0), v.max(0)
+    o = rng.uniform(lo - 50, hi + 50, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, :3], rays[:, 3], rays[:, 4:7], rays[:, 7] = o, 1e-3, d, np.inf
+    # a third of the rays get a finite far bound, some start on a surface (secondary-ray like)
+    rays[::3, 7] = rng.uniform(10, 900, len(rays[::3])).astype(np.float32)
+    return rays
+
+
+def camera_rays(oscene, w, h, n, seed):
+    rng = np.random.RandomState(seed)
+    return np.stack([oscene.camera_ray(0.5, *p)[0] for p in rng.uniform(0, [w, h], (n, 2)).astype(np.float32)])
+
+
+def test_library_is_the_hip_build(gpu_ctx, abi):
+    assert abi.LIB_PATH.endswith("misaki-render_amd/lib/libmsk_gpu.so")
+    assert "gfx950" in gpu_ctx.describe()
+
+
+def test_trace_closest_and_any_bit_exact(scene256):
+    g, o, flat = scene256
+    rays = np.concatenate([random_rays(flat, 400_000, 1), camera_rays(o, 256, 256, 2000, 2)])
+    # secondary rays: start exactly on hit points of the first batch
+    o.set_bvh(1)
+    first = o.trace_closest(rays)
+    ok = np.isfinite(first[:, 0])
+    p = rays[ok, :3] + rays[ok, 4:7] * first[ok, 0:1]
+    sec = random_rays(flat, int(ok.sum()), 3)
+    sec[:, :3] = p
+    sec[:, 3] = (1 + np.abs(p).max(1)) * np.float32(8.940697e-05)
+    rays = np.concatenate([rays, sec])
+    want = o.trace_closest(rays)
+    got = g.trace_closest(rays)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(g.trace_any(rays), o.trace_any(rays))
+    # and the oracle's BVH answers == its brute force answers (order independence of the hit rule)
+    o.set_bvh(0)
+    sub = rays[::7]
+    assert np.array_equal(o.trace_closest(sub).view(np.uint32), want[::7].view(np.uint32))
+    o.set_bvh(1)
+    hits = np.isfinite(want[:, 0]).mean()
+    assert 0.3 < hits < 1.0
+
+
+def test_trace_degenerate_rays(scene256):
+    g, o, _ = scene256
+    rays = np.array([[278, 273, -800, 0, 0, 0, 0, np.inf],          # zero direction (failed BSDF sample)
+                     [278, 273, 100, 1e-3, 0, 1, 0, np.inf],         # axis aligned, hits the light
+                     [278, 273, 100, 1e-3, 0, -1, 0, np.inf],
+                     [278, 273, 100, 1e-3, 1, 0, 0, 10.0],           # far bound before the wall
+                     [0, 0, 0, 1e-3, 0, 0, 1, np.inf],               # along a shared edge / corner
+                     [130, 165, 65, 1e-3, 0, 1, 0, np.inf]], np.float32)
+    assert np.array_equal(g.trace_closest(rays).view(np.uint32), o.trace_closest(rays).view(np.uint32))
+    assert np.array_equal(g.trace_any(rays), o.trace_any(rays))
+    assert g.trace_closest(np.zeros((0, 8), np.float32)).shape == (0, 4)
+
+
+def test_per_sample_radiance_bit_exact(scene256, abi):
+    g, o, _ = scene256
+    prm = abi.render_params(spp=64, seed=3)
+    rng = np.random.RandomState(5)
+    pixels = np.concatenate([rng.randint(0, 256, (48, 2)), [[128, 30], [0, 0], [255, 255], [128, 128]]]).astype(np.int32)
+    gx, gp = g.sample_pixels(prm, pixels)
+    ox, op = o.sample_pixels(prm, pixels)
+    assert np.array_equal(gp, op)
+    assert np.array_equal(gx.view(np.uint32), ox.view(np.uint32))
+    assert np.isfinite(gx).all() and gx.max() > 1.0       # the light is in view of some samples
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(max_depth=1), dict(max_depth=2), dict(max_depth=0), dict(rr_depth=1),
+                                dict(rr_depth=50, max_depth=12), dict(hide_emitters=1), dict(seed=123456789012345)])
+def test_integrator_properties_bit_exact(scene256, abi, kw):
+    g, o, _ = scene256
+    prm = abi.render_params(spp=8, **kw)
+    pixels = np.array([[128, 30], [100, 200], [30, 128], [220, 128], [128, 128], [90, 140]], np.int32)
+    gx, _ = g.sample_pixels(prm, pixels)
+    ox, _ = o.sample_pixels(prm, pixels)
+    assert np.array_equal(gx.view(np.uint32), ox.view(np.uint32))
+
+
+def test_c1_film_bit_exact(scene256, abi, hostmirror):
+    """BASELINE config 1: cbox 256x256 @ 16 spp, GPU film == oracle film, bit for bit."""
+    g, o, _ = scene256
+    prm = abi.render_params(spp=16, seed=0)
+    film, st = g.render(prm)
+    ref, rst = o.render(prm, threads=8)
+    assert st.samples == 256 * 256 * 16 and st.segments == rst.segments
+    assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+    rgb, rgb_ref = hostmirror.develop(film), hostmirror.develop(ref)
+    assert np.sqrt(((rgb[..., :3] - rgb_ref[..., :3]) ** 2).sum(-1)).max() == 0.0
+    assert np.all(film[..., 4] > 0) and np.array_equal(film[..., 3], film[..., 4])     # A == W
+
+
+def test_ragged_film_and_single_sample(gpu_ctx, abi, hostmirror, oracle, golden_lookup):
+    flat = cbox(hostmirror, golden_lookup, 100, 40)        # blocks of 32: ragged right and bottom edges
+    g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+    for spp in (1, 5):
+        prm = abi.render_params(spp=spp, seed=9)
+        film, _ = g.render(prm)
+        ref, _ = o.render(prm, threads=4)
+        assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+    prm = abi.render_params(spp=3, block_size=16)
+    assert np.array_equal(g.render(prm)[0].view(np.uint32), o.render(prm, threads=4)[0].view(np.uint32))
+    g.close()
+    o.close()
+
+
+def test_shards_sum_to_the_whole(scene256, abi, hostmirror):
+    g, o, _ = scene256
+    full, _ = g.render(abi.render_params(spp=8, seed=4))
+    # pixel-tile shard (the multi-GPU decomposition): every rank's film is bit-exact vs the oracle shard
+    parts = []
+    for r in range(3):
+        prm = abi.render_params(spp=8, seed=4, block_first=r, block_stride=3)
+        f, st = g.render(prm)
+        assert np.array_equal(f.view(np.uint32), o.render(prm, threads=8)[0].view(np.uint32))
+        parts.append(f)
+    s = parts[0] + parts[1] + parts[2]
+    interior = np.ones((256, 256), bool)
+    for k in range(0, 256, 32):                       # pixels within the 2-px filter border of a tile edge
+        interior[max(0, k - 2):k + 2, :] = False
+        interior[:, max(0, k - 2):k + 2] = False
+    assert np.array_equal(s[interior], full[interior])           # one rank contributes: exact
+    assert np.allclose(s, full, rtol=3e-7, atol=1e-6)             # <= 4 ranks contribute: fp32 re-association
+    d = hostmirror.develop(s)[..., :3] - hostmirror.develop(full)[..., :3]
+    assert np.sqrt((d ** 2).sum(-1)).max() < 1e-4
+    # sample-index shard
+    sp = [g.render(abi.render_params(spp=8, seed=4, sample_first=r, sample_stride=2))[0] for r in range(2)]
+    assert np.allclose(sp[0] + sp[1], full, rtol=2e-5, atol=1e-5)
+    assert np.array_equal(sp[1].view(np.uint32),
+                          o.render(abi.render_params(spp=8, seed=4, sample_first=1, sample_stride=2), threads=8)[0].view(np.uint32))
+
+
+def test_large_mesh_uses_hbm_bvh(gpu_ctx, abi, hostmirror, oracle, golden_lookup):
+    """A 20k-triangle blob inside the box: BVH no longer fits LDS; also exercises deep traversal."""
+    blob = hostmirror.blob_mesh("blob", (370, 420, 250), 70, 100, 100, hostmirror.WHITE, seed=2)
+    flat = cbox(hostmirror, golden_lookup, 96, 96, extra=[blob])
+    assert flat.desc.n_faces > 19000
+    g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+    rays = np.concatenate([random_rays(flat, 200_000, 11), camera_rays(o, 96, 96, 1000, 12)])
+    want = o.trace_closest(rays)
+    assert np.array_equal(g.trace_closest(rays).view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(g.trace_any(rays), o.trace_any(rays))
+    blob_hits = (want[:, 3].view(np.uint32) >= 32) & np.isfinite(want[:, 0])
+    assert blob_hits.sum() > 1000
+    prm = abi.render_params(spp=4, seed=2)
+    film, _ = g.render(prm)
+    ref, _ = o.render(prm, threads=8)
+    assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+    g.close()
+    o.close()
+
+
+def test_two_emitters(gpu_ctx, abi, hostmirror, oracle, golden_lookup):
+    """Multi-emitter selection path of Scene::sample_emitter_direct (scene.cpp:78-88)."""
+    second = hostmirror.MeshSpec("lamp2", [((100, 300, 558), (200, 300, 558), (200, 400, 558), (100, 400, 558))],
+                                 hostmirror.WHITE, radiance=(40, 40, 40))
+    flat = cbox(hostmirror, golden_lookup, 64, 64, extra=[second])
+    assert flat.desc.n_emitters == 2
+    g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+    prm = abi.render_params(spp=16, seed=8)
+    film, _ = g.render(prm)
+    ref, _ = o.render(prm, threads=8)
+    assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+    g.close()
+    o.close()
+
+
+def test_multi_pass_record_budget(scene256, abi, monkeypatch):
+    """Forcing a tiny record budget splits the render into several block passes; same film."""
+    g, o, _ = scene256
+    prm = abi.render_params(spp=4, seed=6)
+    one, st1 = g.render(prm)
+    monkeypatch.setenv("MSK_RECORD_BUDGET_MB", "1")
+    many, st2 = g.render(prm)
+    assert st2.passes > st1.passes == 1
+    assert np.array_equal(one.view(np.uint32), many.view(np.uint32))
+
+
+def test_pool_shape_does_not_change_results(scene256, abi, monkeypatch):
+    g, o, _ = scene256
+    prm = abi.render_params(spp=4, seed=6)
+    a, _ = g.render(prm)
+    monkeypatch.setenv("MSK_REGIONS", "64")
+    monkeypatch.setenv("MSK_REGION_SIZE", "128")
+    b, st = g.render(prm)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and st.iterations > 20
+
+
+def test_error_behaviour(scene256, gpu_ctx, abi, hostmirror, golden_lookup):
+    g, o, flat = scene256
+    with pytest.raises(abi.MskError) as e:
+        g.render(abi.render_params(spp=4, rng_mode=abi.MSK_RNG_PCG_BLOCK))
+    assert e.value.code == abi.MSK_ERR_UNSUPPORTED
+    with pytest.raises(abi.MskError) as e:
+        g.render(abi.render_params(spp=4, rr_depth=0))            # integrator.cpp:131-132
+    assert "rr_depth" in str(e.value)
+    with pytest.raises(abi.MskError):
+        g.render(abi.render_params(spp=4, max_depth=-2))          # integrator.cpp:135-136
+    with pytest.raises(abi.MskError):
+        g.render(abi.render_params(spp=0))
+    bad = cbox(hostmirror, golden_lookup, 32, 32)
+    bad.desc.meshes[2].bsdf_id = 99
+    with pytest.raises(abi.MskError) as e:
+        abi.Scene(gpu_ctx, bad)
+    assert e.value.code == abi.MSK_ERR_INVALID_ARG
+    bad = cbox(hostmirror, golden_lookup, 32, 32)
+    bad.faces[5, 1] = 1000
+    with pytest.raises(abi.MskError):
+        abi.Scene(gpu_ctx, bad)
+    with pytest.raises(abi.MskError):
+        g.sample_pixels(abi.render_params(spp=1), np.array([[300, 2]], np.int32))
