@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Msamples/s of the path-tracing hot path on the synthetic
+Cornell box at 512x512, 512 spp per GPU (BASELINE.json configs[1]), diffuse BSDFs.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one complete render through the C ABI (msk_gpu_render_device): wavefront path tracing
+of every sample + the ordered film resolve, film left in HBM.  Inputs (scene, BVH) are resident
+in HBM before the timed region.  For N > 1 the driver launches one rank per GPU
+(torch.distributed.run); rank r renders the spiral blocks id = r (mod N) at 512*N spp — per-GPU
+work is constant (weak scaling) — and the films are summed onto rank 0 with one RCCL reduce
+inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH = HEIGHT = 512
+SPP_PER_GPU = 512
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def cpu_baseline(abi, hm, flat, seconds_target=15.0):
+    """The CPU oracle (a port of the reference's Embree3+TBB loop, see oracle/oracle.cpp) timed on
+    this box's host cores on a bounded sample of the same workload.  Reported, never the target."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding
+    orc = oracle_binding.load()
+    threads = min(8, os.cpu_count() or 1)         # the reference CLI caps TBB at 8 threads (main.cpp:43-44)
+    sc = orc.scene(flat)
+    spp = 1
+    prm = abi.render_params(spp=spp, rng_mode=abi.MSK_RNG_PCG_BLOCK)
+    t0 = time.perf_counter()
+    sc.render(prm, threads)
+    dt = time.perf_counter() - t0
+    spp = int(max(1, min(64, seconds_target / max(dt, 1e-3))))
+    prm = abi.render_params(spp=spp, rng_mode=abi.MSK_RNG_PCG_BLOCK)
+    t0 = time.perf_counter()
+    _, st = sc.render(prm, threads)
+    dt = time.perf_counter() - t0
+    sc.close()
+    return {"value": round(st.samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"cbox {WIDTH}x{HEIGHT} @ {spp} spp ({st.samples} samples, {dt:.1f} s), pcg_block sampler, "
+                      f"own BVH instead of Embree", "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=SPP_PER_GPU, help="spp per GPU (default: the BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    abi = importlib.import_module("misaki-render_amd.abi")
+    hm = importlib.import_module("misaki-render_amd.hostmirror")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n = args.gpus
+    if world != n and world > 1:
+        n = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    flat = hm.cbox_scene(WIDTH, HEIGHT)
+    ctx = abi.Context(local_rank)
+    scene = abi.Scene(ctx, flat)
+    spp_total = args.spp * world
+    prm = abi.render_params(spp=spp_total, seed=0, block_first=rank, block_stride=world)
+    film = torch.zeros((HEIGHT, WIDTH, 5), dtype=torch.float32, device="cuda")
+
+    def step():
+        st = scene.render_device(prm, film.data_ptr())
+        if dist is not None:
+            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+        return st
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(args.steps):
+        stats.append(step())
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        samples_step = WIDTH * HEIGHT * spp_total              # all ranks together
+        value = samples_step * args.steps / dt / 1e6
+        # ---- roofline of the dominant kernel, from the HIP events the library records around every
+        #      launch on its own stream (rank 0's launches)
+        seg = sum(s.segments for s in stats)
+        smp = sum(s.samples for s in stats)
+        shd = sum(s.shadow_rays for s in stats)
+        ms_trace = sum(s.ms_trace for s in stats)
+        ms_shade = sum(s.ms_shade for s in stats)
+        n_trace = sum(s.n_trace_launches for s in stats)
+        n_shade = sum(s.n_shade_launches for s in stats)
+        # algorithmic bytes: k_trace 52 B/segment + 64 B/shadow ray;
+        # k_shade_gen 224 B/segment + 20 B/sample record
+        bytes_trace = seg * 52 + shd * 64
+        bytes_shade = seg * 224 + smp * 20
+        if ms_trace >= ms_shade:
+            name, b, ms, nl = "k_trace", bytes_trace, ms_trace, n_trace
+        else:
+            name, b, ms, nl = "k_shade_gen", bytes_shade, ms_shade, n_shade
+        achieved = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get(name, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Msamples/s (paths x spp) on cbox@512spp", "value": round(value, 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cbox {WIDTH}x{HEIGHT} @ {args.spp} spp per GPU ({spp_total} spp total), diffuse BSDFs, "
+                                   f"path integrator (NEE+MIS, RR from depth 4), counter RNG, Gaussian filter, "
+                                   f"ordered film resolve included",
+                       "parallelism": f"tile-shard x{world}" if world > 1 else "single GPU",
+                       "samples_per_step": samples_step,
+                       "segments_per_sample": round(seg / max(smp, 1), 3)},
+            "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "bytes_per_launch": round(b / max(nl, 1)), "avg_launch_ms": round(ms / max(nl, 1), 4),
+                         "launches": nl, "ms_trace": round(ms_trace, 2), "ms_shade": round(ms_shade, 2),
+                         "ms_resolve": round(sum(s.ms_resolve for s in stats), 2),
+                         "ms_total_device": round(sum(s.ms_total for s in stats), 2)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(abi, hm, flat)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    scene.close()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,8 +58,8 @@ struct msk_scene {
     msk_ctx *ctx = nullptr;
     DeviceScene dev;
     DevBuf nodes, tris, tri_verts, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
-    bool lds_scene = false;
-    size_t trace_lds_bytes = 0;
+    bool lds_scene = false, lds_tables = false;
+    size_t trace_lds_bytes = 0, shade_lds_bytes = 0;
     int bvh_depth = 0;
     uint32_t n_tris = 0;
 };
@@ -242,6 +242,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     ds.mesh_info = s->mesh_info.as<int4>(); ds.bsdfs = s->bsdfs.as<float4>(); ds.emitters = s->emitters.as<float4>();
     ds.emitter_d65 = s->emitter_d65.as<float>(); ds.cdf = s->cdf.as<float>(); ds.cie = s->cie.as<float>();
     ds.n_nodes = (uint32_t) (bvh.nodes.size() / 16); ds.n_tris = d->n_faces; ds.n_emitters = d->n_emitters;
+    ds.n_meshes = d->n_meshes; ds.n_bsdfs = d->n_bsdfs; ds.cdf_len = (uint32_t) cdf_all.size();
     ds.root_ref = bvh.root_ref;
     ds.stack_entries = (uint32_t) ((bvh.max_depth + 2 + 3) & ~3);
     std::memcpy(ds.s2c, d->camera.sample_to_camera, 64); std::memcpy(ds.to_world, d->camera.to_world, 64);
@@ -257,6 +258,11 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     const size_t lds_cap = getenv("MSK_LDS_SCENE_KB") ? (size_t) atoi(getenv("MSK_LDS_SCENE_KB")) * 1024 : 48 * 1024;
     s->lds_scene = scene_bytes <= lds_cap && stack_bytes + scene_bytes <= 64 * 1024;
     s->trace_lds_bytes = stack_bytes + (s->lds_scene ? scene_bytes : 0);
+    // LDS plan of k_shade_gen: the small lookup tables (tri_verts, mesh/bsdf/emitter records, cdf, d65, cie)
+    const size_t table_bytes = ((size_t) ds.n_tris * 3 + ds.n_meshes + ds.n_bsdfs + ds.n_emitters * 2 +
+                                (ds.n_emitters * 95 + 3) / 4 + (ds.cdf_len + 3) / 4 + 72) * 16;
+    s->lds_tables = table_bytes <= 40 * 1024;
+    s->shade_lds_bytes = s->lds_tables ? table_bytes : 0;
     if (s->trace_lds_bytes > ctx->prop.sharedMemPerBlock) {
         delete s;
         return fail(ctx, MSK_ERR_UNSUPPORTED, "BVH depth %d needs %zu B of traversal stack per block", bvh.max_depth, stack_bytes);
@@ -303,20 +309,19 @@ static std::vector<HostBlock> spiral_blocks(int w, int h, int bs, int *nbx, int 
 // wavefront driver
 // ------------------------------------------------------------------------------------------
 struct StateBufs {
-    DevBuf id, wl, thr, res, ray_o, ray_d, sh, contrib, hit, bs_pdf, flags, counts, ctrl;
+    DevBuf id, wl, thr, res, ray_o, ray_d, sh, contrib, hit, bs_pdf, counts, ctrl;
     PathState st;
     hipError_t alloc(size_t n, uint32_t n_regions) {
         hipError_t e;
 #define A_(b, sz) if ((e = b.alloc(n * (sz))) != hipSuccess) return e;
-        A_(id, 8) A_(wl, 16) A_(thr, 16) A_(res, 16) A_(ray_o, 16) A_(ray_d, 16) A_(sh, 16) A_(contrib, 16) A_(hit, 16)
-        A_(bs_pdf, 4) A_(flags, 4)
+        A_(id, 16) A_(wl, 16) A_(thr, 16) A_(res, 16) A_(ray_o, 16) A_(ray_d, 16) A_(sh, 16) A_(contrib, 16) A_(hit, 16)
+        A_(bs_pdf, 4)
 #undef A_
-        if ((e = counts.alloc((size_t) n_regions * 4)) != hipSuccess) return e;
+        if ((e = counts.alloc((size_t) n_regions * sizeof(RegionCtl))) != hipSuccess) return e;
         if ((e = ctrl.alloc(sizeof(Ctrl))) != hipSuccess) return e;
-        st.id = id.as<uint2>(); st.wl = wl.as<float4>(); st.thr = thr.as<float4>(); st.res = res.as<float4>();
+        st.id = id.as<uint4>(); st.wl = wl.as<float4>(); st.thr = thr.as<float4>(); st.res = res.as<float4>();
         st.ray_o = ray_o.as<float4>(); st.ray_d = ray_d.as<float4>(); st.sh = sh.as<float4>();
         st.contrib = contrib.as<float4>(); st.hit = hit.as<float4>(); st.bs_pdf = bs_pdf.as<float>();
-        st.flags = flags.as<uint32_t>();
         return hipSuccess;
     }
 };
@@ -342,22 +347,30 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
 
 // Renders the samples of `pix` (pass pixel table, host) into records; leaves records on device.
 static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_params *prm, uint32_t spp_owned,
-                         const uint32_t *d_pix, uint64_t n_pix, float4 *rec_a, float *rec_b, StateBufs &sb,
+                         const uint4 *d_pix, uint64_t n_pix, float4 *rec_a, float *rec_b, StateBufs &sb,
                          uint32_t region_size, uint32_t n_regions, msk_stats *stats, EventPool &ev,
                          std::vector<std::pair<hipEvent_t, hipEvent_t>> &ev_trace,
                          std::vector<std::pair<hipEvent_t, hipEvent_t>> &ev_shade) {
     msk_ctx *ctx = sc->ctx;
     const unsigned long long total = (unsigned long long) n_pix * spp_owned;
-    Ctrl init; std::memset(&init, 0, sizeof init);
-    init.total_samples = total;
-    HIP_TRY(ctx, hipMemcpyAsync(sb.ctrl.p, &init, sizeof init, hipMemcpyHostToDevice, stream));
-    HIP_TRY(ctx, hipMemsetAsync(sb.counts.p, 0, (size_t) n_regions * 4, stream));
+    // static, interleaved partition of the pass's samples over the regions (see RegionCtl)
+    std::vector<RegionCtl> init(n_regions);
+    std::memset(init.data(), 0, init.size() * sizeof(RegionCtl));
+    const unsigned long long n_chunks = (total + 63) / 64;
+    for (uint32_t r = 0; r < n_regions; ++r) {
+        const unsigned long long mine = n_chunks > r ? (n_chunks - r + n_regions - 1) / n_regions : 0;
+        unsigned long long n = mine * 64;
+        if (mine && (mine - 1) * n_regions + r == n_chunks - 1) n -= n_chunks * 64 - total;   // partial last chunk
+        init[r].next_sample = 0; init[r].end_sample = n;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(sb.counts.p, init.data(), init.size() * sizeof(RegionCtl), hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
     PassParams pp;
     pp.seed = prm->seed; pp.spp_owned = spp_owned; pp.sample_first = prm->sample_first;
     pp.sample_stride = prm->sample_stride ? prm->sample_stride : 1;
     pp.rr_depth = prm->rr_depth; pp.max_depth = prm->max_depth; pp.hide_emitters = prm->hide_emitters;
     pp.pix_table = d_pix; pp.rec_a = rec_a; pp.rec_b = rec_b;
-    pp.region_size = region_size; pp.n_regions = n_regions; pp.counts = sb.counts.as<uint32_t>();
+    pp.region_size = region_size; pp.n_regions = n_regions; pp.regions = sb.counts.as<RegionCtl>();
     const uint32_t grid = (n_regions * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
     const uint32_t group = env_u32("MSK_SYNC_GROUP", 8);
     const bool timing = stats != nullptr;
@@ -366,16 +379,20 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
         for (uint32_t g = 0; g < group; ++g, ++it) {
             hipEvent_t a = nullptr, b = nullptr, c = nullptr;
             if (timing) { a = ev.get(); b = ev.get(); c = ev.get(); (void) hipEventRecord(a, stream); }
-            hipLaunchKernelGGL(k_shade_gen, dim3(grid), dim3(MSK_BLOCK), 0, stream, sc->dev, sb.st, pp, sb.ctrl.as<Ctrl>(), it & 1u);
+            if (sc->lds_tables)
+                hipLaunchKernelGGL(k_shade_gen<true>, dim3(grid), dim3(MSK_BLOCK), sc->shade_lds_bytes, stream, sc->dev, sb.st, pp);
+            else
+                hipLaunchKernelGGL(k_shade_gen<false>, dim3(grid), dim3(MSK_BLOCK), 0, stream, sc->dev, sb.st, pp);
             if (timing) (void) hipEventRecord(b, stream);
             launch_trace(sc, stream, sb.st, pp);
             if (timing) { (void) hipEventRecord(c, stream); ev_shade.push_back({a, b}); ev_trace.push_back({b, c}); }
         }
+        hipLaunchKernelGGL(k_reduce_ctl, dim3(1), dim3(MSK_BLOCK), 0, stream, sb.counts.as<RegionCtl>(), n_regions, sb.ctrl.as<Ctrl>());
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctrl, sb.ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
         HIP_TRY(ctx, hipStreamSynchronize(stream));
         const Ctrl &h = *ctx->h_ctrl;
-        if (h.next_sample >= total && h.live[(it - 1) & 1u] == 0) break;
+        if (h.remaining == 0 && h.live == 0) break;
         if (it > 100000000u) return fail(ctx, MSK_ERR_HIP, "wavefront loop did not terminate");
     }
     if (stats) {
@@ -462,7 +479,7 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     for (auto &b : owned) all_samples += (uint64_t) b.size_x * b.size_y * spp_owned;
     pool_shape(all_samples, &region_size, &n_regions);
     const size_t n_slots = (size_t) region_size * n_regions;
-    const size_t state_bytes = n_slots * 144 + 4096;
+    const size_t state_bytes = n_slots * 148 + 4096;
     size_t budget = getenv("MSK_RECORD_BUDGET_MB") ? (size_t) atoll(getenv("MSK_RECORD_BUDGET_MB")) << 20
                                                    : (free_b > state_bytes ? (size_t) ((free_b - state_bytes) * 0.8) : 0);
     const size_t rec_bytes_per_block_max = (size_t) bs * bs * spp_owned * 20;
@@ -486,15 +503,20 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_trace, ev_shade, ev_resolve;
     DevBuf d_pix, d_rec_a, d_rec_b;
     for (auto &ps : passes) {
-        std::vector<uint32_t> pix;
-        for (size_t b = ps.first; b < ps.second; ++b)
+        std::vector<uint4> pix;
+        for (size_t b = ps.first; b < ps.second; ++b) {
+            const uint32_t npix = (uint32_t) (owned[b].size_x * owned[b].size_y);
             for (int y = 0; y < owned[b].size_y; ++y)
-                for (int x = 0; x < owned[b].size_x; ++x)
-                    pix.push_back((uint32_t) ((owned[b].off_y + y) * W + owned[b].off_x + x));
+                for (int x = 0; x < owned[b].size_x; ++x) {
+                    const uint64_t rec0 = (uint64_t) owned[b].pixel_base * spp_owned + (uint32_t) (y * owned[b].size_x + x);
+                    pix.push_back(make_uint4((uint32_t) ((owned[b].off_y + y) * W + owned[b].off_x + x), (uint32_t) rec0,
+                                             (uint32_t) (rec0 >> 32), npix));
+                }
+        }
         const uint64_t n_rec = (uint64_t) pix.size() * spp_owned;
         HIP_TRY(ctx, d_pix.upload(pix));
         if (d_rec_a.bytes < n_rec * 16) { HIP_TRY(ctx, d_rec_a.alloc(n_rec * 16)); HIP_TRY(ctx, d_rec_b.alloc(n_rec * 4)); }
-        rc = run_wavefront(sc, stream, prm, spp_owned, d_pix.as<uint32_t>(), pix.size(), d_rec_a.as<float4>(),
+        rc = run_wavefront(sc, stream, prm, spp_owned, d_pix.as<uint4>(), pix.size(), d_rec_a.as<float4>(),
                            d_rec_b.as<float>(), sb, region_size, n_regions, stats, ev, ev_trace, ev_shade);
         if (rc) return rc;
         const uint32_t nb = (uint32_t) (ps.second - ps.first);
@@ -556,11 +578,12 @@ extern "C" int msk_gpu_sample_pixels(msk_scene *scene, const msk_render_params *
     int rc = check_params(ctx, prm, 1);
     if (rc) return rc;
     const int W = scene->dev.width, H = scene->dev.height;
-    std::vector<uint32_t> pix(n_pixels);
+    std::vector<uint4> pix(n_pixels);
+    if (n_pixels >> 32) return fail(ctx, MSK_ERR_INVALID_ARG, "too many pixels");
     for (uint64_t i = 0; i < n_pixels; ++i) {
         const int x = pixels[2 * i], y = pixels[2 * i + 1];
         if (x < 0 || y < 0 || x >= W || y >= H) return fail(ctx, MSK_ERR_INVALID_ARG, "pixel (%d,%d) outside the %dx%d film", x, y, W, H);
-        pix[i] = (uint32_t) (y * W + x);
+        pix[i] = make_uint4((uint32_t) (y * W + x), (uint32_t) i, 0u, (uint32_t) n_pixels);   // one pseudo-block
     }
     if (n_pixels == 0) return MSK_OK;
     msk_render_params p = *prm; p.sample_first = 0; p.sample_stride = 1;
@@ -573,11 +596,11 @@ extern "C" int msk_gpu_sample_pixels(msk_scene *scene, const msk_render_params *
     HIP_TRY(ctx, ox.alloc(n_rec * 12)); HIP_TRY(ctx, op.alloc(n_rec * 8));
     EventPool ev{ctx, 0};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> e1, e2;
-    rc = run_wavefront(scene, ctx->stream, &p, p.spp, d_pix.as<uint32_t>(), n_pixels, ra.as<float4>(), rb.as<float>(), sb,
+    rc = run_wavefront(scene, ctx->stream, &p, p.spp, d_pix.as<uint4>(), n_pixels, ra.as<float4>(), rb.as<float>(), sb,
                        region_size, n_regions, nullptr, ev, e1, e2);
     if (rc) return rc;
     hipLaunchKernelGGL(k_export_records, dim3((uint32_t) ((n_rec + 255) / 256)), dim3(256), 0, ctx->stream, ra.as<float4>(),
-                       rb.as<float>(), n_rec, ox.as<float>(), op.as<float>());
+                       rb.as<float>(), n_pixels, p.spp, ox.as<float>(), op.as<float>());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out_xyz, ox.p, n_rec * 12, hipMemcpyDeviceToHost));
     if (out_pos) HIP_TRY(ctx, hipMemcpy(out_pos, op.p, n_rec * 8, hipMemcpyDeviceToHost));

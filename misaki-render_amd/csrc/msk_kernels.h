@@ -42,7 +42,7 @@ struct DeviceScene {
     const float *emitter_d65;   // 95 floats per emitter (d65 * d65_scale)
     const float *cdf;           // concatenated area CDFs (face_count+1 each)
     const float *cie;           // 285 floats
-    uint32_t n_nodes, n_tris, n_emitters;
+    uint32_t n_nodes, n_tris, n_emitters, n_meshes, n_bsdfs, cdf_len;
     uint32_t root_ref;          // packed child ref of the root
     uint32_t stack_entries;     // per-lane traversal stack depth (BVH depth + 2)
     float s2c[16], to_world[16];
@@ -54,7 +54,7 @@ struct DeviceScene {
 };
 
 struct PathState {
-    uint2 *id;          // {pixel-in-pass index j, owned-sample index si}
+    uint4 *id;          // {pass pixel j, owned-sample index si, film pixel y*W+x, depth | MSK_FLAG_SHADOW}
     float4 *wl, *thr, *res;
     float4 *ray_o;      // o.xyz, tmin
     float4 *ray_d;      // d.xyz, tmax
@@ -62,24 +62,33 @@ struct PathState {
     float4 *contrib;    // NEE contribution added when the shadow ray is unoccluded
     float4 *hit;        // t,u,v,prim
     float *bs_pdf;
-    uint32_t *flags;    // depth | MSK_FLAG_SHADOW
 };
 
-struct Ctrl {
-    unsigned long long next_sample, total_samples;
-    unsigned long long live[2];
+// Per-region bookkeeping, one record per wave-region, touched only by its owner wave: no atomics
+// anywhere on the wavefront path (a single hot cache line of global counters serialises at
+// ~12 ns per atomic, which at 4 k waves x 5 counters was the whole launch time).
+struct RegionCtl {
+    // This region's static share of the pass's samples: the 64-sample chunks c with
+    // c % n_regions == region, in order.  next/end count samples within that share; sample q of the
+    // share is global sample ((q >> 6) * n_regions + region) * 64 + (q & 63).  Interleaving (rather
+    // than contiguous slices) keeps every region's mix of cheap and expensive pixels the same.
+    unsigned long long next_sample, end_sample;
     unsigned long long segments, shadow_rays, samples_done;
+    uint32_t count, pad;                          // live slots
+};
+struct Ctrl {                                     // written by k_reduce_ctl, read by the host
+    unsigned long long live, remaining, segments, shadow_rays, samples_done;
 };
 
 struct PassParams {
     uint64_t seed;
     uint32_t spp_owned, sample_first, sample_stride;
     int32_t rr_depth, max_depth, hide_emitters;
-    const uint32_t *pix_table;    // pass pixel j -> film linear index y*W+x
-    float4 *rec_a;                // per sample {X,Y,Z,pos.x}
-    float *rec_b;                 // per sample pos.y
+    const uint4 *pix_table;       // pass pixel j -> {film index y*W+x, rec0 lo, rec0 hi, pixels in its block}
+    float4 *rec_a;                // per sample {X,Y,Z,pos.x}; record of (j, si) = rec0(j) + si * npix(j):
+    float *rec_b;                 // per sample pos.y           i.e. [block][sample][pixel], pixel fastest
     uint32_t region_size, n_regions;
-    uint32_t *counts;             // live slots per region
+    RegionCtl *regions;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -203,12 +212,12 @@ k_trace(DeviceScene sc, PathState st, PassParams pp) {
     const uint32_t wave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
     if (wave >= pp.n_regions) return;
-    const uint32_t n = pp.counts[wave];
+    const uint32_t n = pp.regions[wave].count;
     const size_t base = (size_t) wave * pp.region_size;
     for (uint32_t c = lane; c < n; c += MSK_WAVE) {
         const size_t i = base + c;
         const float4 ro = st.ray_o[i], rd = st.ray_d[i];
-        const uint32_t fl = st.flags[i];
+        const uint32_t fl = st.id[i].w;
         const f3 o = mk3(ro.x, ro.y, ro.z);
         float bt, bu, bv; uint32_t bp;
         if (fl & MSK_FLAG_SHADOW) {
@@ -263,8 +272,42 @@ struct Interaction {
     int bsdf_id, emitter_id;
 };
 
+// Small read-only scene tables of the shading kernel; staged in LDS when they fit (every hit
+// looks them up through a chain of dependent indices, which from HBM/L2 costs a round trip each).
+struct SceneTables {
+    const float4 *tri_verts, *tri_normals, *tri_uvs;
+    const int4 *mesh_info;
+    const float4 *bsdfs, *emitters;
+    const float *emitter_d65, *cdf, *cie;
+};
+MSK_DEV uint32_t tables_lds_float4s(const DeviceScene &sc) {
+    return sc.n_tris * 3 + sc.n_meshes + sc.n_bsdfs + sc.n_emitters * 2 + (sc.n_emitters * 95 + 3) / 4 + (sc.cdf_len + 3) / 4 + 72;
+}
+template <bool LDS_TABLES>
+MSK_DEV SceneTables stage_tables(const DeviceScene &sc, float4 *lds) {
+    SceneTables t;
+    t.tri_normals = sc.tri_normals; t.tri_uvs = sc.tri_uvs;
+    if (!LDS_TABLES) {
+        t.tri_verts = sc.tri_verts; t.mesh_info = sc.mesh_info; t.bsdfs = sc.bsdfs; t.emitters = sc.emitters;
+        t.emitter_d65 = sc.emitter_d65; t.cdf = sc.cdf; t.cie = sc.cie;
+        return t;
+    }
+    float4 *p = lds;
+    auto copy4 = [&](const float4 *src, uint32_t n) { for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) p[i] = src[i]; float4 *r = p; p += n; return r; };
+    auto copy1 = [&](const float *src, uint32_t n) { float *d = (float *) p; for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = src[i]; p += (n + 3) / 4; return d; };
+    t.tri_verts = copy4(sc.tri_verts, sc.n_tris * 3);
+    t.mesh_info = (const int4 *) copy4((const float4 *) sc.mesh_info, sc.n_meshes);
+    t.bsdfs = copy4(sc.bsdfs, sc.n_bsdfs);
+    t.emitters = copy4(sc.emitters, sc.n_emitters * 2);
+    t.emitter_d65 = copy1(sc.emitter_d65, sc.n_emitters * 95);
+    t.cdf = copy1(sc.cdf, sc.cdf_len);
+    t.cie = copy1(sc.cie, 285);
+    __syncthreads();
+    return t;
+}
+
 // mesh.cpp:50-101 + interaction.cpp:23-37 + interaction.h:55-60
-MSK_DEV Interaction make_interaction(const DeviceScene &sc, float4 hit, f3 ray_d) {
+MSK_DEV Interaction make_interaction(const SceneTables &sc, float4 hit, f3 ray_d) {
     Interaction si;
     const uint32_t prim = __float_as_uint(hit.w);
     const float4 a = sc.tri_verts[(size_t) prim * 3], b = sc.tri_verts[(size_t) prim * 3 + 1],
@@ -303,7 +346,7 @@ MSK_DEV Interaction make_interaction(const DeviceScene &sc, float4 hit, f3 ray_d
 }
 
 // spectra/srgb_d65.cpp:34-36
-MSK_DEV spec emitter_radiance(const DeviceScene &sc, int e, spec wl) {
+MSK_DEV spec emitter_radiance(const SceneTables &sc, int e, spec wl) {
     const float4 c = sc.emitters[2 * e];
     return regular_eval(sc.emitter_d65 + 95 * e, wl) * srgb_model_eval(c.x, c.y, c.z, wl);
 }
@@ -311,13 +354,16 @@ MSK_DEV spec emitter_radiance(const DeviceScene &sc, int e, spec wl) {
 // ------------------------------------------------------------------------------------------
 // k_shade_gen
 // ------------------------------------------------------------------------------------------
+template <bool LDS_TABLES>
 __global__ void __launch_bounds__(MSK_BLOCK)
-k_shade_gen(DeviceScene sc, PathState st, PassParams pp, Ctrl *ctrl, uint32_t parity) {
+k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
+    extern __shared__ float4 lds_dyn[];
+    const SceneTables tb = stage_tables<LDS_TABLES>(sc, lds_dyn);
     const uint32_t wave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->live[parity ^ 1] = 0;   // slot the NEXT launch accumulates into
     if (wave >= pp.n_regions) return;
-    const uint32_t n_in = pp.counts[wave];
+    RegionCtl rc = pp.regions[wave];
+    const uint32_t n_in = rc.count;
     const size_t base = (size_t) wave * pp.region_size;
     const uint32_t n_em = sc.n_emitters;
     uint32_t cursor = 0, n_shadow = 0, n_done = 0;
@@ -327,14 +373,14 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp, Ctrl *ctrl, uint32_t pa
         const bool active = c < n_in;
         const size_t i = base + (active ? c : 0);
         // ---- load
-        uint2 id = st.id[i];
+        const uint4 id = st.id[i];
         spec wl = from4(st.wl[i]), thr = from4(st.thr[i]), res = from4(st.res[i]);
         const float4 rd4 = st.ray_d[i];
         const float4 hit = st.hit[i];
         float bs_pdf = st.bs_pdf[i];
-        uint32_t depth = st.flags[i] & MSK_DEPTH_MASK;
+        uint32_t depth = id.w & MSK_DEPTH_MASK;
         const f3 rd = mk3(rd4.x, rd4.y, rd4.z);
-        const uint32_t pix = pp.pix_table[id.x];
+        const uint32_t pix = id.z;
         const uint32_t sidx = pp.sample_first + id.y * pp.sample_stride;
         const uint64_t key = counter_key(pp.seed, pix, sidx);
 
@@ -345,14 +391,14 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp, Ctrl *ctrl, uint32_t pa
 
         if (alive && hit.x == MSK_INF_F) alive = false;                   // path.cpp:34-41 / 96-97, no environment
         if (alive) {
-            Interaction si = make_interaction(sc, hit, rd);
-            const float4 bs = sc.bsdfs[si.bsdf_id];
+            Interaction si = make_interaction(tb, hit, rd);
+            const float4 bs = tb.bsdfs[si.bsdf_id];
             if (depth > 1) {
                 // ---- tail of the previous bounce: emitter hit by the BSDF sample (path.cpp:82-88,103-108)
                 if (si.emitter_id >= 0) {
-                    const spec value = si.wi.z > 0.f ? emitter_radiance(sc, si.emitter_id, wl) : splat(0.f);
+                    const spec value = si.wi.z > 0.f ? emitter_radiance(tb, si.emitter_id, wl) : splat(0.f);
                     // set_query (records.cpp:7-14) + pdf_emitter_direct (scene.cpp:105-112, shape.cpp:80-86)
-                    float pdf = sc.emitters[2 * si.emitter_id].w;
+                    float pdf = tb.emitters[2 * si.emitter_id].w;
                     const float dp = fabsf(dot(rd, si.sh.n));
                     pdf *= (dp != 0.f) ? (si.t * si.t) / dp : 0.f;
                     if (n_em != 1) pdf = pdf * (1.f / n_em);
@@ -369,7 +415,7 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp, Ctrl *ctrl, uint32_t pa
             // loop condition of the bounce that starts now (path.cpp:33)
             if (alive && !((int) depth <= pp.max_depth || pp.max_depth < 0)) alive = false;
             if (alive && depth == 1 && si.emitter_id >= 0 && !pp.hide_emitters) {   // path.cpp:42-47
-                const spec le = si.wi.z > 0.f ? emitter_radiance(sc, si.emitter_id, wl) : splat(0.f);
+                const spec le = si.wi.z > 0.f ? emitter_radiance(tb, si.emitter_id, wl) : splat(0.f);
                 res = res + thr * le;
             }
             if (alive && (int) depth >= pp.max_depth && pp.max_depth > 0) alive = false;   // path.cpp:48-49
@@ -388,9 +434,9 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp, Ctrl *ctrl, uint32_t pa
                         u.x = (u.x - index * light_sel_pdf) * n_em;
                         e = index;
                     }
-                    const float4 e0 = sc.emitters[2 * e], e1 = sc.emitters[2 * e + 1];
+                    const float4 e0 = tb.emitters[2 * e], e1 = tb.emitters[2 * e + 1];
                     const uint32_t first_face = __float_as_uint(e1.y), n_faces = __float_as_uint(e1.z);
-                    const float *cdf = sc.cdf + __float_as_uint(e1.w);
+                    const float *cdf = tb.cdf + __float_as_uint(e1.w);
                     // Distribution1D::sample_reuse (core/distribution.h:106-116)
                     uint32_t lo = 0, hi = n_faces + 1;
                     while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (!(u.y < cdf[mid])) lo = mid + 1; else hi = mid; }
@@ -398,17 +444,17 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp, Ctrl *ctrl, uint32_t pa
                     fidx = fidx < 0 ? 0 : fidx; fidx = fidx > (int) n_faces - 1 ? (int) n_faces - 1 : fidx;
                     u.y = (u.y - cdf[fidx]) / (cdf[fidx + 1] - cdf[fidx]);
                     const uint32_t lprim = first_face + (uint32_t) fidx;
-                    const float4 la = sc.tri_verts[(size_t) lprim * 3], lb = sc.tri_verts[(size_t) lprim * 3 + 1],
-                                 lc = sc.tri_verts[(size_t) lprim * 3 + 2];
+                    const float4 la = tb.tri_verts[(size_t) lprim * 3], lb = tb.tri_verts[(size_t) lprim * 3 + 1],
+                                 lc = tb.tri_verts[(size_t) lprim * 3 + 2];
                     const f3 p0 = mk3(la.x, la.y, la.z), p1 = mk3(lb.x, lb.y, lb.z), p2 = mk3(lc.x, lc.y, lc.z);
                     const f3 ed0 = p1 - p0, ed1 = p2 - p0;                 // mesh.cpp:103-133
                     const f2 bc = square_to_uniform_triangle(u);
                     const f3 lp = p0 + ed0 * bc.x + ed1 * bc.y;
                     f3 ln = normalized(cross(ed0, ed1));
-                    const int4 lmi = sc.mesh_info[__float_as_uint(la.w)];
+                    const int4 lmi = tb.mesh_info[__float_as_uint(la.w)];
                     if (lmi.z & 1) {
-                        const float4 na = sc.tri_normals[(size_t) lprim * 3], nb = sc.tri_normals[(size_t) lprim * 3 + 1],
-                                     nc = sc.tri_normals[(size_t) lprim * 3 + 2];
+                        const float4 na = tb.tri_normals[(size_t) lprim * 3], nb = tb.tri_normals[(size_t) lprim * 3 + 1],
+                                     nc = tb.tri_normals[(size_t) lprim * 3 + 2];
                         ln = normalized(mk3(na.x, na.y, na.z) * (1.f - bc.x - bc.y) + mk3(nb.x, nb.y, nb.z) * bc.x +
                                         mk3(nc.x, nc.y, nc.z) * bc.y);
                     }
@@ -421,7 +467,7 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp, Ctrl *ctrl, uint32_t pa
                     pdf *= (dp != 0.f) ? dist2 / dp : 0.f;
                     spec emitter_val;
                     if (dot(d, ln) < 0.f && pdf != 0.f) {                  // area.cpp:39-44
-                        emitter_val = emitter_radiance(sc, (int) e, wl) / pdf;
+                        emitter_val = emitter_radiance(tb, (int) e, wl) / pdf;
                     } else {
                         pdf = 0.f; emitter_val = splat(0.f);
                     }
@@ -464,10 +510,11 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp, Ctrl *ctrl, uint32_t pa
             for (int k = 0; k < 4; ++k) wgt.v[k] = wavelength_weight(wl.v[k]);
             const spec result = res * wgt;
             float X, Y, Z;
-            spectrum_to_xyz(sc.cie, result, wl, &X, &Y, &Z);
+            spectrum_to_xyz(tb.cie, result, wl, &X, &Y, &Z);
             const f2 jit = counter_pair(key, 0);
             const float px = (float) (pix % (uint32_t) sc.width) + jit.x, py = (float) (pix / (uint32_t) sc.width) + jit.y;
-            const size_t r = (size_t) id.x * pp.spp_owned + id.y;
+            const uint4 pt = pp.pix_table[id.x];
+            const size_t r = (((size_t) pt.z << 32) | pt.y) + (size_t) id.y * pt.w;
             pp.rec_a[r] = make_float4(X, Y, Z, px);
             pp.rec_b[r] = py;
         }
@@ -479,29 +526,23 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp, Ctrl *ctrl, uint32_t pa
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every load of this chunk has landed before slots are overwritten
         if (alive) {
             const size_t o = base + cursor + off;
-            st.id[o] = id; st.wl[o] = to4(wl); st.thr[o] = to4(thr); st.res[o] = to4(res);
+            st.id[o] = make_uint4(id.x, id.y, id.z, depth | (has_shadow ? MSK_FLAG_SHADOW : 0u));
+            st.wl[o] = to4(wl); st.thr[o] = to4(thr); st.res[o] = to4(res);
             st.ray_o[o] = new_o; st.ray_d[o] = new_d; st.sh[o] = new_sh; st.contrib[o] = to4(contrib);
-            st.bs_pdf[o] = bs_pdf; st.flags[o] = depth | (has_shadow ? MSK_FLAG_SHADOW : 0u);
+            st.bs_pdf[o] = bs_pdf;
         }
         cursor += __popcll(m);
     }
 
     // ---- regeneration: fill the free tail with new camera samples (integrator.cpp:103-116)
     const uint32_t n_free = pp.region_size - cursor;
-    unsigned long long first = 0; uint32_t got = 0;
-    if (lane == 0 && n_free > 0) {
-        const unsigned long long total = ctrl->total_samples;
-        // cheap pre-check keeps the cursor from running away once the samples are exhausted
-        if (__hip_atomic_load(&ctrl->next_sample, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
-            first = atomicAdd(&ctrl->next_sample, (unsigned long long) n_free);
-            if (first < total) got = (uint32_t) ((total - first < n_free) ? (total - first) : n_free);
-        }
-    }
-    first = __shfl(first, 0); got = __shfl(got, 0);
+    const unsigned long long first = rc.next_sample, left = rc.end_sample - rc.next_sample;
+    const uint32_t got = (uint32_t) (left < n_free ? left : n_free);
     for (uint32_t k = lane; k < got; k += MSK_WAVE) {
-        const unsigned long long sidx_lin = first + k;
+        const unsigned long long q = first + k;
+        const unsigned long long sidx_lin = (((q >> 6) * pp.n_regions + wave) << 6) | (q & 63ull);
         const uint32_t j = (uint32_t) (sidx_lin / pp.spp_owned), si = (uint32_t) (sidx_lin % pp.spp_owned);
-        const uint32_t pix = pp.pix_table[j];
+        const uint32_t pix = pp.pix_table[j].x;
         const uint64_t key = counter_key(pp.seed, pix, pp.sample_first + si * pp.sample_stride);
         const f2 jit = counter_pair(key, 0);
         const float wsample = counter_pair(key, 1).x;
@@ -527,20 +568,36 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp, Ctrl *ctrl, uint32_t pa
         const f3 dw = mk3(m[0] * dl.x + (m[1] * dl.y + m[2] * dl.z), m[4] * dl.x + (m[5] * dl.y + m[6] * dl.z),
                           m[8] * dl.x + (m[9] * dl.y + m[10] * dl.z));
         const size_t o = base + cursor + k;
-        st.id[o] = make_uint2(j, si);
+        st.id[o] = make_uint4(j, si, pix, 1u);
         st.wl[o] = to4(wl); st.thr[o] = make_float4(1.f, 1.f, 1.f, 1.f); st.res[o] = make_float4(0.f, 0.f, 0.f, 0.f);
         st.ray_o[o] = make_float4(ow.x, ow.y, ow.z, sc.near_clip * inv_z);
         st.ray_d[o] = make_float4(dw.x, dw.y, dw.z, sc.far_clip * inv_z);
         st.sh[o] = make_float4(0, 0, 0, 0); st.contrib[o] = make_float4(0, 0, 0, 0);
-        st.bs_pdf[o] = 0.f; st.flags[o] = 1u;
+        st.bs_pdf[o] = 0.f;
     }
     if (lane == 0) {
         const uint32_t n_out = cursor + got;
-        pp.counts[wave] = n_out;
-        if (n_out) { atomicAdd(&ctrl->live[parity], (unsigned long long) n_out); atomicAdd(&ctrl->segments, (unsigned long long) n_out); }
-        if (n_shadow) atomicAdd(&ctrl->shadow_rays, (unsigned long long) n_shadow);
-        if (n_done) atomicAdd(&ctrl->samples_done, (unsigned long long) n_done);
+        rc.count = n_out; rc.next_sample = first + got;
+        rc.segments += n_out; rc.shadow_rays += n_shadow; rc.samples_done += n_done;
+        pp.regions[wave] = rc;
     }
+}
+
+// sums the per-region records for the host (termination test + statistics); one block
+__global__ void __launch_bounds__(MSK_BLOCK) k_reduce_ctl(const RegionCtl *regions, uint32_t n_regions, Ctrl *out) {
+    __shared__ unsigned long long sh[5][MSK_BLOCK];
+    unsigned long long a[5] = {0, 0, 0, 0, 0};
+    for (uint32_t i = threadIdx.x; i < n_regions; i += MSK_BLOCK) {
+        const RegionCtl r = regions[i];
+        a[0] += r.count; a[1] += r.end_sample - r.next_sample; a[2] += r.segments; a[3] += r.shadow_rays; a[4] += r.samples_done;
+    }
+    for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] = a[k];
+    __syncthreads();
+    for (uint32_t s = MSK_BLOCK / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out->live = sh[0][0]; out->remaining = sh[1][0]; out->segments = sh[2][0]; out->shadow_rays = sh[3][0]; out->samples_done = sh[4][0]; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -574,12 +631,14 @@ k_resolve_blocks(DeviceScene sc, const BlockInfo *blocks, uint32_t n_blocks, con
     const int y_lo = max(0, ty - border - span), y_hi = min(b.size_y - 1, ty - border + span);
     const int x_lo = max(0, tx - border - span), x_hi = min(b.size_x - 1, tx - border + span);
     const float offx = (float) (b.off_x - border), offy = (float) (b.off_y - border);
+    const uint32_t npix = (uint32_t) (b.size_x * b.size_y);
     for (int y = y_lo; y <= y_hi; ++y)
         for (int x = x_lo; x <= x_hi; ++x) {
-            const size_t r0 = (size_t) (b.pixel_base + (uint32_t) (y * b.size_x + x)) * spp_owned;
+            const size_t r0 = (size_t) b.pixel_base * spp_owned + (uint32_t) (y * b.size_x + x);
+#pragma unroll 4
             for (uint32_t s = 0; s < spp_owned; ++s) {
-                const float4 ra = rec_a[r0 + s];
-                const float pyv = rec_b[r0 + s];
+                const float4 ra = rec_a[r0 + (size_t) s * npix];
+                const float pyv = rec_b[r0 + (size_t) s * npix];
                 const float px = ra.w - 0.5f - offx, py = pyv - 0.5f - offy;
                 const int lox = max((int) ceilf(px - radius), 0), loy = max((int) ceilf(py - radius), 0);
                 const int hix = min((int) floorf(px + radius), sx - 1), hiy = min((int) floorf(py + radius), sy - 1);
@@ -634,13 +693,15 @@ k_film_put(DeviceScene sc, const BlockInfo *blocks, const int32_t *block_of, con
     for (int c = 0; c < 5; ++c) o[c] = acc[c];
 }
 
-// records of listed pixels -> {X,Y,Z} + position (msk_gpu_sample_pixels)
-__global__ void k_export_records(const float4 *rec_a, const float *rec_b, uint64_t n, float *out_xyz, float *out_pos) {
+// records of listed pixels ([sample][pixel] on device) -> {X,Y,Z} + position, [pixel][sample]
+__global__ void k_export_records(const float4 *rec_a, const float *rec_b, uint64_t n_pix, uint32_t spp, float *out_xyz,
+                                 float *out_pos) {
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n_pix * spp) return;
+    const uint64_t s = i / n_pix, p = i % n_pix, o = p * spp + s;
     const float4 a = rec_a[i];
-    out_xyz[i * 3] = a.x; out_xyz[i * 3 + 1] = a.y; out_xyz[i * 3 + 2] = a.z;
-    if (out_pos) { out_pos[i * 2] = a.w; out_pos[i * 2 + 1] = rec_b[i]; }
+    out_xyz[o * 3] = a.x; out_xyz[o * 3 + 1] = a.y; out_xyz[o * 3 + 2] = a.z;
+    if (out_pos) { out_pos[o * 2] = a.w; out_pos[o * 2 + 1] = rec_b[i]; }
 }
 
 }  // namespace msk
