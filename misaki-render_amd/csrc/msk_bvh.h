@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -49,7 +50,8 @@ struct Builder {
     std::vector<uint32_t> order;
     std::vector<uint32_t> leaf_order;
     float pad = 0;
-    static constexpr int kLeaf = 4, kBins = 16;
+    static constexpr int kBins = 16;
+    int kLeaf = 2;              // max triangles per leaf (MSK_BVH_LEAF overrides for experiments)
     struct Child { int ref; int count; Box box; };
     std::vector<float> nodes;
     int max_depth = 0;
@@ -131,6 +133,7 @@ struct Builder {
 static inline Built build(const float *pos, uint32_t n) {
     Built out;
     Builder b; b.pos = pos; b.n = n;
+    if (const char *e = getenv("MSK_BVH_LEAF")) b.kLeaf = std::max(1, std::min(8, atoi(e)));
     b.tb.resize(n); b.tc.resize(n); b.order.resize(n);
     Box all;
     for (uint32_t i = 0; i < n; ++i) {

@@ -428,7 +428,7 @@ static uint32_t owned_spp(const msk_render_params *p) {
 }
 
 static void pool_shape(uint64_t total_samples, uint32_t *region_size, uint32_t *n_regions) {
-    uint32_t rs = env_u32("MSK_REGION_SIZE", 512), nr = env_u32("MSK_REGIONS", 4096);
+    uint32_t rs = env_u32("MSK_REGION_SIZE", 256), nr = env_u32("MSK_REGIONS", 16384);
     rs = std::max(64u, (rs + 63u) & ~63u);
     const uint64_t need = (total_samples + rs - 1) / rs;
     if (need < nr) nr = (uint32_t) std::max<uint64_t>(need, 1);

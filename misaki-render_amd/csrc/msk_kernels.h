@@ -134,49 +134,55 @@ MSK_DEV bool box_test(float lox, float loy, float loz, float hix, float hiy, flo
 
 // ANY: returns true on the first accepted triangle.  Closest: keeps (t, prim)-minimal hit.
 // nodes/tris may point into LDS or HBM.  stack: this lane's LDS stack, stride MSK_BLOCK.
+// "while-while" form: the inner loop walks inner nodes until the lane holds a leaf (or runs out of
+// work), then the wave tests leaf triangles together — lanes at inner nodes do not sit through
+// other lanes' triangle tests one node at a time.
 template <bool ANY>
 MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict__ tris, uint32_t root_ref,
                       uint32_t n_tris, f3 o, f3 d, float tmin, float tmax, uint32_t *stack, float *best_t, float *best_u,
                       float *best_v, uint32_t *best_prim) {
     float bt = tmax, bu = 0.f, bv = 0.f;
     uint32_t bp = MSK_NO_PRIM;
-    if (n_tris == 0) { *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp; return false; }
+    *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
+    if (n_tris == 0) return false;
     const f3 idir = mk3(fminf(fmaxf(1.f / d.x, -1e25f), 1e25f), fminf(fmaxf(1.f / d.y, -1e25f), 1e25f),
                         fminf(fmaxf(1.f / d.z, -1e25f), 1e25f));
     const f3 oi = mk3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
     int sp = 0;
     uint32_t cur = root_ref;
-    for (;;) {
-        if (cur & MSK_LEAF_BIT) {
-            const uint32_t first = (cur & 0x7fffffffu) >> 5, cnt = cur & 31u;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                const float4 *q = tris + (size_t) (first + i) * 4;
-                float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-                float t, u, v;
-                if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v)) {
-                    if (ANY) return true;
-                    uint32_t prim = __float_as_uint(q0.w);
-                    if (t < bt || (t == bt && prim < bp)) { bt = t; bu = u; bv = v; bp = prim; }
-                }
-            }
-        } else {
+    const uint32_t DONE = 0xffffffffu;      // not a valid ref: a leaf ref never has all of its count bits and index bits set
+    while (cur != DONE) {
+        // ---- inner nodes
+        while (!(cur & MSK_LEAF_BIT)) {
             const float4 *n = nodes + (size_t) cur * 4;
-            float4 a = n[0], b = n[1], c = n[2], m = n[3];
+            const float4 a = n[0], b = n[1], c = n[2], m = n[3];
             float t0, t1;
-            bool h0 = box_test(a.x, a.y, a.z, a.w, b.x, b.y, idir, oi, tmin, bt, &t0);
-            bool h1 = box_test(b.z, b.w, c.x, c.y, c.z, c.w, idir, oi, tmin, bt, &t1);
+            const bool h0 = box_test(a.x, a.y, a.z, a.w, b.x, b.y, idir, oi, tmin, bt, &t0);
+            const bool h1 = box_test(b.z, b.w, c.x, c.y, c.z, c.w, idir, oi, tmin, bt, &t1);
             const uint32_t c0 = __float_as_uint(m.x), c1 = __float_as_uint(m.y);
             if (h0 && h1) {
                 const bool swap = t1 < t0;            // nearer child first, the other one on the stack
                 cur = swap ? c1 : c0;
                 stack[sp * MSK_BLOCK] = swap ? c0 : c1; sp += 1;
-                continue;
-            } else if (h0) { cur = c0; continue; }
-            else if (h1) { cur = c1; continue; }
+            } else if (h0) { cur = c0; }
+            else if (h1) { cur = c1; }
+            else if (sp > 0) { sp -= 1; cur = stack[sp * MSK_BLOCK]; }
+            else { cur = DONE; break; }
         }
-        if (sp == 0) break;
-        sp -= 1;
-        cur = stack[sp * MSK_BLOCK];
+        if (cur == DONE) break;
+        // ---- leaf
+        const uint32_t first = (cur & 0x7fffffffu) >> 5, cnt = cur & 31u;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const float4 *q = tris + (size_t) (first + i) * 4;
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            float t, u, v;
+            if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v)) {
+                if (ANY) return true;
+                const uint32_t prim = __float_as_uint(q0.w);
+                if (t < bt || (t == bt && prim < bp)) { bt = t; bu = u; bv = v; bp = prim; }
+            }
+        }
+        if (sp > 0) { sp -= 1; cur = stack[sp * MSK_BLOCK]; } else cur = DONE;
     }
     *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
     return false;
@@ -201,6 +207,12 @@ MSK_DEV TraceLds stage_scene(const DeviceScene &sc, float4 *lds, bool use_lds) {
 // ------------------------------------------------------------------------------------------
 // k_trace
 // ------------------------------------------------------------------------------------------
+// The shadow result travels in bit 31 of the hit record's prim word (1 = unoccluded); k_shade_gen
+// adds the NEE contribution, so this kernel never touches the radiance arrays.
+// (A per-lane state machine with dynamic ray fetch was measured here and lost: with 64 lanes some
+// lane finishes a ray in almost every iteration, so the fetch/switch path runs every iteration.)
+#define MSK_HIT_UNOCCLUDED 0x80000000u
+#define MSK_PRIM_MASK 0x7fffffffu
 template <bool LDS_SCENE>
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_trace(DeviceScene sc, PathState st, PassParams pp) {
@@ -220,20 +232,17 @@ k_trace(DeviceScene sc, PathState st, PassParams pp) {
         const uint32_t fl = st.id[i].w;
         const f3 o = mk3(ro.x, ro.y, ro.z);
         float bt, bu, bv; uint32_t bp;
+        uint32_t unocc = 0;
         if (fl & MSK_FLAG_SHADOW) {
             const float4 s = st.sh[i];
-            bool occ = traverse<true>(g.nodes, g.tris, sc.root_ref, sc.n_tris, o, mk3(s.x, s.y, s.z), ro.w, s.w,
-                                      stack, &bt, &bu, &bv, &bp);
-            if (!occ) {
-                float4 r = st.res[i], k = st.contrib[i];
-                r.x = r.x + k.x; r.y = r.y + k.y; r.z = r.z + k.z; r.w = r.w + k.w;
-                st.res[i] = r;
-            }
+            const bool occ = traverse<true>(g.nodes, g.tris, sc.root_ref, sc.n_tris, o, mk3(s.x, s.y, s.z), ro.w, s.w,
+                                            stack, &bt, &bu, &bv, &bp);
+            unocc = occ ? 0u : MSK_HIT_UNOCCLUDED;
         }
         traverse<false>(g.nodes, g.tris, sc.root_ref, sc.n_tris, o, mk3(rd.x, rd.y, rd.z), ro.w, rd.w, stack,
                         &bt, &bu, &bv, &bp);
         const bool valid = (bp != MSK_NO_PRIM) && (bt != rd.w);           // scene.cpp:234 tfar != maxt
-        st.hit[i] = make_float4(valid ? bt : MSK_INF_F, bu, bv, __uint_as_float(valid ? bp : MSK_NO_PRIM));
+        st.hit[i] = make_float4(valid ? bt : MSK_INF_F, bu, bv, __uint_as_float((valid ? bp : MSK_PRIM_MASK) | unocc));
     }
 }
 
@@ -376,7 +385,11 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
         const uint4 id = st.id[i];
         spec wl = from4(st.wl[i]), thr = from4(st.thr[i]), res = from4(st.res[i]);
         const float4 rd4 = st.ray_d[i];
-        const float4 hit = st.hit[i];
+        float4 hit = st.hit[i];
+        // the previous bounce's NEE term (path.cpp:60-66), now that the shadow ray has been traced
+        if (active && (id.w & MSK_FLAG_SHADOW) && (__float_as_uint(hit.w) & MSK_HIT_UNOCCLUDED))
+            res = res + from4(st.contrib[i]);
+        hit.w = __uint_as_float(__float_as_uint(hit.w) & MSK_PRIM_MASK);
         float bs_pdf = st.bs_pdf[i];
         uint32_t depth = id.w & MSK_DEPTH_MASK;
         const f3 rd = mk3(rd4.x, rd4.y, rd4.z);
@@ -615,6 +628,9 @@ struct BlockInfo {          // one spiral block of this pass
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_resolve_blocks(DeviceScene sc, const BlockInfo *blocks, uint32_t n_blocks, const float4 *rec_a, const float *rec_b,
                  uint32_t spp_owned, float *block_buf, uint32_t buf_stride) {
+    __shared__ float lut[36];
+    if (threadIdx.x < 33) lut[threadIdx.x] = sc.lut[threadIdx.x];
+    __syncthreads();
     const uint32_t per_block = (buf_stride / 5);
     const uint64_t gid = (uint64_t) blockIdx.x * MSK_BLOCK + threadIdx.x;
     const uint32_t bi = (uint32_t) (gid / per_block), t = (uint32_t) (gid % per_block);
@@ -624,6 +640,7 @@ k_resolve_blocks(DeviceScene sc, const BlockInfo *blocks, uint32_t n_blocks, con
     const int sx = b.size_x + 2 * border, sy = b.size_y + 2 * border;
     if ((int) t >= sx * sy) return;
     const int tx = (int) t % sx, ty = (int) t / sx;
+    const float ftx = (float) tx, fty = (float) ty;
     const float radius = sc.filter_radius, scale = sc.filter_scale;
     // a sample of source pixel x lands on bordered targets within border-r-.5 .. border+r+.5 of x
     const int span = (int) ceilf(radius + 0.5f);
@@ -632,21 +649,30 @@ k_resolve_blocks(DeviceScene sc, const BlockInfo *blocks, uint32_t n_blocks, con
     const int x_lo = max(0, tx - border - span), x_hi = min(b.size_x - 1, tx - border + span);
     const float offx = (float) (b.off_x - border), offy = (float) (b.off_y - border);
     const uint32_t npix = (uint32_t) (b.size_x * b.size_y);
+    constexpr int U = 8;            // records in flight per lane
     for (int y = y_lo; y <= y_hi; ++y)
         for (int x = x_lo; x <= x_hi; ++x) {
             const size_t r0 = (size_t) b.pixel_base * spp_owned + (uint32_t) (y * b.size_x + x);
-#pragma unroll 4
-            for (uint32_t s = 0; s < spp_owned; ++s) {
-                const float4 ra = rec_a[r0 + (size_t) s * npix];
-                const float pyv = rec_b[r0 + (size_t) s * npix];
-                const float px = ra.w - 0.5f - offx, py = pyv - 0.5f - offy;
-                const int lox = max((int) ceilf(px - radius), 0), loy = max((int) ceilf(py - radius), 0);
-                const int hix = min((int) floorf(px + radius), sx - 1), hiy = min((int) floorf(py + radius), sy - 1);
-                if (tx < lox || tx > hix || ty < loy || ty > hiy) continue;
-                const float wx = sc.lut[min((int) fabsf(((float) tx - px) * scale), 32)];
-                const float wy = sc.lut[min((int) fabsf(((float) ty - py) * scale), 32)];
-                const float w = wx * wy;
-                a0 += w * ra.x; a1 += w * ra.y; a2 += w * ra.z; a3 += w * 1.f; a4 += w * 1.f;
+            for (uint32_t s0 = 0; s0 < spp_owned; s0 += U) {
+                float4 ra[U]; float rb[U];
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const uint32_t s = min(s0 + (uint32_t) k, spp_owned - 1);
+                    ra[k] = rec_a[r0 + (size_t) s * npix];
+                    rb[k] = rec_b[r0 + (size_t) s * npix];
+                }
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    if (s0 + (uint32_t) k >= spp_owned) break;
+                    const float px = ra[k].w - 0.5f - offx, py = rb[k] - 0.5f - offy;
+                    const int lox = max((int) ceilf(px - radius), 0), loy = max((int) ceilf(py - radius), 0);
+                    const int hix = min((int) floorf(px + radius), sx - 1), hiy = min((int) floorf(py + radius), sy - 1);
+                    if (tx < lox || tx > hix || ty < loy || ty > hiy) continue;
+                    const float wx = lut[min((int) fabsf((ftx - px) * scale), 32)];
+                    const float wy = lut[min((int) fabsf((fty - py) * scale), 32)];
+                    const float w = wx * wy;
+                    a0 += w * ra[k].x; a1 += w * ra[k].y; a2 += w * ra[k].z; a3 += w * 1.f; a4 += w * 1.f;
+                }
             }
         }
     float *o = block_buf + (size_t) b.slot * buf_stride + (size_t) t * 5;
