@@ -520,12 +520,17 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
                            d_rec_b.as<float>(), sb, region_size, n_regions, stats, ev, ev_trace, ev_shade);
         if (rc) return rc;
         const uint32_t nb = (uint32_t) (ps.second - ps.first);
-        const uint64_t threads = (uint64_t) nb * per_block;
+        const int tile = (int) env_u32("MSK_RESOLVE_TILE", 2);
+        const int tiles_x = (bs + 2 * border + tile - 1) / tile, tiles_y = tiles_x;
+        const uint64_t threads = (uint64_t) nb * tiles_x * tiles_y;
         hipEvent_t a = ev.get(), b = ev.get();
         (void) hipEventRecord(a, stream);
-        hipLaunchKernelGGL(k_resolve_blocks, dim3((uint32_t) ((threads + MSK_BLOCK - 1) / MSK_BLOCK)), dim3(MSK_BLOCK), 0, stream,
-                           sc->dev, d_blocks.as<BlockInfo>() + ps.first, nb, d_rec_a.as<float4>(), d_rec_b.as<float>(),
-                           spp_owned, d_block_buf.as<float>(), buf_stride);
+        const dim3 rgrid((uint32_t) ((threads + MSK_BLOCK - 1) / MSK_BLOCK));
+#define MSK_RESOLVE(T) hipLaunchKernelGGL((k_resolve_blocks<T, T>), rgrid, dim3(MSK_BLOCK), 0, stream, sc->dev,            \
+                           d_blocks.as<BlockInfo>() + ps.first, nb, d_rec_a.as<float4>(), d_rec_b.as<float>(), spp_owned,  \
+                           d_block_buf.as<float>(), buf_stride, tiles_x, tiles_y)
+        if (tile == 1) MSK_RESOLVE(1); else if (tile == 3) MSK_RESOLVE(3); else MSK_RESOLVE(2);
+#undef MSK_RESOLVE
         (void) hipEventRecord(b, stream);
         ev_resolve.push_back({a, b});
         HIP_TRY(ctx, hipStreamSynchronize(stream));   // d_pix / records are reused by the next pass

@@ -622,31 +622,39 @@ struct BlockInfo {          // one spiral block of this pass
     uint32_t slot;          // index of the block's accumulation buffer
 };
 
-// One thread per pixel of the bordered block: replays ImageBlock::put (imageblock.cpp:55-114) for
-// every sample of the block in the order render_block issues them (y, x, s — integrator.cpp:89-98)
-// and keeps only what lands on its own pixel.
+// One thread per TX x TY tile of pixels of the bordered block: replays ImageBlock::put
+// (imageblock.cpp:55-114) for every sample of the block in the order render_block issues them
+// (y, x, s — integrator.cpp:89-98) and keeps what lands on its own pixels.  Every pixel therefore
+// receives exactly the additions, in exactly the order, the scalar loop performs.  A tile shares
+// one read of each record among its pixels ((TX+4)(TY+4)/(TX*TY) reads per pixel instead of 25).
+template <int TX, int TY>
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_resolve_blocks(DeviceScene sc, const BlockInfo *blocks, uint32_t n_blocks, const float4 *rec_a, const float *rec_b,
-                 uint32_t spp_owned, float *block_buf, uint32_t buf_stride) {
+                 uint32_t spp_owned, float *block_buf, uint32_t buf_stride, int tiles_x, int tiles_y) {
     __shared__ float lut[36];
     if (threadIdx.x < 33) lut[threadIdx.x] = sc.lut[threadIdx.x];
     __syncthreads();
-    const uint32_t per_block = (buf_stride / 5);
+    const uint32_t per_block = (uint32_t) (tiles_x * tiles_y);
     const uint64_t gid = (uint64_t) blockIdx.x * MSK_BLOCK + threadIdx.x;
     const uint32_t bi = (uint32_t) (gid / per_block), t = (uint32_t) (gid % per_block);
     if (bi >= n_blocks) return;
     const BlockInfo b = blocks[bi];
     const int border = sc.filter_border;
     const int sx = b.size_x + 2 * border, sy = b.size_y + 2 * border;
-    if ((int) t >= sx * sy) return;
-    const int tx = (int) t % sx, ty = (int) t / sx;
-    const float ftx = (float) tx, fty = (float) ty;
+    const int tx0 = (int) (t % (uint32_t) tiles_x) * TX, ty0 = (int) (t / (uint32_t) tiles_x) * TY;
+    if (tx0 >= sx || ty0 >= sy) return;
     const float radius = sc.filter_radius, scale = sc.filter_scale;
     // a sample of source pixel x lands on bordered targets within border-r-.5 .. border+r+.5 of x
     const int span = (int) ceilf(radius + 0.5f);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
-    const int y_lo = max(0, ty - border - span), y_hi = min(b.size_y - 1, ty - border + span);
-    const int x_lo = max(0, tx - border - span), x_hi = min(b.size_x - 1, tx - border + span);
+    float acc[TY][TX][5];
+#pragma unroll
+    for (int j = 0; j < TY; ++j)
+#pragma unroll
+        for (int i = 0; i < TX; ++i)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) acc[j][i][c] = 0.f;
+    const int y_lo = max(0, ty0 - border - span), y_hi = min(b.size_y - 1, ty0 + TY - 1 - border + span);
+    const int x_lo = max(0, tx0 - border - span), x_hi = min(b.size_x - 1, tx0 + TX - 1 - border + span);
     const float offx = (float) (b.off_x - border), offy = (float) (b.off_y - border);
     const uint32_t npix = (uint32_t) (b.size_x * b.size_y);
     constexpr int U = 8;            // records in flight per lane
@@ -667,16 +675,34 @@ k_resolve_blocks(DeviceScene sc, const BlockInfo *blocks, uint32_t n_blocks, con
                     const float px = ra[k].w - 0.5f - offx, py = rb[k] - 0.5f - offy;
                     const int lox = max((int) ceilf(px - radius), 0), loy = max((int) ceilf(py - radius), 0);
                     const int hix = min((int) floorf(px + radius), sx - 1), hiy = min((int) floorf(py + radius), sy - 1);
-                    if (tx < lox || tx > hix || ty < loy || ty > hiy) continue;
-                    const float wx = lut[min((int) fabsf((ftx - px) * scale), 32)];
-                    const float wy = lut[min((int) fabsf((fty - py) * scale), 32)];
-                    const float w = wx * wy;
-                    a0 += w * ra[k].x; a1 += w * ra[k].y; a2 += w * ra[k].z; a3 += w * 1.f; a4 += w * 1.f;
+                    float wx[TX], wy[TY];
+#pragma unroll
+                    for (int i = 0; i < TX; ++i) wx[i] = lut[min((int) fabsf(((float) (tx0 + i) - px) * scale), 32)];
+#pragma unroll
+                    for (int j = 0; j < TY; ++j) wy[j] = lut[min((int) fabsf(((float) (ty0 + j) - py) * scale), 32)];
+#pragma unroll
+                    for (int j = 0; j < TY; ++j)
+#pragma unroll
+                        for (int i = 0; i < TX; ++i) {
+                            const int tx = tx0 + i, ty = ty0 + j;
+                            if (tx < lox || tx > hix || ty < loy || ty > hiy) continue;
+                            const float w = wx[i] * wy[j];
+                            acc[j][i][0] += w * ra[k].x; acc[j][i][1] += w * ra[k].y; acc[j][i][2] += w * ra[k].z;
+                            acc[j][i][3] += w * 1.f; acc[j][i][4] += w * 1.f;
+                        }
                 }
             }
         }
-    float *o = block_buf + (size_t) b.slot * buf_stride + (size_t) t * 5;
-    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4;
+#pragma unroll
+    for (int j = 0; j < TY; ++j)
+#pragma unroll
+        for (int i = 0; i < TX; ++i) {
+            const int tx = tx0 + i, ty = ty0 + j;
+            if (tx >= sx || ty >= sy) continue;
+            float *o = block_buf + (size_t) b.slot * buf_stride + (size_t) (ty * sx + tx) * 5;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) o[c] = acc[j][i][c];
+        }
 }
 
 // Film::put for every block in spiral order (imageblock.cpp:36-53,133-173; D6: ascending block id).
