@@ -62,6 +62,7 @@ def main():
     import torch
     abi = importlib.import_module("misaki-render_amd.abi")
     hm = importlib.import_module("misaki-render_amd.hostmirror")
+    mg = importlib.import_module("misaki-render_amd.multigpu")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -79,14 +80,13 @@ def main():
     flat = hm.cbox_scene(WIDTH, HEIGHT)
     ctx = abi.Context(local_rank)
     scene = abi.Scene(ctx, flat)
-    spp_total = args.spp * world
-    prm = abi.render_params(spp=spp_total, seed=0, block_first=rank, block_stride=world)
+    spp_total = mg.weak_scaling_spp(args.spp, world)
+    prm = mg.shard_params(abi, spp_total, rank, world, seed=0)
     film = torch.zeros((HEIGHT, WIDTH, 5), dtype=torch.float32, device="cuda")
 
     def step():
         st = scene.render_device(prm, film.data_ptr())
-        if dist is not None:
-            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+        mg.reduce_film(film, dist)
         return st
 
     def fence():
@@ -121,10 +121,11 @@ def main():
         ms_shade = sum(s.ms_shade for s in stats)
         n_trace = sum(s.n_trace_launches for s in stats)
         n_shade = sum(s.n_shade_launches for s in stats)
-        # algorithmic bytes: k_trace 52 B/segment + 64 B/shadow ray;
-        # k_shade_gen 224 B/segment + 20 B/sample record
-        bytes_trace = seg * 52 + shd * 64
-        bytes_shade = seg * 224 + smp * 20
+        # algorithmic bytes of the SoA path state each kernel must move:
+        #   k_trace      64 B/segment (ray_o, ray_d, id in; hit out) + 16 B/shadow ray (sh in)
+        #   k_shade_gen  232 B/segment (100 in, 132 out) + 16 B/shadow ray (contrib in) + 20 B/sample (record out)
+        bytes_trace = seg * 64 + shd * 16
+        bytes_shade = seg * 232 + shd * 16 + smp * 20
         if ms_trace >= ms_shade:
             name, b, ms, nl = "k_trace", bytes_trace, ms_trace, n_trace
         else:
@@ -134,7 +135,8 @@ def main():
         prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get(name, {}).get("hbm_bytes_per_launch")
+                pm = json.load(open(prof))
+                traffic = next((round(v["hbm_bytes_per_launch"]) for k, v in pm.items() if k.startswith(name)), None)
             except Exception:
                 traffic = None
         out = {

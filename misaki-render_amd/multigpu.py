@@ -1,0 +1,28 @@
+"""Multi-GPU decomposition of the hot path: one process per GPU, pixel-tile shard, one film reduce.
+
+Samples are independent; the only coupling is the linear film sum (imageblock.cpp:100-110,
+157-173).  Rank r of G renders the spiral blocks (imageblock.cpp:187-247) whose id is r mod G —
+the interleave balances cheap and expensive tiles — with the full sample count, into its own
+H x W x 5 film of weighted sums; the films are then summed onto rank 0 with ONE collective
+(RCCL `reduce` over xGMI on the GPU box, gloo in the CPU tests).  A pixel further than the filter
+border (2 px) from a tile edge receives a non-zero value from exactly one rank, so the reduced film
+equals the single-GPU film bit for bit there; border pixels differ by fp32 re-association of <= 4 terms.
+"""
+
+
+def shard_params(abi, spp_total, rank, world, **kw):
+    """Render parameters of rank `rank`: blocks id % world == rank, every sample of those blocks."""
+    return abi.render_params(spp=spp_total, block_first=rank, block_stride=world, **kw)
+
+
+def reduce_film(film, dist=None, dst=0):
+    """Sum the per-rank films onto rank `dst` (in place).  film: torch tensor [H, W, 5] float32."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
+    return film
+
+
+def weak_scaling_spp(spp_per_gpu, world):
+    """Weak scaling: per-GPU work constant.  Each rank owns 1/world of the tiles, so the whole job
+    renders spp_per_gpu * world samples per pixel."""
+    return spp_per_gpu * world

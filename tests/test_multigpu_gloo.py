@@ -1,0 +1,58 @@
+"""The N > 1 path on CPU: two processes, gloo backend, each renders its pixel-tile shard with the
+CPU oracle (standing in for the GPU back end behind the same msk_render_params shard selectors),
+one film reduce onto rank 0 — the exact sequence bench.py runs over RCCL."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    abi = importlib.import_module("misaki-render_amd.abi")
+    hm = importlib.import_module("misaki-render_amd.hostmirror")
+    mg = importlib.import_module("misaki-render_amd.multigpu")
+    import oracle_binding
+    orc = oracle_binding.load()
+    flat = hm.cbox_scene(96, 64, coeff_lookup=lambda rgb: (0.0, 0.0, 1.0))
+    sc = orc.scene(flat)
+    spp_total = mg.weak_scaling_spp(2, world)
+    prm = mg.shard_params(abi, spp_total, rank, world, seed=5)
+    assert prm.block_first == rank and prm.block_stride == world and prm.spp == 2 * world
+    film_np, st = sc.render(prm, threads=2)
+    film = torch.from_numpy(film_np.copy())
+    mg.reduce_film(film, dist)
+    n = torch.tensor([float(st.samples)], dtype=torch.float64)
+    dist.all_reduce(n)
+    if rank == 0:
+        full, fst = sc.render(abi.render_params(spp=spp_total, seed=5), threads=2)
+        np.savez(out_path, reduced=film.numpy(), full=full, samples=n.numpy(), full_samples=fst.samples)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_tile_shard_and_film_reduce(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "film.npz")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    d = np.load(out)
+    reduced, full = d["reduced"], d["full"]
+    assert d["samples"][0] == d["full_samples"] == 96 * 64 * 4       # every sample rendered exactly once
+    interior = np.ones((64, 96), bool)
+    for k in range(0, 96, 32):
+        interior[:, max(0, k - 2):k + 2] = False
+    for k in range(0, 64, 32):
+        interior[max(0, k - 2):k + 2, :] = False
+    assert np.array_equal(reduced[interior], full[interior])         # exactly one rank contributes
+    assert np.allclose(reduced, full, rtol=3e-7, atol=1e-6)           # tile borders: <= 4 terms re-associated
+    assert reduced[..., 4].min() > 0
