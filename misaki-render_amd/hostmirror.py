@@ -43,7 +43,6 @@ def gaussian_filter(stddev=0.5):
     stddev = f(stddev)
     radius = f(4) * stddev
     alpha = f(-1.0) / (f(2.0) * stddev * stddev)
-    bias = f(math.exp(float(alpha * radius * radius)))   # std::exp(float) -> expf
     bias = np.exp(alpha * radius * radius, dtype=np.float32)
     vals = np.zeros(abi.MSK_FILTER_RESOLUTION + 1, np.float32)
     s = f(0)
@@ -121,6 +120,41 @@ def write_obj(mesh, path):
                 fh.write("v %.9g %.9g %.9g\n" % tuple(float(np.float32(c)) for c in p))
             fh.write("f " + " ".join(str(n + i + 1) for i in range(len(f))) + "\n")
             n += len(f)
+
+
+def write_scene_xml(meshes, directory, width, height, spp, camera=None, integrator_props=None, film_type="hdrfilm",
+                    filename="scene.xml"):
+    """Writes <directory>/meshes/*.obj and a Mitsuba-style scene XML the C++ host (and the reference's
+    loader) understands; same structure as results/Figure_1_Pathtrace/scene.xml, $-parameters for spp/size."""
+    camera = camera or CBOX_CAMERA
+    os.makedirs(os.path.join(directory, "meshes"), exist_ok=True)
+    v3 = lambda v: ", ".join("%.9g" % float(x) for x in v)
+    out = ['<scene>', '    <default name="spp" value="%d"/>' % spp, '    <default name="width" value="%d"/>' % width,
+           '    <default name="height" value="%d"/>' % height, '    <integrator type="path">']
+    for k, val in (integrator_props or {}).items():
+        tag = "boolean" if isinstance(val, bool) else "integer"
+        out.append('        <%s name="%s" value="%s"/>' % (tag, k, str(val).lower()))
+    out += ['    </integrator>', '    <sensor type="perspective">',
+            '        <float name="near_clip" value="%.9g"/>' % camera["near"], '        <float name="far_clip" value="%.9g"/>' % camera["far"],
+            '        <float name="fov" value="%.9g"/>' % camera["fov"], '        <transform name="to_world">',
+            '            <lookat origin="%s" target="%s" up="%s"/>' % (v3(camera["origin"]), v3(camera["target"]), v3(camera["up"])),
+            '        </transform>', '        <sampler type="independent">', '            <integer name="sample_count" value="$spp"/>',
+            '        </sampler>', '        <film type="%s">' % film_type, '            <integer name="width" value="$width"/>',
+            '            <integer name="height" value="$height"/>', '        </film>', '    </sensor>']
+    for m in meshes:
+        write_obj(m, os.path.join(directory, "meshes", m.name + ".obj"))
+        out += ['    <shape type="obj">', '        <string name="filename" value="meshes/%s.obj"/>' % m.name]
+        if any(float(t) != 0 for t in m.translate):
+            out += ['        <transform name="to_world">', '            <translate x="%.9g" y="%.9g" z="%.9g"/>' % tuple(m.translate),
+                    '        </transform>']
+        out += ['        <bsdf type="diffuse">', '            <rgb name="reflectance" value="%s"/>' % v3(m.reflectance), '        </bsdf>']
+        if m.radiance is not None:
+            out += ['        <emitter type="area">', '            <rgb name="radiance" value="%s"/>' % v3(m.radiance), '        </emitter>']
+        out.append('    </shape>')
+    out.append('</scene>')
+    path = os.path.join(directory, filename)
+    open(path, "w").write("\n".join(out) + "\n")
+    return path
 
 
 WHITE = (0.885809, 0.698859, 0.666422)

@@ -1,0 +1,127 @@
+"""The C++ host side (misaki-render_amd/host): the reference's XML / Properties / plugin interface.
+CPU tests cover loading, flattening and error behaviour; the GPU test renders through
+scene->integrator()->render() and compares with the oracle."""
+import importlib
+import os
+import struct
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    import __graft_entry__ as ge
+    ge.build_gpu_library()
+    ge.build_host_library()
+    return importlib.import_module("misaki-render_amd.hostlib")
+
+
+@pytest.fixture()
+def cbox_xml(tmp_path, hostmirror):
+    return hostmirror.write_scene_xml(hostmirror.cbox_meshes(), str(tmp_path), 64, 48, 4)
+
+
+def test_load_and_flatten_matches_the_python_mirror(hostlib, hostmirror, cbox_xml, oracle):
+    sc = hostlib.HostScene(cbox_xml)
+    assert sc.film_size() == (64, 48, 4)
+    flat = sc.flatten()
+    ref = hostmirror.cbox_scene(64, 48)
+    d, r = flat.desc, ref.desc
+    assert (d.n_meshes, d.n_bsdfs, d.n_emitters, d.n_faces, d.n_vertices) == (8, 8, 1, 32, 64)
+    assert np.array_equal(flat.vertices, ref.vertices) and np.array_equal(flat.faces, ref.faces)   # OBJ round trip, quad split
+    assert [(d.meshes[i].emitter_id, d.meshes[i].first_face, d.meshes[i].face_count) for i in range(8)] == \
+           [(r.meshes[i].emitter_id, r.meshes[i].first_face, r.meshes[i].face_count) for i in range(8)]
+    assert d.emitters[0].d65_scale == r.emitters[0].d65_scale and d.emitters[0].mesh_id == 0
+    assert np.allclose(d.camera.sample_to_camera[:], r.camera.sample_to_camera[:], rtol=2e-6, atol=1e-9)
+    assert np.allclose(d.camera.to_world[:], r.camera.to_world[:], rtol=1e-6, atol=1e-9)
+    assert d.camera.near_clip == 10.0 and d.camera.far_clip == 2800.0
+    assert d.film.filter_radius == 2.0 and np.allclose(d.film.filter_lut[:], r.film.filter_lut[:], rtol=3e-7, atol=1e-9)
+    assert np.array_equal(np.ctypeslib.as_array(d.cie1931_xyz, (285,)), np.ctypeslib.as_array(r.cie1931_xyz, (285,)))
+    # spectral upsampling: the C++ solver and the Python solver agree
+    for i in range(8):
+        assert np.allclose(d.bsdfs[i].reflectance[:], r.bsdfs[i].reflectance[:], rtol=2e-4, atol=2e-6)
+    # render parameters = the reference's effective integrator settings
+    p = flat.params
+    assert (p.spp, p.rng_mode, p.rr_depth, p.max_depth, p.hide_emitters, p.block_size) == (4, 1, 5, -1, 0, 32)
+    # the flattened scene is a valid input of the oracle (and therefore of the C ABI)
+    osc = oracle.scene(flat)
+    film, st = osc.render(p, threads=2)
+    assert st.samples == 64 * 48 * 4 and np.isfinite(film).all() and film[..., 4].min() > 0
+    osc.close()
+    sc.close()
+
+
+def test_parameters_and_properties(hostlib, hostmirror, tmp_path):
+    xml = hostmirror.write_scene_xml(hostmirror.cbox_meshes(), str(tmp_path), 32, 32, 2,
+                                     integrator_props={"max_depth": 3, "rr_depth": 2, "honor_properties": True, "block_size": 16},
+                                     film_type="rgbfilm")
+    sc = hostlib.HostScene(xml, spp=7, width=40)          # $spp / $width override the <default>s
+    assert sc.film_size() == (40, 32, 7)
+    p = sc.flatten().params
+    assert (p.max_depth, p.rr_depth, p.block_size) == (3, 2, 16)
+    sc.close()
+
+
+def test_error_behaviour(hostlib, hostmirror, tmp_path, cbox_xml):
+    with pytest.raises(hostlib.HostError) as e:
+        hostlib.HostScene(str(tmp_path / "nope.xml"))
+    assert "file not exists" in str(e.value)
+    bad = open(cbox_xml).read()
+    cases = {
+        "unknown plugin": (bad.replace('bsdf type="diffuse"', 'bsdf type="velvet"', 1), 'Plugin "velvet" not found'),
+        "bad rr_depth": (bad.replace('<integrator type="path">', '<integrator type="path"><integer name="rr_depth" value="0"/>'),
+                         '"rr_depth" must be set to a value greater than zero!'),
+        "unexpected tag": (bad.replace("<scene>", "<scene><bogus/>", 1), 'unexpected tag "bogus"'),
+        "missing mesh": (bad.replace("meshes/cbox_floor.obj", "meshes/missing.obj"), "file not found"),
+        "wrong type": (bad.replace('<float name="fov"', '<string name="fov"'), 'wrong type'),
+        "unterminated": (bad.replace("</scene>", ""), "missing closing tag"),
+        "two cameras": (bad.replace("</scene>", '<sensor type="perspective"/></scene>'), "Can only have one camera."),
+    }
+    for name, (text, needle) in cases.items():
+        p = tmp_path / (name.replace(" ", "_") + ".xml")
+        p.write_text(text)
+        with pytest.raises(hostlib.HostError) as e:
+            hostlib.HostScene(str(p)).flatten()
+        assert needle in str(e.value), (name, str(e.value))
+
+
+def test_transform_ops_and_default_bsdf(hostlib, hostmirror, tmp_path):
+    """<rotate>/<scale>/<translate> compose right to left; a shape without <bsdf> gets diffuse(0.5)."""
+    m = hostmirror.MeshSpec("tri", [((0, 0, 0), (1, 0, 0), (0, 1, 0))], (0.5, 0.5, 0.5))
+    xml = hostmirror.write_scene_xml([m], str(tmp_path), 16, 16, 1)
+    text = open(xml).read().replace('<bsdf type="diffuse">\n            <rgb name="reflectance" value="0.5, 0.5, 0.5"/>\n        </bsdf>',
+                                    '<transform name="to_world"><scale value="2"/><rotate z="1" angle="90"/><translate x="1" y="2" z="3"/></transform>')
+    assert "<rotate" in text
+    (tmp_path / "t.xml").write_text(text)
+    flat = hostlib.HostScene(str(tmp_path / "t.xml")).flatten()
+    v = flat.vertices[:, :3]
+    assert np.allclose(v, [[1, 2, 3], [1, 4, 3], [-1, 2, 3]], atol=1e-5)      # scale 2 -> rotate 90 about z -> translate
+    assert flat.desc.n_bsdfs == 1 and np.allclose(flat.desc.bsdfs[0].reflectance[:], [0, 0, 0])   # grey 0.5 -> zero polynomial
+
+
+def test_image_writers(hostlib, tmp_path):
+    img = np.random.RandomState(0).rand(5, 7, 4).astype(np.float32)
+    hostlib.write_image(tmp_path / "a.exr", img)
+    raw = (tmp_path / "a.exr").read_bytes()
+    assert struct.unpack("<I", raw[:4])[0] == 20000630 and b"channels\0chlist\0" in raw and b"compression\0" in raw
+    # uncompressed scanlines: the last row's R plane (channels stored alphabetically A,B,G,R) ends the file
+    assert np.array_equal(np.frombuffer(raw[-7 * 4:], np.float32), img[-1, :, 0])
+    hostlib.write_image(tmp_path / "a.pfm", img[..., :3].copy())
+    head, rest = (tmp_path / "a.pfm").read_bytes().split(b"-1.0\n", 1)
+    assert head == b"PF\n7 5\n" and np.array_equal(np.frombuffer(rest, np.float32).reshape(5, 7, 3)[::-1], img[..., :3])
+
+
+@pytest.mark.gpu
+def test_render_through_the_plugin_interface(hostlib, hostmirror, oracle, tmp_path):
+    """scene->integrator()->render(scene, sensor) -> Film::put -> HDRFilm::image(): bit-identical to the oracle."""
+    xml = hostmirror.write_scene_xml(hostmirror.cbox_meshes(), str(tmp_path), 96, 64, 8)
+    sc = hostlib.HostScene(xml)
+    film, rgba, st = sc.render(develop_to=str(tmp_path / "out.exr"))
+    flat = sc.flatten()
+    ref, rst = oracle.scene(flat).render(flat.params, threads=4)
+    assert st.samples == rst.samples == 96 * 64 * 8
+    assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+    assert np.allclose(rgba, hostmirror.develop(ref), rtol=1e-6, atol=1e-7)
+    assert os.path.getsize(tmp_path / "out.exr") > 96 * 64 * 16
+    sc.close()
