@@ -46,16 +46,19 @@ struct DevBuf {
     void *p = nullptr; size_t bytes = 0;
     ~DevBuf() { if (p) (void) hipFree(p); }
     hipError_t alloc(size_t n) { if (p) (void) hipFree(p); p = nullptr; bytes = n; return n ? hipMalloc(&p, n) : hipSuccess; }
+    hipError_t reserve(size_t n) { return (p && bytes >= n) ? hipSuccess : alloc(n); }     // grow-only (workspace reuse)
     template <typename T> hipError_t upload(const std::vector<T> &v) {
-        hipError_t e = alloc(std::max<size_t>(v.size() * sizeof(T), 16));
+        hipError_t e = reserve(std::max<size_t>(v.size() * sizeof(T), 16));
         if (e != hipSuccess) return e;
         return v.empty() ? hipSuccess : hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
     }
     template <typename T> T *as() const { return (T *) p; }
 };
 
+struct Workspace;
 struct msk_scene {
     msk_ctx *ctx = nullptr;
+    Workspace *ws = nullptr;           // render buffers, kept between calls (hipMalloc/hipFree of GBs costs milliseconds)
     DeviceScene dev;
     DevBuf nodes, tris, tri_verts, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
     bool lds_scene = false, lds_tables = false;
@@ -271,9 +274,11 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     return MSK_OK;
 }
 
+void free_workspace(msk_scene *scene);
 extern "C" void msk_gpu_scene_destroy(msk_scene *scene) {
     if (!scene) return;
     (void) hipSetDevice(scene->ctx->device);
+    free_workspace(scene);
     delete scene;
 }
 
@@ -313,17 +318,22 @@ struct StateBufs {
     PathState st;
     hipError_t alloc(size_t n, uint32_t n_regions) {
         hipError_t e;
-#define A_(b, sz) if ((e = b.alloc(n * (sz))) != hipSuccess) return e;
+#define A_(b, sz) if ((e = b.reserve(n * (sz))) != hipSuccess) return e;
         A_(id, 16) A_(wl, 16) A_(thr, 16) A_(res, 16) A_(ray_o, 16) A_(ray_d, 16) A_(sh, 16) A_(contrib, 16) A_(hit, 16)
         A_(bs_pdf, 4)
 #undef A_
-        if ((e = counts.alloc((size_t) n_regions * sizeof(RegionCtl))) != hipSuccess) return e;
-        if ((e = ctrl.alloc(sizeof(Ctrl))) != hipSuccess) return e;
+        if ((e = counts.reserve((size_t) n_regions * sizeof(RegionCtl))) != hipSuccess) return e;
+        if ((e = ctrl.reserve(sizeof(Ctrl))) != hipSuccess) return e;
         st.id = id.as<uint4>(); st.wl = wl.as<float4>(); st.thr = thr.as<float4>(); st.res = res.as<float4>();
         st.ray_o = ray_o.as<float4>(); st.ray_d = ray_d.as<float4>(); st.sh = sh.as<float4>();
         st.contrib = contrib.as<float4>(); st.hit = hit.as<float4>(); st.bs_pdf = bs_pdf.as<float>();
         return hipSuccess;
     }
+};
+
+struct Workspace {
+    StateBufs sb;
+    DevBuf block_buf, blocks, block_of, spiral, pix, rec_a, rec_b, film;
 };
 
 static uint32_t env_u32(const char *name, uint32_t def) {
@@ -338,6 +348,8 @@ struct EventPool {
         return ctx->events[next++];
     }
 };
+
+void free_workspace(msk_scene *scene) { delete scene->ws; scene->ws = nullptr; }
 
 static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st, const PassParams &pp) {
     const uint32_t grid = (pp.n_regions * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
@@ -428,7 +440,7 @@ static uint32_t owned_spp(const msk_render_params *p) {
 }
 
 static void pool_shape(uint64_t total_samples, uint32_t *region_size, uint32_t *n_regions) {
-    uint32_t rs = env_u32("MSK_REGION_SIZE", 256), nr = env_u32("MSK_REGIONS", 16384);
+    uint32_t rs = env_u32("MSK_REGION_SIZE", 256), nr = env_u32("MSK_REGIONS", 32768);
     rs = std::max(64u, (rs + 63u) & ~63u);
     const uint64_t need = (total_samples + rs - 1) / rs;
     if (need < nr) nr = (uint32_t) std::max<uint64_t>(need, 1);
@@ -469,8 +481,10 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     }
     const uint32_t per_block = (uint32_t) ((bs + 2 * border) * (bs + 2 * border));
     const uint32_t buf_stride = per_block * 5;
-    DevBuf d_block_buf, d_blocks, d_block_of, d_spiral;
-    HIP_TRY(ctx, d_block_buf.alloc(std::max<size_t>(owned.size(), 1) * buf_stride * 4));
+    if (!sc->ws) sc->ws = new Workspace();
+    Workspace &ws = *sc->ws;
+    DevBuf &d_block_buf = ws.block_buf, &d_blocks = ws.blocks, &d_block_of = ws.block_of, &d_spiral = ws.spiral;
+    HIP_TRY(ctx, d_block_buf.reserve(std::max<size_t>(owned.size(), 1) * buf_stride * 4));
     // ---- plan passes: consecutive owned blocks whose records fit the budget
     size_t free_b = 0, total_b = 0;
     HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -480,6 +494,8 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     pool_shape(all_samples, &region_size, &n_regions);
     const size_t n_slots = (size_t) region_size * n_regions;
     const size_t state_bytes = n_slots * 148 + 4096;
+    const size_t held = ws.rec_a.bytes + ws.rec_b.bytes + ws.sb.id.bytes * 148 / 16;    // reusable: counts as free
+    free_b += held;
     size_t budget = getenv("MSK_RECORD_BUDGET_MB") ? (size_t) atoll(getenv("MSK_RECORD_BUDGET_MB")) << 20
                                                    : (free_b > state_bytes ? (size_t) ((free_b - state_bytes) * 0.8) : 0);
     const size_t rec_bytes_per_block_max = (size_t) bs * bs * spp_owned * 20;
@@ -498,10 +514,10 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
         passes.push_back({b0, b1}); b0 = b1;
     }
     HIP_TRY(ctx, d_blocks.upload(owned)); HIP_TRY(ctx, d_block_of.upload(block_of)); HIP_TRY(ctx, d_spiral.upload(spiral_id));
-    StateBufs sb;
+    StateBufs &sb = ws.sb;
     if (!owned.empty()) HIP_TRY(ctx, sb.alloc(n_slots, n_regions));
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_trace, ev_shade, ev_resolve;
-    DevBuf d_pix, d_rec_a, d_rec_b;
+    DevBuf &d_pix = ws.pix, &d_rec_a = ws.rec_a, &d_rec_b = ws.rec_b;
     for (auto &ps : passes) {
         std::vector<uint4> pix;
         for (size_t b = ps.first; b < ps.second; ++b) {
@@ -515,21 +531,28 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
         }
         const uint64_t n_rec = (uint64_t) pix.size() * spp_owned;
         HIP_TRY(ctx, d_pix.upload(pix));
-        if (d_rec_a.bytes < n_rec * 16) { HIP_TRY(ctx, d_rec_a.alloc(n_rec * 16)); HIP_TRY(ctx, d_rec_b.alloc(n_rec * 4)); }
+        HIP_TRY(ctx, d_rec_a.reserve(n_rec * 16)); HIP_TRY(ctx, d_rec_b.reserve(n_rec * 4));
         rc = run_wavefront(sc, stream, prm, spp_owned, d_pix.as<uint4>(), pix.size(), d_rec_a.as<float4>(),
                            d_rec_b.as<float>(), sb, region_size, n_regions, stats, ev, ev_trace, ev_shade);
         if (rc) return rc;
         const uint32_t nb = (uint32_t) (ps.second - ps.first);
-        const int tile = (int) env_u32("MSK_RESOLVE_TILE", 2);
-        const int tiles_x = (bs + 2 * border + tile - 1) / tile, tiles_y = tiles_x;
+        // tile of film pixels per thread: 1 wide (adjacent lanes read adjacent records -> full cache lines),
+        // TY tall (a record is shared by TY pixels: 5*(TY+4)/TY reads per pixel)
+        const int tile_x = (int) env_u32("MSK_RESOLVE_TX", 1), tile_y = (int) env_u32("MSK_RESOLVE_TY", 3);
+        const int tiles_x = (bs + 2 * border + tile_x - 1) / tile_x, tiles_y = (bs + 2 * border + tile_y - 1) / tile_y;
         const uint64_t threads = (uint64_t) nb * tiles_x * tiles_y;
         hipEvent_t a = ev.get(), b = ev.get();
         (void) hipEventRecord(a, stream);
         const dim3 rgrid((uint32_t) ((threads + MSK_BLOCK - 1) / MSK_BLOCK));
-#define MSK_RESOLVE(T) hipLaunchKernelGGL((k_resolve_blocks<T, T>), rgrid, dim3(MSK_BLOCK), 0, stream, sc->dev,            \
+#define MSK_RESOLVE(TX, TY) hipLaunchKernelGGL((k_resolve_blocks<TX, TY>), rgrid, dim3(MSK_BLOCK), 0, stream, sc->dev,      \
                            d_blocks.as<BlockInfo>() + ps.first, nb, d_rec_a.as<float4>(), d_rec_b.as<float>(), spp_owned,  \
                            d_block_buf.as<float>(), buf_stride, tiles_x, tiles_y)
-        if (tile == 1) MSK_RESOLVE(1); else if (tile == 3) MSK_RESOLVE(3); else MSK_RESOLVE(2);
+        if (tile_x == 2 && tile_y == 2) MSK_RESOLVE(2, 2);
+        else if (tile_x == 1 && tile_y == 1) MSK_RESOLVE(1, 1);
+        else if (tile_x == 1 && tile_y == 2) MSK_RESOLVE(1, 2);
+        else if (tile_x == 1 && tile_y == 3) MSK_RESOLVE(1, 3);
+        else if (tile_x == 1 && tile_y == 6) MSK_RESOLVE(1, 6);
+        else MSK_RESOLVE(1, 4);
 #undef MSK_RESOLVE
         (void) hipEventRecord(b, stream);
         ev_resolve.push_back({a, b});
@@ -566,9 +589,10 @@ extern "C" int msk_gpu_render(msk_scene *scene, const msk_render_params *params,
     if (!scene || !film_xyzaw) return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_render: NULL argument");
     msk_ctx *ctx = scene->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf film;
+    if (!scene->ws) scene->ws = new Workspace();
+    DevBuf &film = scene->ws->film;
     const size_t bytes = (size_t) scene->dev.width * scene->dev.height * 5 * 4;
-    HIP_TRY(ctx, film.alloc(bytes));
+    HIP_TRY(ctx, film.reserve(bytes));
     int rc = render_impl(scene, params, film.as<float>(), nullptr, stats);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpy(film_xyzaw, film.p, bytes, hipMemcpyDeviceToHost));
