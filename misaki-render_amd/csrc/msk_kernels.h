@@ -209,8 +209,13 @@ MSK_DEV TraceLds stage_scene(const DeviceScene &sc, float4 *lds, bool use_lds) {
 // ------------------------------------------------------------------------------------------
 // The shadow result travels in bit 31 of the hit record's prim word (1 = unoccluded); k_shade_gen
 // adds the NEE contribution, so this kernel never touches the radiance arrays.
-// (A per-lane state machine with dynamic ray fetch was measured here and lost: with 64 lanes some
-// lane finishes a ray in almost every iteration, so the fetch/switch path runs every iteration.)
+// Measured here and rejected (round 1, cbox): (i) a per-lane state machine with dynamic ray fetch —
+// with 64 lanes some lane finishes a ray in almost every iteration, so the fetch/switch path runs every
+// iteration (trace +60 %); (ii) a wave-local LDS counting sort of each region's rays by (origin octant,
+// direction octant) plus packing of the shadow rays — 256 rays over 64 keys leave a wave incoherent, the
+// pre-pass costs more than it saves (trace +5..20 %).  Note for any future wave-level LDS exchange:
+// lanes communicating through LDS need a convergent `__builtin_amdgcn_wave_barrier()` + wavefront fence
+// between the phases — the compiler otherwise runs one side of a divergent region past the other's writes.
 #define MSK_HIT_UNOCCLUDED 0x80000000u
 #define MSK_PRIM_MASK 0x7fffffffu
 template <bool LDS_SCENE>
