@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MSK_ABI_VERSION 1
+#define MSK_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------- */
 #define MSK_OK                 0
@@ -46,7 +46,8 @@ extern "C" {
 #define MSK_ERR_UNSUPPORTED   (-5)
 
 /* ---- plugin type tags (the reference's registered plugin names) --------- */
-#define MSK_BSDF_DIFFUSE       0   /* "diffuse"  bsdfs/diffuse.cpp:73          */
+#define MSK_BSDF_DIFFUSE        0  /* "diffuse"        bsdfs/diffuse.cpp:73          */
+#define MSK_BSDF_ROUGHCONDUCTOR 1  /* "roughconductor" bsdfs/roughconductor.cpp:139 (GGX only) */
 #define MSK_EMITTER_AREA       0   /* "area"     emitters/area.cpp:61          */
 
 /* RNG semantics (the reference's own seeding is not reproducible) */
@@ -74,15 +75,31 @@ typedef struct msk_mesh_desc {
     uint32_t has_texcoords;  /* Mesh::has_vertex_texcoords() (mesh.h:67)        */
 } msk_mesh_desc;
 
+/* A spectrum the device can evaluate: value(l) = scale * S(coeff, l) with the sigmoid polynomial
+ * S of render/srgb.h:8-19.  RGB triples above 1 use the normalisation of srgb_d65.cpp:18-22
+ * (scale = 2 * max(rgb), coeff = fetch(rgb / scale)) without the D65 factor. */
+typedef struct msk_spectrum_desc {
+    float coeff[3];
+    float scale;
+} msk_spectrum_desc;
+
 /*
- * BSDF parameters.  For MSK_BSDF_DIFFUSE `reflectance` holds the three
- * sigmoid-polynomial coefficients srgb_model_fetch() returned for the RGB
- * reflectance (spectra/srgb.cpp:13-19, srgb.cpp:11-28).
+ * BSDF parameters.
+ * MSK_BSDF_DIFFUSE: `reflectance` = the three sigmoid-polynomial coefficients srgb_model_fetch()
+ * returned for the RGB reflectance (spectra/srgb.cpp:13-19, srgb.cpp:11-28).
+ * MSK_BSDF_ROUGHCONDUCTOR (bsdfs/roughconductor.cpp:12-50): GGX microfacet conductor; alpha_u/alpha_v,
+ * sample_visible, and eta / k / specular_reflectance evaluated at the path's four wavelengths (the
+ * reference's RGB-typed code does not compile in its spectral build; DESIGN.md §rough conductor).
+ * back_bsdf implements the "twosided" adapter (bsdfs/twosided.cpp:38-101): the BSDF evaluated with
+ * flipped wi/wo when cos(theta_i) < 0; the entry's own index for twosided(A), -1 for a one-sided BSDF.
  */
 typedef struct msk_bsdf_desc {
     int32_t type;
+    int32_t back_bsdf;
     float   reflectance[3];
-    float   params[12];      /* reserved for the rough BSDF rows  */
+    float   alpha_u, alpha_v;
+    int32_t sample_visible;
+    msk_spectrum_desc eta, k, specular_reflectance;
 } msk_bsdf_desc;
 
 /*

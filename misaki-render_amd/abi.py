@@ -10,10 +10,10 @@ import os
 
 import numpy as np
 
-MSK_ABI_VERSION = 1
+MSK_ABI_VERSION = 2
 MSK_OK = 0
 MSK_ERR_INVALID_ARG, MSK_ERR_NO_DEVICE, MSK_ERR_HIP, MSK_ERR_OOM, MSK_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
-MSK_BSDF_DIFFUSE = 0
+MSK_BSDF_DIFFUSE, MSK_BSDF_ROUGHCONDUCTOR = 0, 1
 MSK_EMITTER_AREA = 0
 MSK_RNG_PCG_BLOCK, MSK_RNG_COUNTER = 0, 1
 MSK_CIE_SAMPLES = 95
@@ -27,8 +27,14 @@ class MeshDesc(C.Structure):
                 ("has_normals", C.c_uint32), ("has_texcoords", C.c_uint32)]
 
 
+class SpectrumDesc(C.Structure):
+    _fields_ = [("coeff", C.c_float * 3), ("scale", C.c_float)]
+
+
 class BsdfDesc(C.Structure):
-    _fields_ = [("type", C.c_int32), ("reflectance", C.c_float * 3), ("params", C.c_float * 12)]
+    _fields_ = [("type", C.c_int32), ("back_bsdf", C.c_int32), ("reflectance", C.c_float * 3),
+                ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("sample_visible", C.c_int32),
+                ("eta", SpectrumDesc), ("k", SpectrumDesc), ("specular_reflectance", SpectrumDesc)]
 
 
 class EmitterDesc(C.Structure):

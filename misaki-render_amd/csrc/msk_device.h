@@ -149,6 +149,40 @@ MSK_DEV float det_cosh(float x) {
     return (float) (0.5 * (e + 1.0 / e));
 }
 
+// arctangent / tangent for the GGX azimuth (render/microfacet.h:23-26)
+MSK_DEV double det_atan_d(double z) {
+    const double pio2 = 1.57079632679489655800, pio4 = 0.78539816339744827900;
+    const double sgn = z < 0.0 ? -1.0 : 1.0;
+    double a = z < 0.0 ? -z : z;
+    const bool inv = a > 1.0;
+    if (inv) a = 1.0 / a;
+    double base = 0.0, t = a;
+    if (a > 0.41421356237309503) { t = (a - 1.0) / (a + 1.0); base = pio4; }
+    const double w = t * t;
+    double p = 1.0 / 45.0;
+    p = 1.0 / 43.0 - w * p; p = 1.0 / 41.0 - w * p; p = 1.0 / 39.0 - w * p; p = 1.0 / 37.0 - w * p;
+    p = 1.0 / 35.0 - w * p; p = 1.0 / 33.0 - w * p; p = 1.0 / 31.0 - w * p; p = 1.0 / 29.0 - w * p;
+    p = 1.0 / 27.0 - w * p; p = 1.0 / 25.0 - w * p; p = 1.0 / 23.0 - w * p; p = 1.0 / 21.0 - w * p;
+    p = 1.0 / 19.0 - w * p; p = 1.0 / 17.0 - w * p; p = 1.0 / 15.0 - w * p; p = 1.0 / 13.0 - w * p;
+    p = 1.0 / 11.0 - w * p; p = 1.0 / 9.0 - w * p; p = 1.0 / 7.0 - w * p; p = 1.0 / 5.0 - w * p;
+    p = 1.0 / 3.0 - w * p; p = 1.0 - w * p;
+    double r = base + t * p;
+    if (inv) r = pio2 - r;
+    return sgn * r;
+}
+MSK_DEV float det_atan(float z) { return (float) det_atan_d((double) z); }
+MSK_DEV float det_tan(float phi) {
+    const double two_over_pi = 0.63661977236758134308;
+    const double pio2_hi = 1.57079632679489655800e+00;
+    const double pio2_lo = 6.12323399573676603587e-17;
+    double x = (double) phi;
+    double k = __builtin_rint(x * two_over_pi);
+    double y = (x - k * pio2_hi) - k * pio2_lo;
+    int q = (int) ((long long) k & 1);
+    double sy = det_sin_poly(y), cy = det_cos_poly(y);
+    return (float) (q ? -cy / sy : sy / cy);
+}
+
 // ------------------------------------------------------------------ counter RNG
 MSK_DEV uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
@@ -262,6 +296,52 @@ MSK_DEV void spectrum_to_xyz(const float *cie, spec value, spec wl, float *X, fl
         cz.v[s] = w0 * cie[190 + i0] + w1 * cie[190 + i0 + 1];
     }
     *X = mean4(cx * value); *Y = mean4(cy * value); *Z = mean4(cz * value);
+}
+
+// ------------------------------------------------------------------ GGX microfacet conductor
+// render/microfacet.h:11-44,104-121,145-172 and render/fresnel.h:65-88, GGX branch only
+MSK_DEV float eval_ggx(f3 m, float au, float av) {
+    float cos_theta2 = m.z * m.z;
+    float beckman_exp = ((m.x * m.x / (au * au)) + (m.y * m.y) / (av * av)) / cos_theta2;
+    float root = (1.f + beckman_exp) * cos_theta2;
+    return 1.f / (MSK_PI_F * au * av * root * root);
+}
+MSK_DEV f3 sample_ggx(f2 sample, float au, float av, float *pdf_out) {
+    float phi_m = det_atan(au / av * det_tan(MSK_PI_F + 2 * MSK_PI_F * sample.y)) + MSK_PI_F * floorf(2 * sample.y + 0.5f);
+    float sin_phi_m, cos_phi_m;
+    det_sincos(phi_m, &sin_phi_m, &cos_phi_m);
+    float cs = cos_phi_m / au, sn = sin_phi_m / av;
+    float alpha_sqr = 1.f / (cs * cs + sn * sn);
+    float tan_theta_m_sqr = alpha_sqr * sample.x / (1.f - sample.x);
+    float cos_theta_m = 1.f / __builtin_sqrtf(1.f + tan_theta_m_sqr);
+    float tmp = 1 + tan_theta_m_sqr / alpha_sqr;
+    float pdf = MSK_INV_PI_F / (au * av * cos_theta_m * cos_theta_m * cos_theta_m * tmp * tmp);
+    if (pdf < 1e-20f) pdf = 0;
+    float sin_theta_m = safe_sqrt(1 - cos_theta_m * cos_theta_m);
+    *pdf_out = pdf;
+    return mk3(sin_theta_m * cos_phi_m, sin_theta_m * sin_phi_m, cos_theta_m);
+}
+MSK_DEV float distr_eval(f3 m, float au, float av) {
+    if (m.z <= 0) return 0.0f;
+    float result = eval_ggx(m, au, av);
+    return result * m.z > 1e-20f ? result : 0.f;
+}
+MSK_DEV float smith_g1(f3 v, f3 m, float au, float av) {
+    float xy_alpha_2 = (au * v.x) * (au * v.x) + (av * v.y) * (av * v.y), tan_theta_alpha_2 = xy_alpha_2 / (v.z * v.z);
+    if (xy_alpha_2 == 0.f) return 1.f;
+    if (dot(v, m) * v.z <= 0.f) return 0.f;
+    return 2.f / (1.f + __builtin_sqrtf(1.f + tan_theta_alpha_2));
+}
+MSK_DEV float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
+    float cos_theta_i_2 = cos_theta_i * cos_theta_i, sin_theta_i_2 = 1.f - cos_theta_i_2, sin_theta_i_4 = sin_theta_i_2 * sin_theta_i_2;
+    float temp_1 = eta_r * eta_r - eta_i * eta_i - sin_theta_i_2;
+    float a_2_pb_2 = __builtin_sqrtf(temp_1 * temp_1 + 4.f * eta_i * eta_i * eta_r * eta_r);
+    float a = __builtin_sqrtf(.5f * (a_2_pb_2 + temp_1));
+    float term_1 = a_2_pb_2 + cos_theta_i_2, term_2 = 2.f * cos_theta_i * a;
+    float r_s = (term_1 - term_2) / (term_1 + term_2);
+    float term_3 = a_2_pb_2 * cos_theta_i_2 + sin_theta_i_4, term_4 = term_2 * sin_theta_i_2;
+    float r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
+    return .5f * (r_s + r_p);
 }
 
 MSK_DEV float mis_weight(float pdf_a, float pdf_b) {        // integrators/path.cpp:127-131

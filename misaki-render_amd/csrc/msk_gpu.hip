@@ -61,7 +61,7 @@ struct msk_scene {
     Workspace *ws = nullptr;           // render buffers, kept between calls (hipMalloc/hipFree of GBs costs milliseconds)
     DeviceScene dev;
     DevBuf nodes, tris, tri_verts, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
-    bool lds_scene = false, lds_tables = false;
+    bool lds_scene = false, lds_tables = false, all_diffuse = true;
     size_t trace_lds_bytes = 0, shade_lds_bytes = 0;
     int bvh_depth = 0;
     uint32_t n_tris = 0;
@@ -201,11 +201,19 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     for (uint32_t g = 0; g < d->n_faces; ++g)
         if (!covered[g]) return fail(ctx, MSK_ERR_INVALID_ARG, "face %u belongs to no mesh", g);
 
-    std::vector<float> bsdfs((size_t) std::max(1u, d->n_bsdfs) * 4, 0.f);
+    static_assert(sizeof(msk_bsdf_desc) == 80, "msk_bsdf_desc is uploaded verbatim as 5 float4");
+    std::vector<float> bsdfs((size_t) std::max(1u, d->n_bsdfs) * 20, 0.f);
+    bool all_diffuse = true;
     for (uint32_t b = 0; b < d->n_bsdfs; ++b) {
-        if (d->bsdfs[b].type != MSK_BSDF_DIFFUSE)
-            return fail(ctx, MSK_ERR_UNSUPPORTED, "bsdf %u: type %d is not supported by this back end (diffuse only)", b, d->bsdfs[b].type);
-        for (int c = 0; c < 3; ++c) bsdfs[b * 4 + c] = d->bsdfs[b].reflectance[c];
+        const msk_bsdf_desc &bd = d->bsdfs[b];
+        if (bd.type != MSK_BSDF_DIFFUSE && bd.type != MSK_BSDF_ROUGHCONDUCTOR)
+            return fail(ctx, MSK_ERR_UNSUPPORTED, "bsdf %u: type %d is not supported by this back end (diffuse, roughconductor)", b, bd.type);
+        if (bd.back_bsdf >= (int32_t) d->n_bsdfs || bd.back_bsdf < -1)
+            return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: back_bsdf %d out of range", b, bd.back_bsdf);
+        if (bd.type == MSK_BSDF_ROUGHCONDUCTOR && !(bd.alpha_u >= 0.f && bd.alpha_v >= 0.f))
+            return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: negative roughness", b);
+        if (bd.type != MSK_BSDF_DIFFUSE || bd.back_bsdf >= 0) all_diffuse = false;
+        std::memcpy(&bsdfs[(size_t) b * 20], &bd, sizeof bd);
     }
     std::vector<float> emitters((size_t) std::max(1u, d->n_emitters) * 8, 0.f), d65((size_t) std::max(1u, d->n_emitters) * 95, 0.f), cdf_all;
     for (uint32_t e = 0; e < d->n_emitters; ++e) {
@@ -228,7 +236,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     mskbvh::Built bvh = mskbvh::build(pos.data(), d->n_faces);
 
     msk_scene *s = new msk_scene();
-    s->ctx = ctx; s->n_tris = d->n_faces; s->bvh_depth = bvh.max_depth;
+    s->ctx = ctx; s->n_tris = d->n_faces; s->bvh_depth = bvh.max_depth; s->all_diffuse = all_diffuse;
     std::vector<float> cie(d->cie1931_xyz, d->cie1931_xyz + 3 * MSK_CIE_SAMPLES);
     hipError_t e = hipSuccess;
     auto up = [&](DevBuf &b, const std::vector<float> &v) { if (e == hipSuccess) e = b.upload(v); };
@@ -262,7 +270,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     s->lds_scene = scene_bytes <= lds_cap && stack_bytes + scene_bytes <= 64 * 1024;
     s->trace_lds_bytes = stack_bytes + (s->lds_scene ? scene_bytes : 0);
     // LDS plan of k_shade_gen: the small lookup tables (tri_verts, mesh/bsdf/emitter records, cdf, d65, cie)
-    const size_t table_bytes = ((size_t) ds.n_tris * 3 + ds.n_meshes + ds.n_bsdfs + ds.n_emitters * 2 +
+    const size_t table_bytes = ((size_t) ds.n_tris * 3 + ds.n_meshes + ds.n_bsdfs * 5 + ds.n_emitters * 2 +
                                 (ds.n_emitters * 95 + 3) / 4 + (ds.cdf_len + 3) / 4 + 72) * 16;
     s->lds_tables = table_bytes <= 40 * 1024;
     s->shade_lds_bytes = s->lds_tables ? table_bytes : 0;
@@ -391,10 +399,10 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
         for (uint32_t g = 0; g < group; ++g, ++it) {
             hipEvent_t a = nullptr, b = nullptr, c = nullptr;
             if (timing) { a = ev.get(); b = ev.get(); c = ev.get(); (void) hipEventRecord(a, stream); }
-            if (sc->lds_tables)
-                hipLaunchKernelGGL(k_shade_gen<true>, dim3(grid), dim3(MSK_BLOCK), sc->shade_lds_bytes, stream, sc->dev, sb.st, pp);
-            else
-                hipLaunchKernelGGL(k_shade_gen<false>, dim3(grid), dim3(MSK_BLOCK), 0, stream, sc->dev, sb.st, pp);
+#define MSK_SHADE(L, D) hipLaunchKernelGGL((k_shade_gen<L, D>), dim3(grid), dim3(MSK_BLOCK), (L) ? sc->shade_lds_bytes : 0, stream, sc->dev, sb.st, pp)
+            if (sc->lds_tables) { if (sc->all_diffuse) MSK_SHADE(true, true); else MSK_SHADE(true, false); }
+            else { if (sc->all_diffuse) MSK_SHADE(false, true); else MSK_SHADE(false, false); }
+#undef MSK_SHADE
             if (timing) (void) hipEventRecord(b, stream);
             launch_trace(sc, stream, sb.st, pp);
             if (timing) { (void) hipEventRecord(c, stream); ev_shade.push_back({a, b}); ev_trace.push_back({b, c}); }

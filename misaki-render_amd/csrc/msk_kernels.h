@@ -37,7 +37,7 @@ struct DeviceScene {
     const float4 *tri_normals;  // 3 x float4 per triangle (n0 n1 n2) or nullptr
     const float4 *tri_uvs;      // 2 x float4 per triangle (uv0 uv1 | uv2 -) or nullptr
     const int4 *mesh_info;      // {bsdf_id, emitter_id, flags(1=normals,2=texcoords), first_face}
-    const float4 *bsdfs;        // per bsdf: {c0,c1,c2,type}
+    const float4 *bsdfs;        // 5 x float4 per bsdf = msk_bsdf_desc verbatim (20 words)
     const float4 *emitters;     // 2 x float4 per emitter: {c0,c1,c2,inv_area} {mesh,first_face,face_count,cdf_off (uint bits)}
     const float *emitter_d65;   // 95 floats per emitter (d65 * d65_scale)
     const float *cdf;           // concatenated area CDFs (face_count+1 each)
@@ -295,7 +295,7 @@ struct SceneTables {
     const float *emitter_d65, *cdf, *cie;
 };
 MSK_DEV uint32_t tables_lds_float4s(const DeviceScene &sc) {
-    return sc.n_tris * 3 + sc.n_meshes + sc.n_bsdfs + sc.n_emitters * 2 + (sc.n_emitters * 95 + 3) / 4 + (sc.cdf_len + 3) / 4 + 72;
+    return sc.n_tris * 3 + sc.n_meshes + sc.n_bsdfs * 5 + sc.n_emitters * 2 + (sc.n_emitters * 95 + 3) / 4 + (sc.cdf_len + 3) / 4 + 72;
 }
 template <bool LDS_TABLES>
 MSK_DEV SceneTables stage_tables(const DeviceScene &sc, float4 *lds) {
@@ -311,7 +311,7 @@ MSK_DEV SceneTables stage_tables(const DeviceScene &sc, float4 *lds) {
     auto copy1 = [&](const float *src, uint32_t n) { float *d = (float *) p; for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = src[i]; p += (n + 3) / 4; return d; };
     t.tri_verts = copy4(sc.tri_verts, sc.n_tris * 3);
     t.mesh_info = (const int4 *) copy4((const float4 *) sc.mesh_info, sc.n_meshes);
-    t.bsdfs = copy4(sc.bsdfs, sc.n_bsdfs);
+    t.bsdfs = copy4(sc.bsdfs, sc.n_bsdfs * 5);
     t.emitters = copy4(sc.emitters, sc.n_emitters * 2);
     t.emitter_d65 = copy1(sc.emitter_d65, sc.n_emitters * 95);
     t.cdf = copy1(sc.cdf, sc.cdf_len);
@@ -366,9 +366,83 @@ MSK_DEV spec emitter_radiance(const SceneTables &sc, int e, spec wl) {
 }
 
 // ------------------------------------------------------------------------------------------
+// BSDF layer (bsdfs/diffuse.cpp:18-57, bsdfs/roughconductor.cpp:52-120, bsdfs/twosided.cpp:38-101).
+// A bsdf record is msk_bsdf_desc as 5 float4: {type, back, r0, r1} {r2, au, av, sample_visible} eta k spec.
+// ------------------------------------------------------------------------------------------
+struct BsdfRec { float4 a, b, eta, k, spec; };
+MSK_DEV BsdfRec load_bsdf(const SceneTables &tb, int id) {
+    BsdfRec r; const float4 *p = tb.bsdfs + (size_t) id * 5;
+    r.a = p[0]; r.b = p[1]; r.eta = p[2]; r.k = p[3]; r.spec = p[4];
+    return r;
+}
+MSK_DEV spec spectrum_eval(float4 s, spec wl) { return srgb_model_eval(s.x, s.y, s.z, wl) * s.w; }
+MSK_DEV float clamp_alpha(float a) { return fmax_std(a, 1e-4f); }
+
+// eval + pdf with wi on the front side (roughconductor.cpp:82-117 / diffuse.cpp:35-57)
+template <bool DIFFUSE_ONLY>
+MSK_DEV void bsdf_eval_pdf(const BsdfRec &b, f3 wi, f3 wo, spec wl, spec *val, float *pdf) {
+    *val = splat(0.f); *pdf = 0.f;
+    const float cos_i = wi.z, cos_o = wo.z;
+    if (DIFFUSE_ONLY || __float_as_int(b.a.x) == 0) {
+        if (cos_i > 0.f && cos_o > 0.f) {
+            *val = srgb_model_eval(b.a.z, b.a.w, b.b.x, wl) * MSK_INV_PI_F * cos_o;
+            *pdf = MSK_INV_PI_F * wo.z;
+        }
+        return;
+    }
+    const float au = clamp_alpha(b.b.y), av = clamp_alpha(b.b.z);
+    if (cos_i > 0.f && cos_o > 0.f) {
+        const f3 H = normalized(wo + wi);
+        const float D = distr_eval(H, au, av);
+        if (D != 0) {
+            const float G = smith_g1(wi, H, au, av) * smith_g1(wo, H, au, av);
+            const float result = D * G / (4.f * wi.z);
+            const spec eta = spectrum_eval(b.eta, wl), kk = spectrum_eval(b.k, wl);
+            const float c = dot(wi, H);
+            spec F;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) F.v[i] = fresnel_conductor(c, eta.v[i], kk.v[i]);
+            *val = F * spectrum_eval(b.spec, wl) * result;
+        }
+    }
+    const f3 m = normalized(wo + wi);
+    if (cos_i > 0.f && cos_o > 0.f && dot(wi, m) > 0.f && dot(wo, m) > 0.f) {
+        if (__float_as_int(b.b.w)) *pdf = distr_eval(m, au, av) * smith_g1(wi, m, au, av) / (4.f * cos_i);
+        else *pdf = (distr_eval(m, au, av) * m.z) / (4.f * dot(wo, m));
+    }
+}
+// sample with wi on the front side; returns the weight, fills wo / pdf / ok (= a direction was produced)
+template <bool DIFFUSE_ONLY>
+MSK_DEV spec bsdf_sample(const BsdfRec &b, f3 wi, f2 sample, spec wl, f3 *wo, float *pdf, bool *ok) {
+    *wo = mk3(0.f, 0.f, 0.f); *pdf = 0.f; *ok = false;
+    const float cos_i = wi.z;
+    if (cos_i <= 0.f) return splat(0.f);
+    *ok = true;
+    if (DIFFUSE_ONLY || __float_as_int(b.a.x) == 0) {
+        *wo = square_to_cosine_hemisphere(sample);
+        *pdf = MSK_INV_PI_F * wo->z;
+        return *pdf > 0.f ? srgb_model_eval(b.a.z, b.a.w, b.b.x, wl) : splat(0.f);
+    }
+    const float au = clamp_alpha(b.b.y), av = clamp_alpha(b.b.z);
+    const f3 m = sample_ggx(sample, au, av, pdf);
+    *wo = m * 2.f * dot(wi, m) - wi;
+    if (!(*pdf != 0.f && wo->z > 0.f)) return splat(0.f);
+    float weight;
+    if (__float_as_int(b.b.w)) weight = smith_g1(*wo, m, au, av);
+    else weight = smith_g1(wi, m, au, av) * smith_g1(*wo, m, au, av) * dot(wi, m) / (cos_i * m.z);
+    *pdf /= 4.f * dot(*wo, m);
+    const spec eta = spectrum_eval(b.eta, wl), kk = spectrum_eval(b.k, wl);
+    const float c = dot(wi, m);
+    spec F;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) F.v[i] = fresnel_conductor(c, eta.v[i], kk.v[i]);
+    return F * weight;
+}
+
+// ------------------------------------------------------------------------------------------
 // k_shade_gen
 // ------------------------------------------------------------------------------------------
-template <bool LDS_TABLES>
+template <bool LDS_TABLES, bool DIFFUSE_ONLY>
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
     extern __shared__ float4 lds_dyn[];
@@ -410,7 +484,14 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
         if (alive && hit.x == MSK_INF_F) alive = false;                   // path.cpp:34-41 / 96-97, no environment
         if (alive) {
             Interaction si = make_interaction(tb, hit, rd);
-            const float4 bs = tb.bsdfs[si.bsdf_id];
+            // twosided.cpp:38-101: the nested BSDF of the side wi is on, with z of wi / wo flipped on the back
+            BsdfRec bs = load_bsdf(tb, si.bsdf_id);
+            f3 wi_s = si.wi;
+            bool flipped = false;
+            if (!DIFFUSE_ONLY) {
+                const int back = __float_as_int(bs.a.y);
+                if (back >= 0 && wi_s.z < 0.f) { wi_s.z = -wi_s.z; flipped = true; if (back != si.bsdf_id) bs = load_bsdf(tb, back); }
+            }
             if (depth > 1) {
                 // ---- tail of the previous bounce: emitter hit by the BSDF sample (path.cpp:82-88,103-108)
                 if (si.emitter_id >= 0) {
@@ -439,7 +520,6 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
             if (alive && (int) depth >= pp.max_depth && pp.max_depth > 0) alive = false;   // path.cpp:48-49
             if (alive) {
                 const uint32_t pb = 3 + 3 * (depth - 1);
-                const spec refl = srgb_model_eval(bs.x, bs.y, bs.z, wl);
                 // ---- next-event estimation (path.cpp:56-67, scene.cpp:68-103)
                 if (n_em > 0) {
                     f2 u = counter_pair(key, pb + 0);
@@ -491,12 +571,10 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
                     }
                     if (n_em > 1) { pdf *= light_sel_pdf; emitter_val = emitter_val * (float) n_em; }
                     if (pdf != 0.f) {
-                        const f3 wo = si.sh.to_local(d);
-                        spec bsdf_val = splat(0.f); float bsdf_pdf = 0.f;
-                        if (si.wi.z > 0.f && wo.z > 0.f) {                 // diffuse.cpp:35-57
-                            bsdf_val = refl * MSK_INV_PI_F * wo.z;
-                            bsdf_pdf = MSK_INV_PI_F * wo.z;
-                        }
+                        f3 wo = si.sh.to_local(d);
+                        if (flipped) wo.z = -wo.z;
+                        spec bsdf_val; float bsdf_pdf;
+                        bsdf_eval_pdf<DIFFUSE_ONLY>(bs, wi_s, wo, wl, &bsdf_val, &bsdf_pdf);
                         const float w = mis_weight(pdf, bsdf_pdf);
                         contrib = thr * emitter_val * bsdf_val * w;
                         if (any_nonzero(contrib)) {
@@ -505,19 +583,25 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
                         }
                     }
                 }
-                // ---- BSDF sampling (path.cpp:71-80, diffuse.cpp:18-33)
-                if (!(si.wi.z > 0.f)) {
-                    alive = false;             // failed sample: zero direction, the reference's ray misses
-                } else {
+                // ---- BSDF sampling (path.cpp:71-80)
+                {
                     const f2 u2 = counter_pair(key, pb + 2);
-                    const f3 wo_l = square_to_cosine_hemisphere(u2);
-                    bs_pdf = MSK_INV_PI_F * wo_l.z;
-                    const spec bsdf_val = bs_pdf > 0.f ? refl : splat(0.f);
-                    const f3 wo = si.sh.to_world(wo_l);
-                    new_o = make_float4(si.p.x, si.p.y, si.p.z, (1.f + max_abs(si.p)) * MSK_RAY_EPS_F);
-                    new_d = make_float4(wo.x, wo.y, wo.z, MSK_INF_F);
-                    thr = thr * bsdf_val;                                  // path.cpp:99
-                    depth += 1;
+                    f3 wo_l; bool ok;
+                    const spec bsdf_val = bsdf_sample<DIFFUSE_ONLY>(bs, wi_s, u2, wl, &wo_l, &bs_pdf, &ok);
+                    if (!ok) {
+                        alive = false;         // failed sample: zero direction, the reference's ray misses (no NEE either)
+                    } else {
+                        if (flipped) wo_l.z = -wo_l.z;
+                        const f3 wo = si.sh.to_world(wo_l);
+                        thr = thr * bsdf_val;                              // path.cpp:99
+                        // A path whose throughput is now zero can only add zeros from here on; it lives one more
+                        // iteration iff a shadow ray is pending (tmax < 0: the extension ray finds nothing).
+                        const bool dead = !any_nonzero(thr);
+                        if (dead && !has_shadow) alive = false;
+                        new_o = make_float4(si.p.x, si.p.y, si.p.z, (1.f + max_abs(si.p)) * MSK_RAY_EPS_F);
+                        new_d = make_float4(wo.x, wo.y, wo.z, dead ? -1.f : MSK_INF_F);
+                        depth += 1;
+                    }
                 }
             }
         }

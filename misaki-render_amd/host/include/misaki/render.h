@@ -16,7 +16,7 @@ class Texture : public Object {
 public:
     // plugins that the GPU back end can evaluate describe themselves as a sigmoid-polynomial
     // (render/srgb.h:8-19) optionally multiplied by a scaled D65 table (spectra/srgb_d65.cpp:34-36)
-    struct Flat { float coeff[3] = {0, 0, 0}; float d65_scale = 0.f; bool uses_d65 = false; };
+    struct Flat { float coeff[3] = {0, 0, 0}; float scale = 1.f; float d65_scale = 0.f; bool uses_d65 = false; };
     virtual bool flatten(Flat &out) const { (void) out; return false; }
     virtual float mean() const { return 0.f; }
     static ref<Texture> D65(float scale);
@@ -97,6 +97,7 @@ protected:
 class BSDF : public Object {
 public:
     virtual bool flatten(msk_bsdf_desc &out) const { (void) out; return false; }
+    virtual const BSDF *nested(int side) const { (void) side; return nullptr; }   // twosided: the BSDF of side 0 / 1
     std::string id() const override { return m_id; }
     MSK_DECLARE_CLASS()
 protected:

@@ -183,6 +183,25 @@ private:
 MSK_IMPLEMENT_CLASS(SRGBReflectanceSpectrum, Texture)
 MSK_REGISTER_INSTANCE(SRGBReflectanceSpectrum, "srgb")
 
+// srgb with the normalisation of spectra/srgb_d65.cpp:18-22 but no illuminant: value = scale * S(fetch(rgb / scale))
+// for colours above 1 (conductor eta / k given as <rgb>), plain srgb otherwise
+class SRGBUnboundedSpectrum final : public Texture {
+public:
+    SRGBUnboundedSpectrum(const Properties &props) : Texture(props) {
+        Color3 c = props.color("color");
+        const float mx = std::max(c.r, std::max(c.g, c.b));
+        if (mx > 1.f) { m_scale = mx * 2.f; c.r /= m_scale; c.g /= m_scale; c.b /= m_scale; }
+        m_value = srgb_model_fetch(c);
+    }
+    bool flatten(Flat &out) const override { out.coeff[0] = m_value.r; out.coeff[1] = m_value.g; out.coeff[2] = m_value.b; out.scale = m_scale; out.uses_d65 = false; return true; }
+    MSK_DECLARE_CLASS()
+private:
+    Color3 m_value;
+    float m_scale = 1.f;
+};
+MSK_IMPLEMENT_CLASS(SRGBUnboundedSpectrum, Texture)
+MSK_REGISTER_INSTANCE(SRGBUnboundedSpectrum, "srgb_unbounded")
+
 // spectra/d65.cpp:29-47: a D65 table scaled by scale / 10568
 class D65Spectrum final : public Texture {
 public:
@@ -314,6 +333,13 @@ class RGBFilm final : public HDRFilm { public: RGBFilm(const Properties &p) : HD
 MSK_IMPLEMENT_CLASS(RGBFilm, HDRFilm)
 MSK_REGISTER_INSTANCE(RGBFilm, "rgbfilm")
 
+static void init_bsdf_desc(msk_bsdf_desc &out) {
+    std::memset(&out, 0, sizeof out);
+    out.back_bsdf = -1;
+    const msk_spectrum_desc one{{0.f, 0.f, INFINITY}, 1.f};
+    out.eta = out.k = out.specular_reflectance = one;
+}
+
 // =========================================================================== bsdf, emitter, sensor, shape
 // bsdfs/diffuse.cpp:12-16
 class SmoothDiffuse final : public BSDF {
@@ -322,7 +348,7 @@ public:
     bool flatten(msk_bsdf_desc &out) const override {
         Texture::Flat f;
         if (!m_reflectance->flatten(f) || f.uses_d65) return false;
-        std::memset(&out, 0, sizeof out);
+        init_bsdf_desc(out);
         out.type = MSK_BSDF_DIFFUSE;
         std::memcpy(out.reflectance, f.coeff, sizeof f.coeff);
         return true;
@@ -333,6 +359,80 @@ private:
 };
 MSK_IMPLEMENT_CLASS(SmoothDiffuse, BSDF)
 MSK_REGISTER_INSTANCE(SmoothDiffuse, "diffuse")
+
+// bsdfs/roughconductor.cpp:12-50.  Adaptation (DESIGN.md §rough conductor; the reference's version is not
+// compiled and typed against RGB): GGX only — "beckmann", the reference's default, evaluates to
+// zero there (microfacet.h:113-115) and is rejected here; alpha is a float property; eta / k /
+// specular_reflectance are spectra.  An <rgb> above 1 (metal eta, k) is loaded as an srgb_unbounded texture.
+class RoughConductor final : public BSDF {
+public:
+    RoughConductor(const Properties &props) : BSDF(props) {
+        if (!props.has_property("eta") || !props.has_property("k"))
+            Throw("roughconductor: both \"eta\" and \"k\" must be specified");
+        m_eta = unbounded(props, "eta"); m_k = unbounded(props, "k");
+        const std::string distr = props.string("distribution", "ggx");
+        if (distr != "ggx") {
+            if (distr == "beckmann") Throw("roughconductor: the \"beckmann\" distribution is not implemented (use \"ggx\")");
+            Throw("Specified an invalid distribution \"{}\", must be \"beckmann\" or \"ggx\"!", distr);
+        }
+        m_sample_visible = props.bool_("sample_visible", false);
+        if (props.has_property("alpha_u") || props.has_property("alpha_v")) {
+            if (!props.has_property("alpha_u") || !props.has_property("alpha_v"))
+                Throw("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.");
+            if (props.has_property("alpha")) Throw("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.");
+            m_alpha_u = props.float_("alpha_u"); m_alpha_v = props.float_("alpha_v");
+        } else {
+            m_alpha_u = m_alpha_v = props.float_("alpha", 0.1f);
+        }
+        m_specular_reflectance = props.texture("specular_reflectance", 1.f);
+    }
+    // props.texture() builds a bounded "srgb" texture from <rgb>; conductors need values above 1
+    static ref<Texture> unbounded(const Properties &props, const std::string &name) {
+        if (props.type(name) == Properties::Type::Object) return props.texture(name);
+        Properties p("srgb_unbounded");
+        if (props.type(name) == Properties::Type::Color) p.set_color("color", props.color(name));
+        else { const float v = props.float_(name); p.set_color("color", Color3{v, v, v}); }
+        return InstanceManager::get()->create_instance<Texture>(p);
+    }
+    bool flatten(msk_bsdf_desc &out) const override {
+        Texture::Flat e, k, s;
+        if (!m_eta->flatten(e) || !m_k->flatten(k) || !m_specular_reflectance->flatten(s) || e.uses_d65 || k.uses_d65 || s.uses_d65) return false;
+        init_bsdf_desc(out);
+        out.type = MSK_BSDF_ROUGHCONDUCTOR;
+        out.alpha_u = m_alpha_u; out.alpha_v = m_alpha_v; out.sample_visible = m_sample_visible ? 1 : 0;
+        auto put = [](msk_spectrum_desc &d, const Texture::Flat &f) { std::memcpy(d.coeff, f.coeff, sizeof f.coeff); d.scale = f.scale; };
+        put(out.eta, e); put(out.k, k); put(out.specular_reflectance, s);
+        return true;
+    }
+    MSK_DECLARE_CLASS()
+private:
+    ref<Texture> m_eta, m_k, m_specular_reflectance;
+    float m_alpha_u, m_alpha_v;
+    bool m_sample_visible;
+};
+MSK_IMPLEMENT_CLASS(RoughConductor, BSDF)
+MSK_REGISTER_INSTANCE(RoughConductor, "roughconductor")
+
+// bsdfs/twosided.cpp:12-36
+class TwoSidedBRDF final : public BSDF {
+public:
+    TwoSidedBRDF(const Properties &props) : BSDF(props) {
+        auto bsdfs = props.objects();
+        for (auto &kv : bsdfs) if (!dynamic_cast<BSDF *>(kv.second.get())) Throw("twosided: nested object \"{}\" is not a BSDF", kv.first);
+        if (!bsdfs.empty()) m_brdf[0] = static_cast<BSDF *>(bsdfs[0].second.get());
+        if (bsdfs.size() == 2) m_brdf[1] = static_cast<BSDF *>(bsdfs[1].second.get());
+        else if (bsdfs.size() > 2) Throw("At most two nested BSDFs can be specified!");
+        if (!m_brdf[0]) Throw("A nested one-sided material is required!");
+        if (!m_brdf[1]) m_brdf[1] = m_brdf[0];
+    }
+    const BSDF *nested(int i) const override { return m_brdf[i].get(); }
+    bool flatten(msk_bsdf_desc &out) const override { return m_brdf[0]->flatten(out); }   // front side; flatten_scene adds the back
+    MSK_DECLARE_CLASS()
+private:
+    ref<BSDF> m_brdf[2];
+};
+MSK_IMPLEMENT_CLASS(TwoSidedBRDF, BSDF)
+MSK_REGISTER_INSTANCE(TwoSidedBRDF, "twosided")
 
 // emitters/area.cpp:13-18
 class AreaLight final : public Emitter {
@@ -488,6 +588,16 @@ void flatten_scene(const Scene *scene, const Sensor *sensor, FlatScene &out) {
         msk_bsdf_desc bd;
         if (!shape->bsdf()->flatten(bd))
             Throw("BSDF \"{}\" of shape {} cannot be evaluated by the GPU path integrator", shape->bsdf()->clazz()->name(), i);
+        if (const BSDF *back = shape->bsdf()->nested(1)) {          // twosided adapter (twosided.cpp:38-101)
+            if (back == shape->bsdf()->nested(0)) {
+                bd.back_bsdf = (int32_t) out.bsdfs.size();
+            } else {
+                msk_bsdf_desc bb;
+                if (!back->flatten(bb)) Throw("BSDF \"{}\" of shape {} cannot be evaluated by the GPU path integrator", back->clazz()->name(), i);
+                out.bsdfs.push_back(bb);
+                bd.back_bsdf = (int32_t) out.bsdfs.size() - 1;
+            }
+        }
         out.bsdfs.push_back(bd);
         int eid = -1;
         if (shape->is_emitter()) {

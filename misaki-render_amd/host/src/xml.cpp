@@ -263,7 +263,11 @@ std::pair<std::string, std::string> parse(Context &ctx, Node &n, Tag parent_tag,
                 if (t.size() != 3) rd.fail(n.offset, "'rgb' tag requires one or three values (got \"" + n.value("value") + "\")");
                 Color3 c{parse_float(rd, n, t[0]), parse_float(rd, n, t[1]), parse_float(rd, n, t[2])};
                 if (!within_spectrum) {       // xml.cpp:269-277: srgb_d65 inside <emitter>, srgb elsewhere
-                    Properties p(within_emitter ? "srgb_d65" : "srgb");
+                    // "eta" / "k" are physical quantities, not reflectances: the bounded srgb texture would clamp
+                    // them to 1 (rgb2spec.c:83-84).  Like Mitsuba 2's loader they get the unbounded variant here.
+                    const std::string pname = n.value("name");
+                    const bool unbounded = !within_emitter && (pname == "eta" || pname == "k");
+                    Properties p(within_emitter ? "srgb_d65" : unbounded ? "srgb_unbounded" : "srgb");
                     p.set_color("color", c);
                     props.set_object(n.value("name"), InstanceManager::get()->create_instance(p, Class::for_name("Texture")));
                 } else {

@@ -86,9 +86,12 @@ def perspective_camera(fov, near, far, width, height, origin, target, up):
 class MeshSpec:
     """One <shape type="obj"> of the scene: faces as 3- or 4-tuples of 3D points."""
 
-    def __init__(self, name, faces, reflectance, radiance=None, translate=(0, 0, 0), normals=None):
+    def __init__(self, name, faces, reflectance, radiance=None, translate=(0, 0, 0), normals=None, bsdf=None):
+        """bsdf: None = <bsdf type="diffuse"> with `reflectance`; or a dict for a rough conductor
+        {"type": "roughconductor", "alpha": a | ("alpha_u","alpha_v"), "eta": rgb, "k": rgb,
+         "specular_reflectance": rgb (default 1), "sample_visible": bool, "twosided": bool}."""
         self.name, self.faces, self.reflectance, self.radiance = name, faces, reflectance, radiance
-        self.translate, self.normals = translate, normals
+        self.translate, self.normals, self.bsdf = translate, normals, bsdf
 
 
 def triangulate(mesh):
@@ -226,6 +229,39 @@ def blob_mesh(name, center, radius, n_theta, n_phi, reflectance, seed=1, bump=0.
     return MeshSpec(name, faces, reflectance)
 
 
+def spectrum_desc(rgb, fetch):
+    """rgb -> msk_spectrum_desc.  In-gamut colours: S(fetch(rgb)); values above 1 (conductor eta/k) use the
+    normalisation of spectra/srgb_d65.cpp:18-22 without the D65 factor: scale = 2 max, fetch(rgb / scale)."""
+    rgb = np.asarray(rgb, np.float32)
+    if rgb.max() <= 1.0:
+        return abi.SpectrumDesc((C.c_float * 3)(*fetch(tuple(float(x) for x in rgb))), 1.0)
+    scale = np.float32(rgb.max() * np.float32(2.0))
+    return abi.SpectrumDesc((C.c_float * 3)(*fetch(tuple(float(x) for x in rgb / scale))), float(scale))
+
+
+def _bsdf_desc(m, fetch, index):
+    b = abi.BsdfDesc()
+    b.back_bsdf = -1
+    one = abi.SpectrumDesc((C.c_float * 3)(0.0, 0.0, float("inf")), 1.0)
+    b.eta, b.k, b.specular_reflectance = one, one, one
+    spec = m.bsdf or {"type": "diffuse"}
+    if spec["type"] == "diffuse":
+        b.type = abi.MSK_BSDF_DIFFUSE
+        b.reflectance[:] = fetch(tuple(m.reflectance))
+    elif spec["type"] == "roughconductor":
+        b.type = abi.MSK_BSDF_ROUGHCONDUCTOR
+        a = spec.get("alpha", 0.1)
+        b.alpha_u, b.alpha_v = (a, a) if np.isscalar(a) else a
+        b.sample_visible = int(bool(spec.get("sample_visible", False)))
+        b.eta, b.k = spectrum_desc(spec["eta"], fetch), spectrum_desc(spec["k"], fetch)
+        b.specular_reflectance = spectrum_desc(spec.get("specular_reflectance", (1.0, 1.0, 1.0)), fetch)
+    else:
+        raise ValueError(spec["type"])
+    if spec.get("twosided"):
+        b.back_bsdf = index            # twosided(A): the same BSDF on both sides (twosided.cpp:23-24)
+    return b
+
+
 # ----------------------------------------------------------------------------- flatten
 class FlatScene:
     """Owns the numpy arrays an msk_scene_desc points into."""
@@ -247,9 +283,7 @@ def flatten(meshes, width, height, camera=None, filter_stddev=0.5, coeff_lookup=
     nv = nf = 0
     for i, m in enumerate(meshes):
         v, f = triangulate(m)
-        c = fetch(tuple(m.reflectance))
-        b = abi.BsdfDesc(abi.MSK_BSDF_DIFFUSE, (C.c_float * 3)(*c), (C.c_float * 12)())
-        bd.append(b)
+        bd.append(_bsdf_desc(m, fetch, len(bd)))
         eid = -1
         if m.radiance is not None:
             # spectra/srgb_d65.cpp:13-31: scale = 2*max(rgb); color /= scale; d65 scale *= scale;

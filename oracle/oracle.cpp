@@ -550,6 +550,136 @@ static float mis_weight(float pdf_a, float pdf_b) {
     return pdf_a > 0.f ? pdf_a / (pdf_a + pdf_b) : 0.f;
 }
 
+// ===========================================================================
+// BSDFs: a11 diffuse (bsdfs/diffuse.cpp:18-57); §8(f)1 rough conductor
+// (bsdfs/roughconductor.cpp:52-120, render/microfacet.h:11-44,145-175,
+// render/fresnel.h:65-88) and the twosided adapter (bsdfs/twosided.cpp:38-101).
+//
+// The rough conductor has NO runnable reference (not compiled, written
+// against Color3/eval_3, default distribution Beckmann is unimplemented).  This
+// restates its arithmetic with the adaptation DESIGN.md §rough conductor states:
+// GGX only; alpha is a float property; eta, k and specular_reflectance are
+// spectra evaluated at the path's four wavelengths (value = scale * S(coeff, l)).
+// ===========================================================================
+struct BSDFSampleRec { V3 wo; float pdf, eta; uint32_t sampled_type; };   // render/bsdf.h:60-80
+enum : uint32_t { kDiffuseReflection = 1u, kGlossyReflection = 2u };
+
+static S4 spectrum_eval(const msk_spectrum_desc &sp, S4 wl) { return srgb_model_eval(sp.coeff, wl) * sp.scale; }
+
+// render/microfacet.h:11-18
+static float eval_ggx(V3 m, float au, float av) {
+    float cos_theta2 = m.z * m.z;
+    float beckman_exp = ((m.x * m.x / (au * au)) + (m.y * m.y) / (av * av)) / cos_theta2;
+    float root = (1.f + beckman_exp) * cos_theta2;
+    return 1.f / (kPi * au * av * root * root);
+}
+// render/microfacet.h:20-40
+static V3 sample_ggx(V2 sample, float au, float av, float *pdf_out) {
+    float phi_m = det_atan(au / av * det_tan(kPi + 2 * kPi * sample.y)) + kPi * std::floor(2 * sample.y + 0.5f);
+    float sin_phi_m, cos_phi_m;
+    det_sincos(phi_m, &sin_phi_m, &cos_phi_m);
+    float cs = cos_phi_m / au, sn = sin_phi_m / av;
+    float alpha_sqr = 1.f / (cs * cs + sn * sn);
+    float tan_theta_m_sqr = alpha_sqr * sample.x / (1.f - sample.x);
+    float cos_theta_m = 1.f / std::sqrt(1.f + tan_theta_m_sqr);
+    float tmp = 1 + tan_theta_m_sqr / alpha_sqr;
+    float pdf = kInvPi / (au * av * cos_theta_m * cos_theta_m * cos_theta_m * tmp * tmp);
+    if (pdf < 1e-20f) pdf = 0;
+    float sin_theta_m = safe_sqrt(1 - cos_theta_m * cos_theta_m);
+    *pdf_out = pdf;
+    return mk3(sin_theta_m * cos_phi_m, sin_theta_m * sin_phi_m, cos_theta_m);
+}
+// MicrofacetDistribution::eval (microfacet.h:104-121), GGX
+static float distr_eval(V3 m, float au, float av) {
+    if (m.z <= 0) return 0.0f;
+    float result = eval_ggx(m, au, av);
+    return result * m.z > 1e-20f ? result : 0.f;
+}
+// MicrofacetDistribution::smith_g1 (microfacet.h:145-172), GGX
+static float smith_g1(V3 v, V3 m, float au, float av) {
+    float xy_alpha_2 = (au * v.x) * (au * v.x) + (av * v.y) * (av * v.y), tan_theta_alpha_2 = xy_alpha_2 / (v.z * v.z);
+    if (xy_alpha_2 == 0.f) return 1.f;
+    if (dot(v, m) * v.z <= 0.f) return 0.f;
+    return 2.f / (1.f + std::sqrt(1.f + tan_theta_alpha_2));
+}
+// render/fresnel.h:65-88, one wavelength
+static float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
+    float cos_theta_i_2 = cos_theta_i * cos_theta_i, sin_theta_i_2 = 1.f - cos_theta_i_2, sin_theta_i_4 = sin_theta_i_2 * sin_theta_i_2;
+    float temp_1 = eta_r * eta_r - eta_i * eta_i - sin_theta_i_2;
+    float a_2_pb_2 = std::sqrt(temp_1 * temp_1 + 4.f * eta_i * eta_i * eta_r * eta_r);
+    float a = std::sqrt(.5f * (a_2_pb_2 + temp_1));
+    float term_1 = a_2_pb_2 + cos_theta_i_2, term_2 = 2.f * cos_theta_i * a;
+    float r_s = (term_1 - term_2) / (term_1 + term_2);
+    float term_3 = a_2_pb_2 * cos_theta_i_2 + sin_theta_i_4, term_4 = term_2 * sin_theta_i_2;
+    float r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
+    return .5f * (r_s + r_p);
+}
+static S4 fresnel_conductor4(float c, S4 eta, S4 k) {
+    S4 r; for (int i = 0; i < 4; ++i) r.v[i] = fresnel_conductor(c, eta.v[i], k.v[i]); return r;
+}
+static float clamp_alpha(float a) { return std::max(a, 1e-4f); }   // MicrofacetDistribution::configure
+
+// one-sided evaluation (wi already on the front side for twosided)
+static void bsdf_eval_pdf(const msk_bsdf_desc &b, V3 wi, V3 wo, S4 wl, S4 *val, float *pdf) {
+    *val = s4(0.f); *pdf = 0.f;
+    float cos_i = wi.z, cos_o = wo.z;
+    if (b.type == MSK_BSDF_DIFFUSE) {                                  // diffuse.cpp:35-57
+        if (cos_i > 0.f && cos_o > 0.f) {
+            *val = srgb_model_eval(b.reflectance, wl) * kInvPi * cos_o;
+            *pdf = square_to_cosine_hemisphere_pdf(wo);
+        }
+        return;
+    }
+    const float au = clamp_alpha(b.alpha_u), av = clamp_alpha(b.alpha_v);
+    // roughconductor.cpp:82-98 eval
+    if (cos_i > 0.f && cos_o > 0.f) {
+        V3 H = normalized(wo + wi);
+        float D = distr_eval(H, au, av);
+        if (D != 0) {
+            float G = smith_g1(wi, H, au, av) * smith_g1(wo, H, au, av);
+            float result = D * G / (4.f * wi.z);
+            S4 F = fresnel_conductor4(dot(wi, H), spectrum_eval(b.eta, wl), spectrum_eval(b.k, wl));
+            *val = F * spectrum_eval(b.specular_reflectance, wl) * result;
+        }
+    }
+    // roughconductor.cpp:100-117 pdf
+    V3 m = normalized(wo + wi);
+    if (cos_i > 0.f && cos_o > 0.f && dot(wi, m) > 0.f && dot(wo, m) > 0.f) {
+        if (b.sample_visible) *pdf = distr_eval(m, au, av) * smith_g1(wi, m, au, av) / (4.f * cos_i);
+        else *pdf = (distr_eval(m, au, av) * m.z) / (4.f * dot(wo, m));
+    }
+}
+static S4 bsdf_sample(const msk_bsdf_desc &b, V3 wi, float sample1, V2 sample, S4 wl, BSDFSampleRec *bs) {
+    (void) sample1;
+    bs->wo = mk3(0, 0, 0); bs->pdf = 0.f; bs->eta = 1.f; bs->sampled_type = 0;       // render/bsdf.h:75-77
+    float cos_i = wi.z;
+    if (cos_i <= 0.f) return s4(0.f);
+    if (b.type == MSK_BSDF_DIFFUSE) {                                  // diffuse.cpp:18-33
+        bs->wo = square_to_cosine_hemisphere(sample);
+        bs->pdf = square_to_cosine_hemisphere_pdf(bs->wo);
+        bs->sampled_type = kDiffuseReflection;
+        return bs->pdf > 0.f ? srgb_model_eval(b.reflectance, wl) : s4(0.f);
+    }
+    // roughconductor.cpp:52-80
+    const float au = clamp_alpha(b.alpha_u), av = clamp_alpha(b.alpha_v);
+    V3 m = sample_ggx(sample, au, av, &bs->pdf);
+    bs->wo = m * 2.f * dot(wi, m) - wi;                                // fresnel.h:17-21 reflect(wi, m)
+    bs->sampled_type = kGlossyReflection;
+    if (!(bs->pdf != 0.f && bs->wo.z > 0.f)) return s4(0.f);
+    float weight;
+    if (b.sample_visible) weight = smith_g1(bs->wo, m, au, av);
+    else weight = smith_g1(wi, m, au, av) * smith_g1(bs->wo, m, au, av) * dot(wi, m) / (cos_i * m.z);
+    bs->pdf /= 4.f * dot(bs->wo, m);
+    S4 F = fresnel_conductor4(dot(wi, m), spectrum_eval(b.eta, wl), spectrum_eval(b.k, wl));
+    return F * weight;
+}
+// twosided.cpp:38-101: pick the nested BSDF by the side wi is on, flip z of wi and wo on the back
+static const msk_bsdf_desc *bsdf_side(const Scene &sc, const msk_bsdf_desc &b, V3 *wi, bool *flipped) {
+    *flipped = false;
+    if (b.back_bsdf >= 0 && wi->z < 0.f) { wi->z *= -1.f; *flipped = true; return &sc.bsdfs[b.back_bsdf]; }
+    return &b;
+}
+
 struct Counters { uint64_t samples = 0, segments = 0, shadow_rays = 0; };
 
 // ===========================================================================
@@ -580,31 +710,29 @@ static S4 path_sample(const Scene &sc, Sampler &sampler, Ray ray, S4 wl, const m
             S4 emitter_val;
             ds = sample_emitter_direct(sc, si, u, wl, &emitter_val, &cnt.shadow_rays);
             if (ds.pdf != 0.f) {
-                V3 wo = si.sh.to_local(ds.d);
-                // diffuse.cpp:35-57 eval / pdf
-                float cos_i = si.wi.z, cos_o = wo.z;
-                S4 bsdf_val = s4(0.f); float bsdf_pdf = 0.f;
-                if (cos_i > 0.f && cos_o > 0.f) {
-                    bsdf_val = srgb_model_eval(bsdf.reflectance, wl) * kInvPi * cos_o;
-                    bsdf_pdf = square_to_cosine_hemisphere_pdf(wo);
-                }
+                V3 wo = si.sh.to_local(ds.d), wi_s = si.wi;
+                bool flipped;
+                const msk_bsdf_desc *bb = bsdf_side(sc, bsdf, &wi_s, &flipped);
+                if (flipped) wo.z *= -1.f;
+                S4 bsdf_val; float bsdf_pdf;
+                bsdf_eval_pdf(*bb, wi_s, wo, wl, &bsdf_val, &bsdf_pdf);
                 float weight = mis_weight(ds.pdf, bsdf_pdf);
                 result = result + throughput * emitter_val * bsdf_val * weight;
             }
         }
-        // ---- BSDF sampling (path.cpp:71-73, diffuse.cpp:18-33), D3 order
-        float sample1 = sampler.single(base + 1, 0); (void) sample1;
+        // ---- BSDF sampling (path.cpp:71-73), D3 order
+        float sample1 = sampler.single(base + 1, 0);
         V2 u2; sampler.pair(base + 2, &u2.x, &u2.y);
-        V3 bs_wo = mk3(0, 0, 0); float bs_pdf = 0.f, bs_eta = 1.f;
-        S4 bsdf_val = s4(0.f);
-        uint32_t sampled_type = 0;
-        if (si.wi.z > 0.f) {
-            bs_wo = square_to_cosine_hemisphere(u2);
-            bs_pdf = square_to_cosine_hemisphere_pdf(bs_wo);
-            bs_eta = 1.f;
-            sampled_type = 1;
-            bsdf_val = bs_pdf > 0.f ? srgb_model_eval(bsdf.reflectance, wl) : s4(0.f);
+        BSDFSampleRec bs;
+        S4 bsdf_val;
+        {
+            V3 wi_s = si.wi; bool flipped;
+            const msk_bsdf_desc *bb = bsdf_side(sc, bsdf, &wi_s, &flipped);
+            bsdf_val = bsdf_sample(*bb, wi_s, sample1, u2, wl, &bs);
+            if (flipped) bs.wo.z *= -1.f;
         }
+        const V3 bs_wo = bs.wo; const float bs_pdf = bs.pdf, bs_eta = bs.eta;
+        const uint32_t sampled_type = bs.sampled_type;
         scattered |= true;   // path.cpp:73: sampled_type (0 on failure) != Null is always true
         V3 wo = si.sh.to_world(bs_wo);
         bool hit_emitter = false;
@@ -887,6 +1015,29 @@ void msk_oracle_warps(const float *u2, float *tri2, float *disk2, float *hemi3) 
 }
 void msk_oracle_det_math(float x, float *out4) {   // sin, cos, atanh, cosh
     det_sincos(x, &out4[0], &out4[1]); out4[2] = det_atanh(x); out4[3] = det_cosh(x);
+}
+void msk_oracle_det_math2(float x, float *out2) { out2[0] = det_atan(x); out2[1] = det_tan(x); }
+// BSDF layer hooks: wi/wo in the local shading frame, twosided handled like the integrator does
+void msk_oracle_bsdf_eval(const msk_bsdf_desc *bsdfs, int n, int id, const float *wi3, const float *wo3, const float *wl4,
+                          float *val4, float *pdf) {
+    Scene sc; sc.bsdfs.assign(bsdfs, bsdfs + n);
+    V3 wi = mk3(wi3[0], wi3[1], wi3[2]), wo = mk3(wo3[0], wo3[1], wo3[2]);
+    S4 wl; for (int i = 0; i < 4; ++i) wl.v[i] = wl4[i];
+    bool flipped; const msk_bsdf_desc *b = bsdf_side(sc, sc.bsdfs[id], &wi, &flipped);
+    if (flipped) wo.z *= -1.f;
+    S4 v; bsdf_eval_pdf(*b, wi, wo, wl, &v, pdf);
+    for (int i = 0; i < 4; ++i) val4[i] = v.v[i];
+}
+void msk_oracle_bsdf_sample(const msk_bsdf_desc *bsdfs, int n, int id, const float *wi3, const float *u2, const float *wl4,
+                            float *wo3, float *pdf, float *weight4) {
+    Scene sc; sc.bsdfs.assign(bsdfs, bsdfs + n);
+    V3 wi = mk3(wi3[0], wi3[1], wi3[2]);
+    S4 wl; for (int i = 0; i < 4; ++i) wl.v[i] = wl4[i];
+    bool flipped; const msk_bsdf_desc *b = bsdf_side(sc, sc.bsdfs[id], &wi, &flipped);
+    BSDFSampleRec bs; S4 w = bsdf_sample(*b, wi, 0.f, V2{u2[0], u2[1]}, wl, &bs);
+    if (flipped) bs.wo.z *= -1.f;
+    wo3[0] = bs.wo.x; wo3[1] = bs.wo.y; wo3[2] = bs.wo.z; *pdf = bs.pdf;
+    for (int i = 0; i < 4; ++i) weight4[i] = w.v[i];
 }
 // filters/gaussian.cpp:10-20 + rfilter.cpp:12-27 (host side of the reference; libm expf)
 void msk_oracle_gaussian_filter(float stddev, float *radius, float *lut33, float *scale_factor, int *border) {

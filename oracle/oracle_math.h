@@ -184,6 +184,45 @@ static inline float det_cosh(float x) {
     return (float) (0.5 * (e + 1.0 / e));
 }
 
+// arctangent of a double (any finite z): two range reductions, then the Taylor series on |t| <= tan(pi/8)
+static inline double det_atan_d(double z) {
+    const double pio2 = 1.57079632679489655800, pio4 = 0.78539816339744827900;
+    const double sgn = z < 0.0 ? -1.0 : 1.0;
+    double a = z < 0.0 ? -z : z;
+    const bool inv = a > 1.0;
+    if (inv) a = 1.0 / a;
+    double base = 0.0, t = a;
+    if (a > 0.41421356237309503) { t = (a - 1.0) / (a + 1.0); base = pio4; }
+    const double w = t * t;
+    double p = 1.0 / 45.0;
+    p = 1.0 / 43.0 - w * p; p = 1.0 / 41.0 - w * p; p = 1.0 / 39.0 - w * p; p = 1.0 / 37.0 - w * p;
+    p = 1.0 / 35.0 - w * p; p = 1.0 / 33.0 - w * p; p = 1.0 / 31.0 - w * p; p = 1.0 / 29.0 - w * p;
+    p = 1.0 / 27.0 - w * p; p = 1.0 / 25.0 - w * p; p = 1.0 / 23.0 - w * p; p = 1.0 / 21.0 - w * p;
+    p = 1.0 / 19.0 - w * p; p = 1.0 / 17.0 - w * p; p = 1.0 / 15.0 - w * p; p = 1.0 / 13.0 - w * p;
+    p = 1.0 / 11.0 - w * p; p = 1.0 / 9.0 - w * p; p = 1.0 / 7.0 - w * p; p = 1.0 / 5.0 - w * p;
+    p = 1.0 / 3.0 - w * p; p = 1.0 - w * p;
+    double r = base + t * p;
+    if (inv) r = pio2 - r;
+    return sgn * r;
+}
+static inline float det_atan(float z) {
+    if (g_use_libm) return std::atan(z);
+    return (float) det_atan_d((double) z);
+}
+// tangent of an fp32 angle: sin/cos of the det_sincos core in fp64, one rounding
+static inline float det_tan(float phi) {
+    if (g_use_libm) return std::tan(phi);
+    const double two_over_pi = 0.63661977236758134308;
+    const double pio2_hi = 1.57079632679489655800e+00;
+    const double pio2_lo = 6.12323399573676603587e-17;
+    double x = (double) phi;
+    double k = std::rint(x * two_over_pi);
+    double y = (x - k * pio2_hi) - k * pio2_lo;
+    int q = (int) ((long long) k & 1);
+    double sy = det_sin_poly(y), cy = det_cos_poly(y);
+    return (float) (q ? -cy / sy : sy / cy);
+}
+
 // ---------------------------------------------------------------------------
 // PCG32 — core/mathutils.h:85-143
 // ---------------------------------------------------------------------------

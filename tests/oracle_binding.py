@@ -40,6 +40,9 @@ class Oracle:
         lib.msk_oracle_block_put.argtypes = [C.POINTER(abi.FilmDesc), C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_int, vp, vp, vp]
         lib.msk_oracle_rgb2spec_fetch.argtypes = [C.c_int, vp, vp, vp, vp]
+        lib.msk_oracle_det_math2.argtypes = [C.c_float, vp]
+        lib.msk_oracle_bsdf_eval.argtypes = [C.POINTER(abi.BsdfDesc), C.c_int, C.c_int, vp, vp, vp, vp, vp]
+        lib.msk_oracle_bsdf_sample.argtypes = [C.POINTER(abi.BsdfDesc), C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
 
     # ---- scene-level
     def scene(self, flat):
@@ -89,6 +92,25 @@ class Oracle:
         o = np.zeros(4, np.float32)
         self.lib.msk_oracle_det_math(x, _p(o))
         return o
+
+    def det_math2(self, x):
+        o = np.zeros(2, np.float32)
+        self.lib.msk_oracle_det_math2(x, _p(o))
+        return o
+
+    def bsdf_eval(self, bsdfs, idx, wi, wo, wl=(450, 520, 600, 680)):
+        arr = (self.abi.BsdfDesc * len(bsdfs))(*bsdfs)
+        wi, wo, wl = (np.asarray(v, np.float32) for v in (wi, wo, wl))
+        val, pdf = np.zeros(4, np.float32), C.c_float()
+        self.lib.msk_oracle_bsdf_eval(arr, len(bsdfs), idx, _p(wi), _p(wo), _p(wl), _p(val), C.byref(pdf))
+        return val, pdf.value
+
+    def bsdf_sample(self, bsdfs, idx, wi, u, wl=(450, 520, 600, 680)):
+        arr = (self.abi.BsdfDesc * len(bsdfs))(*bsdfs)
+        wi, u, wl = (np.asarray(v, np.float32) for v in (wi, u, wl))
+        wo, pdf, w = np.zeros(3, np.float32), C.c_float(), np.zeros(4, np.float32)
+        self.lib.msk_oracle_bsdf_sample(arr, len(bsdfs), idx, _p(wi), _p(u), _p(wl), _p(wo), C.byref(pdf), _p(w))
+        return wo, pdf.value, w
 
     def set_libm(self, on):
         self.lib.msk_oracle_set_libm(int(on))

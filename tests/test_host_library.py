@@ -100,6 +100,34 @@ def test_transform_ops_and_default_bsdf(hostlib, hostmirror, tmp_path):
     assert flat.desc.n_bsdfs == 1 and np.allclose(flat.desc.bsdfs[0].reflectance[:], [0, 0, 0])   # grey 0.5 -> zero polynomial
 
 
+def test_roughconductor_and_twosided_plugins(hostlib, hostmirror, tmp_path, abi):
+    """bsdfs/roughconductor.cpp:12-50 and bsdfs/twosided.cpp:12-36 through the XML loader."""
+    m = hostmirror.MeshSpec("tri", [((0, 0, 0), (1, 0, 0), (0, 1, 0))], (0.5, 0.5, 0.5))
+    xml = hostmirror.write_scene_xml([m, m], str(tmp_path), 16, 16, 1)
+    text = open(xml).read()
+    plain = '<bsdf type="diffuse">\n            <rgb name="reflectance" value="0.5, 0.5, 0.5"/>\n        </bsdf>'
+    rc = ('<bsdf type="roughconductor"><float name="alpha" value="0.25"/><string name="distribution" value="ggx"/>'
+          '<rgb name="eta" value="2.8656, 2.11918, 1.94008"/><rgb name="k" value="3.03233, 2.05611, 1.61629"/></bsdf>')
+    two = '<bsdf type="twosided">' + rc.replace('value="0.25"', 'value="0.1"') + '<bsdf type="diffuse"><rgb name="reflectance" value="0.2, 0.3, 0.4"/></bsdf></bsdf>'
+    text = text.replace(plain, rc, 1).replace(plain, two, 1)
+    (tmp_path / "rc.xml").write_text(text)
+    d = hostlib.HostScene(str(tmp_path / "rc.xml")).flatten().desc
+    assert d.n_bsdfs == 3                       # rough conductor | twosided back (diffuse) | twosided front
+    b0 = d.bsdfs[d.meshes[0].bsdf_id]
+    assert b0.type == abi.MSK_BSDF_ROUGHCONDUCTOR and b0.back_bsdf == -1 and b0.alpha_u == b0.alpha_v == np.float32(0.25)
+    assert np.isclose(b0.eta.scale, 2 * 2.8656) and np.isclose(b0.k.scale, 2 * 3.03233) and b0.specular_reflectance.scale == 1.0
+    assert np.isinf(b0.specular_reflectance.coeff[2])           # white -> S == 1
+    b1 = d.bsdfs[d.meshes[1].bsdf_id]
+    back = d.bsdfs[b1.back_bsdf]
+    assert b1.type == abi.MSK_BSDF_ROUGHCONDUCTOR and b1.alpha_u == np.float32(0.1) and back.type == abi.MSK_BSDF_DIFFUSE
+    for bad, needle in ((rc.replace("ggx", "beckmann"), "beckmann"), (rc.replace('<rgb name="k" value="3.03233, 2.05611, 1.61629"/>', ""), "eta"),
+                        ('<bsdf type="twosided"></bsdf>', "A nested one-sided material is required!")):
+        (tmp_path / "bad.xml").write_text(open(xml).read().replace(plain, bad, 1))
+        with pytest.raises(hostlib.HostError) as e:
+            hostlib.HostScene(str(tmp_path / "bad.xml"))
+        assert needle in str(e.value)
+
+
 def test_image_writers(hostlib, tmp_path):
     img = np.random.RandomState(0).rand(5, 7, 4).astype(np.float32)
     hostlib.write_image(tmp_path / "a.exr", img)
