@@ -48,6 +48,7 @@ extern "C" {
 /* ---- plugin type tags (the reference's registered plugin names) --------- */
 #define MSK_BSDF_DIFFUSE        0  /* "diffuse"        bsdfs/diffuse.cpp:73          */
 #define MSK_BSDF_ROUGHCONDUCTOR 1  /* "roughconductor" bsdfs/roughconductor.cpp:139 (GGX only) */
+#define MSK_BSDF_ROUGHDIELECTRIC 2 /* "roughdielectric" bsdfs/roughdielectric.cpp:209 (GGX only) */
 #define MSK_EMITTER_AREA       0   /* "area"     emitters/area.cpp:61          */
 
 /* RNG semantics (the reference's own seeding is not reproducible) */
@@ -90,6 +91,9 @@ typedef struct msk_spectrum_desc {
  * MSK_BSDF_ROUGHCONDUCTOR (bsdfs/roughconductor.cpp:12-50): GGX microfacet conductor; alpha_u/alpha_v,
  * sample_visible, and eta / k / specular_reflectance evaluated at the path's four wavelengths (the
  * reference's RGB-typed code does not compile in its spectral build; DESIGN.md §rough conductor).
+ * MSK_BSDF_ROUGHDIELECTRIC (bsdfs/roughdielectric.cpp:14-55): GGX microfacet dielectric with reflection and
+ * transmission lobes; ior_eta = int_ior / ext_ior, ior_inv_eta = ext_ior / int_ior, alpha_*, sample_visible,
+ * specular_reflectance / specular_transmittance.
  * back_bsdf implements the "twosided" adapter (bsdfs/twosided.cpp:38-101): the BSDF evaluated with
  * flipped wi/wo when cos(theta_i) < 0; the entry's own index for twosided(A), -1 for a one-sided BSDF.
  */
@@ -99,7 +103,9 @@ typedef struct msk_bsdf_desc {
     float   reflectance[3];
     float   alpha_u, alpha_v;
     int32_t sample_visible;
-    msk_spectrum_desc eta, k, specular_reflectance;
+    msk_spectrum_desc eta, k, specular_reflectance, specular_transmittance;
+    float   ior_eta, ior_inv_eta;
+    float   reserved[2];
 } msk_bsdf_desc;
 
 /*

@@ -13,7 +13,7 @@ import numpy as np
 MSK_ABI_VERSION = 2
 MSK_OK = 0
 MSK_ERR_INVALID_ARG, MSK_ERR_NO_DEVICE, MSK_ERR_HIP, MSK_ERR_OOM, MSK_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
-MSK_BSDF_DIFFUSE, MSK_BSDF_ROUGHCONDUCTOR = 0, 1
+MSK_BSDF_DIFFUSE, MSK_BSDF_ROUGHCONDUCTOR, MSK_BSDF_ROUGHDIELECTRIC = 0, 1, 2
 MSK_EMITTER_AREA = 0
 MSK_RNG_PCG_BLOCK, MSK_RNG_COUNTER = 0, 1
 MSK_CIE_SAMPLES = 95
@@ -34,7 +34,9 @@ class SpectrumDesc(C.Structure):
 class BsdfDesc(C.Structure):
     _fields_ = [("type", C.c_int32), ("back_bsdf", C.c_int32), ("reflectance", C.c_float * 3),
                 ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("sample_visible", C.c_int32),
-                ("eta", SpectrumDesc), ("k", SpectrumDesc), ("specular_reflectance", SpectrumDesc)]
+                ("eta", SpectrumDesc), ("k", SpectrumDesc), ("specular_reflectance", SpectrumDesc),
+                ("specular_transmittance", SpectrumDesc), ("ior_eta", C.c_float), ("ior_inv_eta", C.c_float),
+                ("reserved", C.c_float * 2)]
 
 
 class EmitterDesc(C.Structure):

@@ -332,6 +332,20 @@ MSK_DEV float smith_g1(f3 v, f3 m, float au, float av) {
     if (dot(v, m) * v.z <= 0.f) return 0.f;
     return 2.f / (1.f + __builtin_sqrtf(1.f + tan_theta_alpha_2));
 }
+// render/fresnel.h:37-63
+MSK_DEV void fresnel_dielectric(float cos_theta_i, float eta, float *F, float *cos_theta_t, float *eta_it, float *eta_ti) {
+    if (cos_theta_i >= 0.f) { *eta_it = eta; *eta_ti = 1.f / eta; } else { *eta_it = 1.f / eta; *eta_ti = eta; }
+    const float cos_theta_t_sqr = 1.f - *eta_ti * *eta_ti * (1.f - cos_theta_i * cos_theta_i);
+    const float cos_theta_i_abs = fabsf(cos_theta_i);
+    const float cos_theta_t_abs = safe_sqrt(cos_theta_t_sqr);
+    const float a_s = (cos_theta_i_abs - *eta_it * cos_theta_t_abs) / (cos_theta_i_abs + *eta_it * cos_theta_t_abs);
+    const float a_p = (cos_theta_t_abs - *eta_it * cos_theta_i_abs) / (cos_theta_t_abs + *eta_it * cos_theta_i_abs);
+    float r;
+    if (eta == 1.f || cos_theta_i_abs == 0.f) r = eta == 1.f ? 0.f : 1.f;
+    else r = 0.5f * (a_s * a_s + a_p * a_p);
+    *cos_theta_t = copysignf(cos_theta_t_abs, -cos_theta_i);
+    *F = r;
+}
 MSK_DEV float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
     float cos_theta_i_2 = cos_theta_i * cos_theta_i, sin_theta_i_2 = 1.f - cos_theta_i_2, sin_theta_i_4 = sin_theta_i_2 * sin_theta_i_2;
     float temp_1 = eta_r * eta_r - eta_i * eta_i - sin_theta_i_2;

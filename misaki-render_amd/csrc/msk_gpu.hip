@@ -201,19 +201,22 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     for (uint32_t g = 0; g < d->n_faces; ++g)
         if (!covered[g]) return fail(ctx, MSK_ERR_INVALID_ARG, "face %u belongs to no mesh", g);
 
-    static_assert(sizeof(msk_bsdf_desc) == 80, "msk_bsdf_desc is uploaded verbatim as 5 float4");
-    std::vector<float> bsdfs((size_t) std::max(1u, d->n_bsdfs) * 20, 0.f);
+    static_assert(sizeof(msk_bsdf_desc) == 16 * MSK_BSDF_F4, "msk_bsdf_desc is uploaded verbatim as MSK_BSDF_F4 float4");
+    std::vector<float> bsdfs((size_t) std::max(1u, d->n_bsdfs) * 4 * MSK_BSDF_F4, 0.f);
     bool all_diffuse = true;
     for (uint32_t b = 0; b < d->n_bsdfs; ++b) {
         const msk_bsdf_desc &bd = d->bsdfs[b];
-        if (bd.type != MSK_BSDF_DIFFUSE && bd.type != MSK_BSDF_ROUGHCONDUCTOR)
-            return fail(ctx, MSK_ERR_UNSUPPORTED, "bsdf %u: type %d is not supported by this back end (diffuse, roughconductor)", b, bd.type);
+        if (bd.type != MSK_BSDF_DIFFUSE && bd.type != MSK_BSDF_ROUGHCONDUCTOR && bd.type != MSK_BSDF_ROUGHDIELECTRIC)
+            return fail(ctx, MSK_ERR_UNSUPPORTED,
+                        "bsdf %u: type %d is not supported by this back end (diffuse, roughconductor, roughdielectric)", b, bd.type);
         if (bd.back_bsdf >= (int32_t) d->n_bsdfs || bd.back_bsdf < -1)
             return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: back_bsdf %d out of range", b, bd.back_bsdf);
-        if (bd.type == MSK_BSDF_ROUGHCONDUCTOR && !(bd.alpha_u >= 0.f && bd.alpha_v >= 0.f))
+        if (bd.type != MSK_BSDF_DIFFUSE && !(bd.alpha_u >= 0.f && bd.alpha_v >= 0.f))
             return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: negative roughness", b);
+        if (bd.type == MSK_BSDF_ROUGHDIELECTRIC && !(bd.ior_eta > 0.f && bd.ior_inv_eta > 0.f))
+            return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: the relative index of refraction must be positive", b);
         if (bd.type != MSK_BSDF_DIFFUSE || bd.back_bsdf >= 0) all_diffuse = false;
-        std::memcpy(&bsdfs[(size_t) b * 20], &bd, sizeof bd);
+        std::memcpy(&bsdfs[(size_t) b * 4 * MSK_BSDF_F4], &bd, sizeof bd);
     }
     std::vector<float> emitters((size_t) std::max(1u, d->n_emitters) * 8, 0.f), d65((size_t) std::max(1u, d->n_emitters) * 95, 0.f), cdf_all;
     for (uint32_t e = 0; e < d->n_emitters; ++e) {
@@ -270,7 +273,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     s->lds_scene = scene_bytes <= lds_cap && stack_bytes + scene_bytes <= 64 * 1024;
     s->trace_lds_bytes = stack_bytes + (s->lds_scene ? scene_bytes : 0);
     // LDS plan of k_shade_gen: the small lookup tables (tri_verts, mesh/bsdf/emitter records, cdf, d65, cie)
-    const size_t table_bytes = ((size_t) ds.n_tris * 3 + ds.n_meshes + ds.n_bsdfs * 5 + ds.n_emitters * 2 +
+    const size_t table_bytes = ((size_t) ds.n_tris * 3 + ds.n_meshes + ds.n_bsdfs * MSK_BSDF_F4 + ds.n_emitters * 2 +
                                 (ds.n_emitters * 95 + 3) / 4 + (ds.cdf_len + 3) / 4 + 72) * 16;
     s->lds_tables = table_bytes <= 40 * 1024;
     s->shade_lds_bytes = s->lds_tables ? table_bytes : 0;
@@ -322,19 +325,19 @@ static std::vector<HostBlock> spiral_blocks(int w, int h, int bs, int *nbx, int 
 // wavefront driver
 // ------------------------------------------------------------------------------------------
 struct StateBufs {
-    DevBuf id, wl, thr, res, ray_o, ray_d, sh, contrib, hit, bs_pdf, counts, ctrl;
+    DevBuf id, wl, thr, res, ray_o, ray_d, sh, contrib, hit, bs_pdf, eta, counts, ctrl;
     PathState st;
     hipError_t alloc(size_t n, uint32_t n_regions) {
         hipError_t e;
 #define A_(b, sz) if ((e = b.reserve(n * (sz))) != hipSuccess) return e;
         A_(id, 16) A_(wl, 16) A_(thr, 16) A_(res, 16) A_(ray_o, 16) A_(ray_d, 16) A_(sh, 16) A_(contrib, 16) A_(hit, 16)
-        A_(bs_pdf, 4)
+        A_(bs_pdf, 4) A_(eta, 4)
 #undef A_
         if ((e = counts.reserve((size_t) n_regions * sizeof(RegionCtl))) != hipSuccess) return e;
         if ((e = ctrl.reserve(sizeof(Ctrl))) != hipSuccess) return e;
         st.id = id.as<uint4>(); st.wl = wl.as<float4>(); st.thr = thr.as<float4>(); st.res = res.as<float4>();
         st.ray_o = ray_o.as<float4>(); st.ray_d = ray_d.as<float4>(); st.sh = sh.as<float4>();
-        st.contrib = contrib.as<float4>(); st.hit = hit.as<float4>(); st.bs_pdf = bs_pdf.as<float>();
+        st.contrib = contrib.as<float4>(); st.hit = hit.as<float4>(); st.bs_pdf = bs_pdf.as<float>(); st.eta = eta.as<float>();
         return hipSuccess;
     }
 };

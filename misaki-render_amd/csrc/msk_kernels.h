@@ -20,10 +20,12 @@
 // (imageblock.cpp:55-114, 133-173), so the film is bit-identical to the scalar CPU order.
 #pragma once
 #include "msk_device.h"
+#include "../../include/msk_gpu.h"
 
 namespace msk {
 
 #define MSK_WAVE 64
+#define MSK_BSDF_F4 7   /* sizeof(msk_bsdf_desc) / 16 */
 #define MSK_BLOCK 256
 #define MSK_LEAF_BIT 0x80000000u  /* child ref: leaf = BIT | first_tri << 5 | count ; inner = node index */
 #define MSK_NO_PRIM 0xffffffffu
@@ -62,6 +64,7 @@ struct PathState {
     float4 *contrib;    // NEE contribution added when the shadow ray is unoccluded
     float4 *hit;        // t,u,v,prim
     float *bs_pdf;
+    float *eta;
 };
 
 // Per-region bookkeeping, one record per wave-region, touched only by its owner wave: no atomics
@@ -295,7 +298,7 @@ struct SceneTables {
     const float *emitter_d65, *cdf, *cie;
 };
 MSK_DEV uint32_t tables_lds_float4s(const DeviceScene &sc) {
-    return sc.n_tris * 3 + sc.n_meshes + sc.n_bsdfs * 5 + sc.n_emitters * 2 + (sc.n_emitters * 95 + 3) / 4 + (sc.cdf_len + 3) / 4 + 72;
+    return sc.n_tris * 3 + sc.n_meshes + sc.n_bsdfs * MSK_BSDF_F4 + sc.n_emitters * 2 + (sc.n_emitters * 95 + 3) / 4 + (sc.cdf_len + 3) / 4 + 72;
 }
 template <bool LDS_TABLES>
 MSK_DEV SceneTables stage_tables(const DeviceScene &sc, float4 *lds) {
@@ -311,7 +314,7 @@ MSK_DEV SceneTables stage_tables(const DeviceScene &sc, float4 *lds) {
     auto copy1 = [&](const float *src, uint32_t n) { float *d = (float *) p; for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = src[i]; p += (n + 3) / 4; return d; };
     t.tri_verts = copy4(sc.tri_verts, sc.n_tris * 3);
     t.mesh_info = (const int4 *) copy4((const float4 *) sc.mesh_info, sc.n_meshes);
-    t.bsdfs = copy4(sc.bsdfs, sc.n_bsdfs * 5);
+    t.bsdfs = copy4(sc.bsdfs, sc.n_bsdfs * MSK_BSDF_F4);
     t.emitters = copy4(sc.emitters, sc.n_emitters * 2);
     t.emitter_d65 = copy1(sc.emitter_d65, sc.n_emitters * 95);
     t.cdf = copy1(sc.cdf, sc.cdf_len);
@@ -367,16 +370,81 @@ MSK_DEV spec emitter_radiance(const SceneTables &sc, int e, spec wl) {
 
 // ------------------------------------------------------------------------------------------
 // BSDF layer (bsdfs/diffuse.cpp:18-57, bsdfs/roughconductor.cpp:52-120, bsdfs/twosided.cpp:38-101).
-// A bsdf record is msk_bsdf_desc as 5 float4: {type, back, r0, r1} {r2, au, av, sample_visible} eta k spec.
+// A bsdf record is msk_bsdf_desc as 7 float4: {type, back, r0, r1} {r2, au, av, sample_visible} eta k spec trans
+// {ior_eta, ior_inv_eta, -, -}.
 // ------------------------------------------------------------------------------------------
-struct BsdfRec { float4 a, b, eta, k, spec; };
+struct BsdfRec { float4 a, b, eta, k, spec, trans, ior; };
 MSK_DEV BsdfRec load_bsdf(const SceneTables &tb, int id) {
-    BsdfRec r; const float4 *p = tb.bsdfs + (size_t) id * 5;
-    r.a = p[0]; r.b = p[1]; r.eta = p[2]; r.k = p[3]; r.spec = p[4];
+    BsdfRec r; const float4 *p = tb.bsdfs + (size_t) id * MSK_BSDF_F4;
+    r.a = p[0]; r.b = p[1]; r.eta = p[2]; r.k = p[3]; r.spec = p[4]; r.trans = p[5]; r.ior = p[6];
     return r;
 }
 MSK_DEV spec spectrum_eval(float4 s, spec wl) { return srgb_model_eval(s.x, s.y, s.z, wl) * s.w; }
 MSK_DEV float clamp_alpha(float a) { return fmax_std(a, 1e-4f); }
+
+// bsdfs/roughdielectric.cpp:118-190 eval + pdf (both lobes, TransportMode::Radiance)
+MSK_DEV void roughdielectric_eval_pdf(const BsdfRec &b, f3 wi, f3 wo, spec wl, spec *val, float *pdf) {
+    const float cos_i = wi.z, cos_o = wo.z;
+    if (cos_i == 0.f) return;
+    const float au = clamp_alpha(b.b.y), av = clamp_alpha(b.b.z);
+    const bool reflect = cos_i * cos_o > 0.f;
+    const float eta = cos_i > 0.f ? b.ior.x : b.ior.y, inv_eta = cos_i > 0.f ? b.ior.y : b.ior.x;
+    f3 m = normalized(wi + wo * (reflect ? 1.f : eta));
+    m = m * copysignf(1.f, m.z);
+    float F, ct, e_it, e_ti;
+    const float D = distr_eval(m, au, av);
+    fresnel_dielectric(dot(wi, m), b.ior.x, &F, &ct, &e_it, &e_ti);
+    const float G = smith_g1(wi, m, au, av) * smith_g1(wo, m, au, av);
+    if (reflect) {
+        *val = spectrum_eval(b.spec, wl) * (F * D * G) / (4.f * fabsf(cos_i));
+    } else {
+        const float scale = inv_eta * inv_eta;
+        const float denom = dot(wi, m) + eta * dot(wo, m);
+        *val = spectrum_eval(b.trans, wl) *
+               fabsf((scale * (1.f - F) * D * G * eta * eta * dot(wi, m) * dot(wo, m)) / (cos_i * (denom * denom)));
+    }
+    if (dot(wi, m) * wi.z <= 0.f || dot(wo, m) * wo.z <= 0.f) return;
+    const float denom = dot(wi, m) + eta * dot(wo, m);
+    const float dwh_dwo = reflect ? 1.f / (4.f * dot(wo, m)) : (eta * eta * dot(wo, m)) / (denom * denom);
+    float sau = au, sav = av;
+    if (!__float_as_int(b.b.w)) { const float sc = 1.2f - .2f * __builtin_sqrtf(fabsf(wi.z)); sau *= sc; sav *= sc; }
+    float prob = distr_eval(m, sau, sav) * m.z;
+    prob *= reflect ? F : 1.f - F;
+    *pdf = prob * fabsf(dwh_dwo);
+}
+// bsdfs/roughdielectric.cpp:57-116 sample; *eta_out = bs.eta
+MSK_DEV spec roughdielectric_sample(const BsdfRec &b, f3 wi, float sample1, f2 sample, spec wl, f3 *wo, float *pdf,
+                                    float *eta_out, bool *ok) {
+    const float cos_i = wi.z;
+    const float au = clamp_alpha(b.b.y), av = clamp_alpha(b.b.z);
+    float sau = au, sav = av;
+    if (!__float_as_int(b.b.w)) { const float sc = 1.2f - .2f * __builtin_sqrtf(fabsf(cos_i)); sau *= sc; sav *= sc; }
+    const f3 m = sample_ggx(sample, sau, sav, pdf);
+    if (*pdf == 0.f) return splat(0.f);
+    *ok = true;
+    float F, cos_t, eta_it, eta_ti;
+    fresnel_dielectric(dot(wi, m), b.ior.x, &F, &cos_t, &eta_it, &eta_ti);
+    const bool selected_r = sample1 <= F;
+    spec weight = splat(1.f);
+    *pdf *= selected_r ? F : (1.f - F);
+    const float bs_eta = selected_r ? 1.f : eta_it;
+    float dwh_dwo;
+    if (selected_r) {
+        *wo = m * 2.f * dot(wi, m) - wi;
+        weight = weight * spectrum_eval(b.spec, wl);
+        dwh_dwo = 1.f / (4.f * dot(*wo, m));
+    } else {
+        *wo = m * (dot(wi, m) * eta_ti + cos_t) - wi * eta_ti;
+        weight = weight * (eta_ti * eta_ti);
+        const float denom = dot(wi, m) + bs_eta * dot(*wo, m);
+        dwh_dwo = (bs_eta * bs_eta) * dot(*wo, m) / (denom * denom);
+    }
+    if (__float_as_int(b.b.w)) weight = weight * smith_g1(*wo, m, au, av);
+    else weight = weight * (smith_g1(wi, m, au, av) * smith_g1(*wo, m, au, av) * dot(wi, m) / (cos_i * m.z));
+    *pdf *= fabsf(dwh_dwo);
+    *eta_out = bs_eta;
+    return weight;
+}
 
 // eval + pdf with wi on the front side (roughconductor.cpp:82-117 / diffuse.cpp:35-57)
 template <bool DIFFUSE_ONLY>
@@ -390,6 +458,7 @@ MSK_DEV void bsdf_eval_pdf(const BsdfRec &b, f3 wi, f3 wo, spec wl, spec *val, f
         }
         return;
     }
+    if (__float_as_int(b.a.x) == MSK_BSDF_ROUGHDIELECTRIC) { roughdielectric_eval_pdf(b, wi, wo, wl, val, pdf); return; }
     const float au = clamp_alpha(b.b.y), av = clamp_alpha(b.b.z);
     if (cos_i > 0.f && cos_o > 0.f) {
         const f3 H = normalized(wo + wi);
@@ -413,8 +482,10 @@ MSK_DEV void bsdf_eval_pdf(const BsdfRec &b, f3 wi, f3 wo, spec wl, spec *val, f
 }
 // sample with wi on the front side; returns the weight, fills wo / pdf / ok (= a direction was produced)
 template <bool DIFFUSE_ONLY>
-MSK_DEV spec bsdf_sample(const BsdfRec &b, f3 wi, f2 sample, spec wl, f3 *wo, float *pdf, bool *ok) {
-    *wo = mk3(0.f, 0.f, 0.f); *pdf = 0.f; *ok = false;
+MSK_DEV spec bsdf_sample(const BsdfRec &b, f3 wi, float sample1, f2 sample, spec wl, f3 *wo, float *pdf, float *eta_out, bool *ok) {
+    *wo = mk3(0.f, 0.f, 0.f); *pdf = 0.f; *ok = false; *eta_out = 1.f;
+    if (!DIFFUSE_ONLY && __float_as_int(b.a.x) == MSK_BSDF_ROUGHDIELECTRIC)
+        return roughdielectric_sample(b, wi, sample1, sample, wl, wo, pdf, eta_out, ok);
     const float cos_i = wi.z;
     if (cos_i <= 0.f) return splat(0.f);
     *ok = true;
@@ -470,6 +541,8 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
             res = res + from4(st.contrib[i]);
         hit.w = __uint_as_float(__float_as_uint(hit.w) & MSK_PRIM_MASK);
         float bs_pdf = st.bs_pdf[i];
+        float eta = 1.f;                                                   // path.cpp:29, carried only when a BSDF can change it
+        if (!DIFFUSE_ONLY) eta = st.eta[i];
         uint32_t depth = id.w & MSK_DEPTH_MASK;
         const f3 rd = mk3(rd4.x, rd4.y, rd4.z);
         const uint32_t pix = id.z;
@@ -503,9 +576,9 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
                     if (n_em != 1) pdf = pdf * (1.f / n_em);
                     res = res + thr * value * mis_weight(bs_pdf, pdf);
                 }
-                // ---- Russian roulette (path.cpp:116-122); eta == 1 on this path
+                // ---- Russian roulette (path.cpp:116-122)
                 if ((int) depth >= pp.rr_depth) {
-                    const float q = fmin_std(max4(thr), 0.95f);
+                    const float q = fmin_std(DIFFUSE_ONLY ? max4(thr) : max4(thr) * eta * eta, 0.95f);
                     const float u = counter_pair(key, 3 + 3 * (depth - 2) + 1).y;
                     if (u >= q) alive = false;
                     else thr = thr / q;
@@ -586,14 +659,16 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
                 // ---- BSDF sampling (path.cpp:71-80)
                 {
                     const f2 u2 = counter_pair(key, pb + 2);
-                    f3 wo_l; bool ok;
-                    const spec bsdf_val = bsdf_sample<DIFFUSE_ONLY>(bs, wi_s, u2, wl, &wo_l, &bs_pdf, &ok);
+                    f3 wo_l; bool ok; float bs_eta;
+                    const float sample1 = DIFFUSE_ONLY ? 0.f : counter_pair(key, pb + 1).x;
+                    const spec bsdf_val = bsdf_sample<DIFFUSE_ONLY>(bs, wi_s, sample1, u2, wl, &wo_l, &bs_pdf, &bs_eta, &ok);
                     if (!ok) {
                         alive = false;         // failed sample: zero direction, the reference's ray misses (no NEE either)
                     } else {
                         if (flipped) wo_l.z = -wo_l.z;
                         const f3 wo = si.sh.to_world(wo_l);
                         thr = thr * bsdf_val;                              // path.cpp:99
+                        eta *= bs_eta;                                     // path.cpp:100
                         // A path whose throughput is now zero can only add zeros from here on; it lives one more
                         // iteration iff a shadow ray is pending (tmax < 0: the extension ray finds nothing).
                         const bool dead = !any_nonzero(thr);
@@ -632,6 +707,7 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
             st.wl[o] = to4(wl); st.thr[o] = to4(thr); st.res[o] = to4(res);
             st.ray_o[o] = new_o; st.ray_d[o] = new_d; st.sh[o] = new_sh; st.contrib[o] = to4(contrib);
             st.bs_pdf[o] = bs_pdf;
+            if (!DIFFUSE_ONLY) st.eta[o] = eta;
         }
         cursor += __popcll(m);
     }
@@ -676,6 +752,7 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
         st.ray_d[o] = make_float4(dw.x, dw.y, dw.z, sc.far_clip * inv_z);
         st.sh[o] = make_float4(0, 0, 0, 0); st.contrib[o] = make_float4(0, 0, 0, 0);
         st.bs_pdf[o] = 0.f;
+        if (!DIFFUSE_ONLY) st.eta[o] = 1.f;
     }
     if (lane == 0) {
         const uint32_t n_out = cursor + got;

@@ -4,6 +4,7 @@
 #include <misaki/render.h>
 
 #include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <cstring>
 #include <fstream>
@@ -337,7 +338,8 @@ static void init_bsdf_desc(msk_bsdf_desc &out) {
     std::memset(&out, 0, sizeof out);
     out.back_bsdf = -1;
     const msk_spectrum_desc one{{0.f, 0.f, INFINITY}, 1.f};
-    out.eta = out.k = out.specular_reflectance = one;
+    out.eta = out.k = out.specular_reflectance = out.specular_transmittance = one;
+    out.ior_eta = out.ior_inv_eta = 1.f;
 }
 
 // =========================================================================== bsdf, emitter, sensor, shape
@@ -412,6 +414,51 @@ private:
 };
 MSK_IMPLEMENT_CLASS(RoughConductor, BSDF)
 MSK_REGISTER_INSTANCE(RoughConductor, "roughconductor")
+
+// bsdfs/roughdielectric.cpp:12-55.  The reference defaults to the Beckmann distribution here, whose branches are
+// empty in render/microfacet.h:115-118,135-137; only "ggx" renders there, and only "ggx" is accepted here.
+class RoughDielectric final : public BSDF {
+public:
+    RoughDielectric(const Properties &props) : BSDF(props) {
+        m_specular_reflectance = props.texture("specular_reflectance", 1.f);
+        m_specular_transmittance = props.texture("specular_transmittance", 1.f);
+        const float int_ior = props.float_("int_ior", 1.5046f), ext_ior = props.float_("ext_ior", 1.00028f);
+        if (int_ior < 0.f || ext_ior < 0.f || int_ior == ext_ior)
+            Throw("The interior and exterior indices of refraction must be positive and differ!");
+        m_eta = int_ior / ext_ior; m_inv_eta = ext_ior / int_ior;
+        std::string distr = props.string("distribution", "beckmann");
+        for (auto &c : distr) c = (char) std::tolower((unsigned char) c);
+        if (distr == "beckmann") Throw("roughdielectric: the \"beckmann\" distribution is not implemented (use \"ggx\")");
+        if (distr != "ggx") Throw("Specified an invalid distribution \"{}\", must be \"beckmann\" or \"ggx\"!", distr);
+        m_sample_visible = props.bool_("sample_visible", false);
+        if (props.has_property("alpha_u") || props.has_property("alpha_v")) {
+            if (!props.has_property("alpha_u") || !props.has_property("alpha_v"))
+                Throw("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.");
+            if (props.has_property("alpha")) Throw("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.");
+            m_alpha_u = props.float_("alpha_u"); m_alpha_v = props.float_("alpha_v");
+        } else {
+            m_alpha_u = m_alpha_v = props.float_("alpha", 0.1f);
+        }
+    }
+    bool flatten(msk_bsdf_desc &out) const override {
+        Texture::Flat r, t;
+        if (!m_specular_reflectance->flatten(r) || !m_specular_transmittance->flatten(t) || r.uses_d65 || t.uses_d65) return false;
+        init_bsdf_desc(out);
+        out.type = MSK_BSDF_ROUGHDIELECTRIC;
+        out.alpha_u = m_alpha_u; out.alpha_v = m_alpha_v; out.sample_visible = m_sample_visible ? 1 : 0;
+        out.ior_eta = m_eta; out.ior_inv_eta = m_inv_eta;
+        auto put = [](msk_spectrum_desc &d, const Texture::Flat &f) { std::memcpy(d.coeff, f.coeff, sizeof f.coeff); d.scale = f.scale; };
+        put(out.specular_reflectance, r); put(out.specular_transmittance, t);
+        return true;
+    }
+    MSK_DECLARE_CLASS()
+private:
+    ref<Texture> m_specular_reflectance, m_specular_transmittance;
+    float m_eta, m_inv_eta, m_alpha_u, m_alpha_v;
+    bool m_sample_visible;
+};
+MSK_IMPLEMENT_CLASS(RoughDielectric, BSDF)
+MSK_REGISTER_INSTANCE(RoughDielectric, "roughdielectric")
 
 // bsdfs/twosided.cpp:12-36
 class TwoSidedBRDF final : public BSDF {

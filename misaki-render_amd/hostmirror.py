@@ -125,6 +125,34 @@ def write_obj(mesh, path):
             n += len(f)
 
 
+def _bsdf_xml(m, v3):
+    """The <bsdf> element of one shape (reference plugin parameter names)."""
+    spec = m.bsdf
+    if spec is None:
+        return ['        <bsdf type="diffuse">', '            <rgb name="reflectance" value="%s"/>' % v3(m.reflectance), '        </bsdf>']
+    body = []
+    a = spec.get("alpha", 0.1)
+    if np.isscalar(a):
+        body.append('<float name="alpha" value="%r"/>' % float(a))
+    else:
+        body += ['<float name="alpha_u" value="%r"/>' % float(a[0]), '<float name="alpha_v" value="%r"/>' % float(a[1])]
+    body.append('<string name="distribution" value="ggx"/>')
+    if spec.get("sample_visible"):
+        body.append('<boolean name="sample_visible" value="true"/>')
+    keys = {"roughconductor": ("eta", "k", "specular_reflectance"),
+            "roughdielectric": ("specular_reflectance", "specular_transmittance")}[spec["type"]]
+    for k in keys:
+        if k in spec:
+            body.append('<rgb name="%s" value="%s"/>' % (k, v3(spec[k])))
+    for k in ("int_ior", "ext_ior"):
+        if k in spec:
+            body.append('<float name="%s" value="%r"/>' % (k, float(spec[k])))
+    inner = ['<bsdf type="%s">' % spec["type"]] + ['    ' + b for b in body] + ['</bsdf>']
+    if spec.get("twosided"):
+        inner = ['<bsdf type="twosided">'] + ['    ' + b for b in inner] + ['</bsdf>']
+    return ['        ' + b for b in inner]
+
+
 def write_scene_xml(meshes, directory, width, height, spp, camera=None, integrator_props=None, film_type="hdrfilm",
                     filename="scene.xml"):
     """Writes <directory>/meshes/*.obj and a Mitsuba-style scene XML the C++ host (and the reference's
@@ -150,7 +178,7 @@ def write_scene_xml(meshes, directory, width, height, spp, camera=None, integrat
         if any(float(t) != 0 for t in m.translate):
             out += ['        <transform name="to_world">', '            <translate x="%.9g" y="%.9g" z="%.9g"/>' % tuple(m.translate),
                     '        </transform>']
-        out += ['        <bsdf type="diffuse">', '            <rgb name="reflectance" value="%s"/>' % v3(m.reflectance), '        </bsdf>']
+        out += _bsdf_xml(m, v3)
         if m.radiance is not None:
             out += ['        <emitter type="area">', '            <rgb name="radiance" value="%s"/>' % v3(m.radiance), '        </emitter>']
         out.append('    </shape>')
@@ -243,7 +271,8 @@ def _bsdf_desc(m, fetch, index):
     b = abi.BsdfDesc()
     b.back_bsdf = -1
     one = abi.SpectrumDesc((C.c_float * 3)(0.0, 0.0, float("inf")), 1.0)
-    b.eta, b.k, b.specular_reflectance = one, one, one
+    b.eta, b.k, b.specular_reflectance, b.specular_transmittance = one, one, one, one
+    b.ior_eta = b.ior_inv_eta = 1.0
     spec = m.bsdf or {"type": "diffuse"}
     if spec["type"] == "diffuse":
         b.type = abi.MSK_BSDF_DIFFUSE
@@ -255,6 +284,16 @@ def _bsdf_desc(m, fetch, index):
         b.sample_visible = int(bool(spec.get("sample_visible", False)))
         b.eta, b.k = spectrum_desc(spec["eta"], fetch), spectrum_desc(spec["k"], fetch)
         b.specular_reflectance = spectrum_desc(spec.get("specular_reflectance", (1.0, 1.0, 1.0)), fetch)
+    elif spec["type"] == "roughdielectric":
+        # bsdfs/roughdielectric.cpp:14-24: m_eta = int_ior / ext_ior in fp32
+        b.type = abi.MSK_BSDF_ROUGHDIELECTRIC
+        a = spec.get("alpha", 0.1)
+        b.alpha_u, b.alpha_v = (a, a) if np.isscalar(a) else a
+        b.sample_visible = int(bool(spec.get("sample_visible", False)))
+        int_ior, ext_ior = np.float32(spec.get("int_ior", 1.5046)), np.float32(spec.get("ext_ior", 1.00028))
+        b.ior_eta, b.ior_inv_eta = float(int_ior / ext_ior), float(ext_ior / int_ior)
+        b.specular_reflectance = spectrum_desc(spec.get("specular_reflectance", (1.0, 1.0, 1.0)), fetch)
+        b.specular_transmittance = spectrum_desc(spec.get("specular_transmittance", (1.0, 1.0, 1.0)), fetch)
     else:
         raise ValueError(spec["type"])
     if spec.get("twosided"):

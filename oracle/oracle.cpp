@@ -562,7 +562,7 @@ static float mis_weight(float pdf_a, float pdf_b) {
 // spectra evaluated at the path's four wavelengths (value = scale * S(coeff, l)).
 // ===========================================================================
 struct BSDFSampleRec { V3 wo; float pdf, eta; uint32_t sampled_type; };   // render/bsdf.h:60-80
-enum : uint32_t { kDiffuseReflection = 1u, kGlossyReflection = 2u };
+enum : uint32_t { kDiffuseReflection = 1u, kGlossyReflection = 2u, kGlossyTransmission = 4u };
 
 static S4 spectrum_eval(const msk_spectrum_desc &sp, S4 wl) { return srgb_model_eval(sp.coeff, wl) * sp.scale; }
 
@@ -618,6 +618,85 @@ static S4 fresnel_conductor4(float c, S4 eta, S4 k) {
     S4 r; for (int i = 0; i < 4; ++i) r.v[i] = fresnel_conductor(c, eta.v[i], k.v[i]); return r;
 }
 static float clamp_alpha(float a) { return std::max(a, 1e-4f); }   // MicrofacetDistribution::configure
+// render/fresnel.h:37-63 fresnel(): F, cos_theta_t, eta_it, eta_ti
+static void fresnel_dielectric(float cos_theta_i, float eta, float *F, float *cos_theta_t, float *eta_it, float *eta_ti) {
+    if (cos_theta_i >= 0.f) { *eta_it = eta; *eta_ti = 1.f / eta; } else { *eta_it = 1.f / eta; *eta_ti = eta; }
+    float cos_theta_t_sqr = 1.f - *eta_ti * *eta_ti * (1.f - cos_theta_i * cos_theta_i);
+    float cos_theta_i_abs = std::fabs(cos_theta_i);
+    float cos_theta_t_abs = safe_sqrt(cos_theta_t_sqr);
+    float a_s = (cos_theta_i_abs - *eta_it * cos_theta_t_abs) / (cos_theta_i_abs + *eta_it * cos_theta_t_abs);
+    float a_p = (cos_theta_t_abs - *eta_it * cos_theta_i_abs) / (cos_theta_t_abs + *eta_it * cos_theta_i_abs);
+    float r;
+    if (eta == 1.f || cos_theta_i_abs == 0.f) r = eta == 1.f ? 0.f : 1.f;
+    else r = 0.5f * (a_s * a_s + a_p * a_p);
+    *cos_theta_t = cos_theta_t_abs * std::copysign(1.f, -cos_theta_i);
+    *F = r;
+}
+// bsdfs/roughdielectric.cpp:118-190 eval + pdf (both lobes enabled, TransportMode::Radiance)
+static void roughdielectric_eval_pdf(const msk_bsdf_desc &b, V3 wi, V3 wo, S4 wl, S4 *val, float *pdf) {
+    *val = s4(0.f); *pdf = 0.f;
+    const float cos_i = wi.z, cos_o = wo.z;
+    if (cos_i == 0.f) return;
+    const float au = clamp_alpha(b.alpha_u), av = clamp_alpha(b.alpha_v);
+    const bool reflect = cos_i * cos_o > 0.f;
+    const float eta = cos_i > 0.f ? b.ior_eta : b.ior_inv_eta, inv_eta = cos_i > 0.f ? b.ior_inv_eta : b.ior_eta;
+    V3 m = normalized(wi + wo * (reflect ? 1.f : eta));
+    m = m * std::copysign(1.f, m.z);
+    float F, ct, e_it, e_ti;
+    {   // eval
+        float D = distr_eval(m, au, av);
+        fresnel_dielectric(dot(wi, m), b.ior_eta, &F, &ct, &e_it, &e_ti);
+        float G = smith_g1(wi, m, au, av) * smith_g1(wo, m, au, av);
+        if (reflect) {
+            *val = spectrum_eval(b.specular_reflectance, wl) * (F * D * G) / (4.f * std::fabs(cos_i));
+        } else {
+            float scale = inv_eta * inv_eta;
+            float denom = dot(wi, m) + eta * dot(wo, m);
+            *val = spectrum_eval(b.specular_transmittance, wl) *
+                   std::fabs((scale * (1.f - F) * D * G * eta * eta * dot(wi, m) * dot(wo, m)) / (cos_i * (denom * denom)));
+        }
+    }
+    // pdf
+    if (dot(wi, m) * wi.z <= 0.f || dot(wo, m) * wo.z <= 0.f) return;
+    float denom = dot(wi, m) + eta * dot(wo, m);
+    float dwh_dwo = reflect ? 1.f / (4.f * dot(wo, m)) : (eta * eta * dot(wo, m)) / (denom * denom);
+    float sau = au, sav = av;
+    if (!b.sample_visible) { float sc = 1.2f - .2f * std::sqrt(std::fabs(wi.z)); sau *= sc; sav *= sc; }
+    float prob = distr_eval(m, sau, sav) * m.z;
+    prob *= reflect ? F : 1.f - F;
+    *pdf = prob * std::fabs(dwh_dwo);
+}
+// bsdfs/roughdielectric.cpp:57-116 sample (both lobes enabled)
+static S4 roughdielectric_sample(const msk_bsdf_desc &b, V3 wi, float sample1, V2 sample, S4 wl, BSDFSampleRec *bs) {
+    const float cos_i = wi.z;
+    const float au = clamp_alpha(b.alpha_u), av = clamp_alpha(b.alpha_v);
+    float sau = au, sav = av;
+    if (!b.sample_visible) { float sc = 1.2f - .2f * std::sqrt(std::fabs(cos_i)); sau *= sc; sav *= sc; }
+    V3 m = sample_ggx(sample, sau, sav, &bs->pdf);
+    if (bs->pdf == 0) return s4(0.f);
+    float F, cos_t, eta_it, eta_ti;
+    fresnel_dielectric(dot(wi, m), b.ior_eta, &F, &cos_t, &eta_it, &eta_ti);
+    const bool selected_r = sample1 <= F;
+    S4 weight = s4(1.f);
+    bs->pdf *= selected_r ? F : (1.f - F);
+    bs->eta = selected_r ? 1.f : eta_it;
+    bs->sampled_type = selected_r ? kGlossyReflection : kGlossyTransmission;
+    float dwh_dwo;
+    if (selected_r) {
+        bs->wo = m * 2.f * dot(wi, m) - wi;                               // fresnel.h:17-21
+        weight = weight * spectrum_eval(b.specular_reflectance, wl);
+        dwh_dwo = 1.f / (4.f * dot(bs->wo, m));
+    } else {
+        bs->wo = m * (dot(wi, m) * eta_ti + cos_t) - wi * eta_ti;          // fresnel.h:30-35 refract(wi, m, cos_t, eta_ti)
+        weight = weight * (eta_ti * eta_ti);
+        float denom = dot(wi, m) + bs->eta * dot(bs->wo, m);
+        dwh_dwo = (bs->eta * bs->eta) * dot(bs->wo, m) / (denom * denom);
+    }
+    if (b.sample_visible) weight = weight * smith_g1(bs->wo, m, au, av);
+    else weight = weight * (smith_g1(wi, m, au, av) * smith_g1(bs->wo, m, au, av) * dot(wi, m) / (cos_i * m.z));
+    bs->pdf *= std::fabs(dwh_dwo);
+    return weight;
+}
 
 // one-sided evaluation (wi already on the front side for twosided)
 static void bsdf_eval_pdf(const msk_bsdf_desc &b, V3 wi, V3 wo, S4 wl, S4 *val, float *pdf) {
@@ -630,6 +709,7 @@ static void bsdf_eval_pdf(const msk_bsdf_desc &b, V3 wi, V3 wo, S4 wl, S4 *val, 
         }
         return;
     }
+    if (b.type == MSK_BSDF_ROUGHDIELECTRIC) { roughdielectric_eval_pdf(b, wi, wo, wl, val, pdf); return; }
     const float au = clamp_alpha(b.alpha_u), av = clamp_alpha(b.alpha_v);
     // roughconductor.cpp:82-98 eval
     if (cos_i > 0.f && cos_o > 0.f) {
@@ -650,8 +730,8 @@ static void bsdf_eval_pdf(const msk_bsdf_desc &b, V3 wi, V3 wo, S4 wl, S4 *val, 
     }
 }
 static S4 bsdf_sample(const msk_bsdf_desc &b, V3 wi, float sample1, V2 sample, S4 wl, BSDFSampleRec *bs) {
-    (void) sample1;
     bs->wo = mk3(0, 0, 0); bs->pdf = 0.f; bs->eta = 1.f; bs->sampled_type = 0;       // render/bsdf.h:75-77
+    if (b.type == MSK_BSDF_ROUGHDIELECTRIC) return roughdielectric_sample(b, wi, sample1, sample, wl, bs);
     float cos_i = wi.z;
     if (cos_i <= 0.f) return s4(0.f);
     if (b.type == MSK_BSDF_DIFFUSE) {                                  // diffuse.cpp:18-33
@@ -1037,6 +1117,18 @@ void msk_oracle_bsdf_sample(const msk_bsdf_desc *bsdfs, int n, int id, const flo
     BSDFSampleRec bs; S4 w = bsdf_sample(*b, wi, 0.f, V2{u2[0], u2[1]}, wl, &bs);
     if (flipped) bs.wo.z *= -1.f;
     wo3[0] = bs.wo.x; wo3[1] = bs.wo.y; wo3[2] = bs.wo.z; *pdf = bs.pdf;
+    for (int i = 0; i < 4; ++i) weight4[i] = w.v[i];
+}
+// as above with the lobe-selection sample, returning BSDFSample::eta and sampled_type too
+void msk_oracle_bsdf_sample2(const msk_bsdf_desc *bsdfs, int n, int id, const float *wi3, float sample1, const float *u2,
+                             const float *wl4, float *wo3, float *pdf, float *weight4, float *eta, uint32_t *sampled_type) {
+    Scene sc; sc.bsdfs.assign(bsdfs, bsdfs + n);
+    V3 wi = mk3(wi3[0], wi3[1], wi3[2]);
+    S4 wl; for (int i = 0; i < 4; ++i) wl.v[i] = wl4[i];
+    bool flipped; const msk_bsdf_desc *b = bsdf_side(sc, sc.bsdfs[id], &wi, &flipped);
+    BSDFSampleRec bs; S4 w = bsdf_sample(*b, wi, sample1, V2{u2[0], u2[1]}, wl, &bs);
+    if (flipped) bs.wo.z *= -1.f;
+    wo3[0] = bs.wo.x; wo3[1] = bs.wo.y; wo3[2] = bs.wo.z; *pdf = bs.pdf; *eta = bs.eta; *sampled_type = bs.sampled_type;
     for (int i = 0; i < 4; ++i) weight4[i] = w.v[i];
 }
 // filters/gaussian.cpp:10-20 + rfilter.cpp:12-27 (host side of the reference; libm expf)

@@ -43,6 +43,7 @@ class Oracle:
         lib.msk_oracle_det_math2.argtypes = [C.c_float, vp]
         lib.msk_oracle_bsdf_eval.argtypes = [C.POINTER(abi.BsdfDesc), C.c_int, C.c_int, vp, vp, vp, vp, vp]
         lib.msk_oracle_bsdf_sample.argtypes = [C.POINTER(abi.BsdfDesc), C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+        lib.msk_oracle_bsdf_sample2.argtypes = [C.POINTER(abi.BsdfDesc), C.c_int, C.c_int, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp]
 
     # ---- scene-level
     def scene(self, flat):
@@ -111,6 +112,15 @@ class Oracle:
         wo, pdf, w = np.zeros(3, np.float32), C.c_float(), np.zeros(4, np.float32)
         self.lib.msk_oracle_bsdf_sample(arr, len(bsdfs), idx, _p(wi), _p(u), _p(wl), _p(wo), C.byref(pdf), _p(w))
         return wo, pdf.value, w
+
+    def bsdf_sample2(self, bsdfs, idx, wi, sample1, u, wl=(450, 520, 600, 680)):
+        """-> wo, pdf, weight, eta, sampled_type (with the lobe-selection sample of BSDF::sample)"""
+        arr = (self.abi.BsdfDesc * len(bsdfs))(*bsdfs)
+        wi, u, wl = (np.asarray(v, np.float32) for v in (wi, u, wl))
+        wo, pdf, w, eta, typ = np.zeros(3, np.float32), C.c_float(), np.zeros(4, np.float32), C.c_float(), C.c_uint32()
+        self.lib.msk_oracle_bsdf_sample2(arr, len(bsdfs), idx, _p(wi), C.c_float(sample1), _p(u), _p(wl), _p(wo), C.byref(pdf), _p(w),
+                                         C.byref(eta), C.byref(typ))
+        return wo, pdf.value, w, eta.value, typ.value
 
     def set_libm(self, on):
         self.lib.msk_oracle_set_libm(int(on))
