@@ -50,6 +50,7 @@ extern "C" {
 #define MSK_BSDF_ROUGHCONDUCTOR 1  /* "roughconductor" bsdfs/roughconductor.cpp:139 (GGX only) */
 #define MSK_BSDF_ROUGHDIELECTRIC 2 /* "roughdielectric" bsdfs/roughdielectric.cpp:209 (GGX only) */
 #define MSK_EMITTER_AREA       0   /* "area"     emitters/area.cpp:61          */
+#define MSK_EMITTER_CONSTANT   1   /* "constant" emitters/constant.cpp:95 (environment; mesh_id = -1, at most one) */
 
 /* RNG semantics (the reference's own seeding is not reproducible) */
 #define MSK_RNG_PCG_BLOCK      0   /* one PCG32 stream per 32x32 block; CPU oracle only */
@@ -112,6 +113,9 @@ typedef struct msk_bsdf_desc {
  * Area emitter (emitters/area.cpp) with an `srgb_d65` radiance
  * (spectra/srgb_d65.cpp:13-36): radiance(l) = d65(l) * d65_scale * S(coeff, l),
  * d65_scale = scale * 2*max(rgb) / 10568 (srgb_d65.cpp:18-26, d65.cpp:33-34).
+ * The constant environment emitter (emitters/constant.cpp) uses the same radiance form (its default is
+ * Texture::D65(1): coefficients {0, 0, +inf}); it has no mesh (mesh_id = -1), and its place in `emitters`
+ * is its place in Scene::m_emitters (scene.cpp:27-41: XML order, shapes' area lights and top-level emitters mixed).
  */
 typedef struct msk_emitter_desc {
     int32_t type;

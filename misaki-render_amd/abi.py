@@ -14,6 +14,7 @@ MSK_ABI_VERSION = 2
 MSK_OK = 0
 MSK_ERR_INVALID_ARG, MSK_ERR_NO_DEVICE, MSK_ERR_HIP, MSK_ERR_OOM, MSK_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 MSK_BSDF_DIFFUSE, MSK_BSDF_ROUGHCONDUCTOR, MSK_BSDF_ROUGHDIELECTRIC = 0, 1, 2
+MSK_EMITTER_AREA, MSK_EMITTER_CONSTANT = 0, 1
 MSK_EMITTER_AREA = 0
 MSK_RNG_PCG_BLOCK, MSK_RNG_COUNTER = 0, 1
 MSK_CIE_SAMPLES = 95

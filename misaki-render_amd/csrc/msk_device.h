@@ -52,6 +52,7 @@ MSK_DEV bool any_nonzero(spec a) { return a.v[0] != 0.f || a.v[1] != 0.f || a.v[
 
 // core/mathutils.h:10-20
 #define MSK_PI_F        3.14159274101257324f      /* float(3.14159265358979323846) */
+#define MSK_INV_FOUR_PI_F 0.0795774683356285095f   /* float(0.07957747154594766788) */
 #define MSK_INV_PI_F    0.318309873342514038f     /* float(0.31830988618379067154) */
 #define MSK_EPSILON_F   5.9604644775390625e-08f
 #define MSK_RAY_EPS_F   (MSK_EPSILON_F * 1500)
@@ -220,6 +221,12 @@ MSK_DEV float safe_sqrt(float a) { return __builtin_sqrtf(fmax_std(a, 0.f)); }
 MSK_DEV f2 square_to_uniform_triangle(f2 sample) {          // core/warp.h:11-15
     float t = safe_sqrt(1.f - sample.x);
     f2 r; r.x = 1.f - t; r.y = t * sample.y; return r;
+}
+MSK_DEV f3 square_to_uniform_sphere(f2 sample) {            // core/warp.h:7-9,46-53
+    const float z = -2.f * sample.y + 1.f, r = safe_sqrt(-z * z + 1.f);
+    const float t = (2.f * MSK_PI_F) * sample.x;
+    float sn, cs; det_sincos(t, &sn, &cs);
+    return mk3(r * cs, r * sn, z);
 }
 MSK_DEV f2 square_to_uniform_disk_concentric(f2 sample) {   // core/warp.h:17-32
     float x = 2.f * sample.x - 1.f;

@@ -219,19 +219,30 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         std::memcpy(&bsdfs[(size_t) b * 4 * MSK_BSDF_F4], &bd, sizeof bd);
     }
     std::vector<float> emitters((size_t) std::max(1u, d->n_emitters) * 8, 0.f), d65((size_t) std::max(1u, d->n_emitters) * 95, 0.f), cdf_all;
+    int env_emitter = -1;
     for (uint32_t e = 0; e < d->n_emitters; ++e) {
         const msk_emitter_desc &ed = d->emitters[e];
-        if (ed.type != MSK_EMITTER_AREA) return fail(ctx, MSK_ERR_UNSUPPORTED, "emitter %u: type %d is not supported", e, ed.type);
-        if (ed.mesh_id < 0 || (uint32_t) ed.mesh_id >= d->n_meshes || d->meshes[ed.mesh_id].emitter_id != (int32_t) e)
-            return fail(ctx, MSK_ERR_INVALID_ARG, "emitter %u: mesh_id %d does not point back at it", e, ed.mesh_id);
-        const msk_mesh_desc &md = d->meshes[ed.mesh_id];
-        if (md.face_count == 0) return fail(ctx, MSK_ERR_INVALID_ARG, "emitter %u: its mesh has no faces", e);
         float *o = &emitters[e * 8];
         o[0] = ed.radiance[0]; o[1] = ed.radiance[1]; o[2] = ed.radiance[2];
-        o[3] = 1.f / mesh_area[ed.mesh_id];                               // mesh.cpp:129 ps.pdf
-        uint32_t meta[4] = {(uint32_t) ed.mesh_id, md.first_face, md.face_count, (uint32_t) cdf_all.size()};
-        std::memcpy(&o[4], meta, 16);
-        cdf_all.insert(cdf_all.end(), mesh_cdf[ed.mesh_id].begin(), mesh_cdf[ed.mesh_id].end());
+        if (ed.type == MSK_EMITTER_CONSTANT) {
+            if (env_emitter >= 0) return fail(ctx, MSK_ERR_INVALID_ARG, "Can only have one environment light");   // scene.cpp:38-39
+            if (ed.mesh_id != -1) return fail(ctx, MSK_ERR_INVALID_ARG, "emitter %u: an environment emitter has no mesh (mesh_id must be -1)", e);
+            env_emitter = (int) e;
+            o[3] = 0.f;
+            const uint32_t meta[4] = {0xffffffffu, 0u, 0u, 0u};
+            std::memcpy(&o[4], meta, 16);
+        } else if (ed.type == MSK_EMITTER_AREA) {
+            if (ed.mesh_id < 0 || (uint32_t) ed.mesh_id >= d->n_meshes || d->meshes[ed.mesh_id].emitter_id != (int32_t) e)
+                return fail(ctx, MSK_ERR_INVALID_ARG, "emitter %u: mesh_id %d does not point back at it", e, ed.mesh_id);
+            const msk_mesh_desc &md = d->meshes[ed.mesh_id];
+            if (md.face_count == 0) return fail(ctx, MSK_ERR_INVALID_ARG, "emitter %u: its mesh has no faces", e);
+            o[3] = 1.f / mesh_area[ed.mesh_id];                               // mesh.cpp:129 ps.pdf
+            uint32_t meta[4] = {(uint32_t) ed.mesh_id, md.first_face, md.face_count, (uint32_t) cdf_all.size()};
+            std::memcpy(&o[4], meta, 16);
+            cdf_all.insert(cdf_all.end(), mesh_cdf[ed.mesh_id].begin(), mesh_cdf[ed.mesh_id].end());
+        } else {
+            return fail(ctx, MSK_ERR_UNSUPPORTED, "emitter %u: type %d is not supported (area, constant)", e, ed.type);
+        }
         for (int i = 0; i < 95; ++i) d65[e * 95 + i] = d->d65[i] * ed.d65_scale;   // d65.cpp:41-42
     }
     if (cdf_all.empty()) cdf_all.push_back(0.f);
@@ -266,6 +277,18 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     ds.filter_scale = float(MSK_FILTER_RESOLUTION) / d->film.filter_radius;           // rfilter.cpp:21
     ds.filter_border = (int) std::ceil(d->film.filter_radius - .5f);                  // rfilter.cpp:22
     std::memcpy(ds.lut, d->film.filter_lut, sizeof ds.lut);
+    // constant.cpp:21-28 set_scene: the sphere around Scene::bbox() (bbox.h:105-112), in fp32 exactly as the oracle does
+    ds.env_emitter = env_emitter; ds.env_radius = 0.f;
+    if (env_emitter >= 0) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t v = 0; v < d->n_vertices; ++v)
+            for (int k = 0; k < 3; ++k) { const float q = d->vertices[(size_t) v * 8 + k]; lo[k] = std::min(lo[k], q); hi[k] = std::max(hi[k], q); }
+        float r[3];
+        for (int k = 0; k < 3; ++k) { const float c = (lo[k] + hi[k]) * .5f; r[k] = c - hi[k]; }
+        const float radius = std::sqrt(r[0] * r[0] + (r[1] * r[1] + r[2] * r[2]));
+        ds.env_radius = std::max(MSK_RAY_EPS_F, radius * (1.f + MSK_RAY_EPS_F));
+        s->all_diffuse = false;             // the environment terms live in the general shading variant
+    }
     // LDS plan of k_trace: per-lane stack + (when it fits) the whole BVH
     const size_t stack_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4;
     const size_t scene_bytes = ((size_t) ds.n_nodes + ds.n_tris) * 64;
@@ -325,19 +348,19 @@ static std::vector<HostBlock> spiral_blocks(int w, int h, int bs, int *nbx, int 
 // wavefront driver
 // ------------------------------------------------------------------------------------------
 struct StateBufs {
-    DevBuf id, wl, thr, res, ray_o, ray_d, sh, contrib, hit, bs_pdf, eta, counts, ctrl;
+    DevBuf id, wl, thr, res, ray_o, ray_d, sh, contrib, hit, bs_pdf, aux, counts, ctrl;
     PathState st;
     hipError_t alloc(size_t n, uint32_t n_regions) {
         hipError_t e;
 #define A_(b, sz) if ((e = b.reserve(n * (sz))) != hipSuccess) return e;
         A_(id, 16) A_(wl, 16) A_(thr, 16) A_(res, 16) A_(ray_o, 16) A_(ray_d, 16) A_(sh, 16) A_(contrib, 16) A_(hit, 16)
-        A_(bs_pdf, 4) A_(eta, 4)
+        A_(bs_pdf, 4) A_(aux, 8)
 #undef A_
         if ((e = counts.reserve((size_t) n_regions * sizeof(RegionCtl))) != hipSuccess) return e;
         if ((e = ctrl.reserve(sizeof(Ctrl))) != hipSuccess) return e;
         st.id = id.as<uint4>(); st.wl = wl.as<float4>(); st.thr = thr.as<float4>(); st.res = res.as<float4>();
         st.ray_o = ray_o.as<float4>(); st.ray_d = ray_d.as<float4>(); st.sh = sh.as<float4>();
-        st.contrib = contrib.as<float4>(); st.hit = hit.as<float4>(); st.bs_pdf = bs_pdf.as<float>(); st.eta = eta.as<float>();
+        st.contrib = contrib.as<float4>(); st.hit = hit.as<float4>(); st.bs_pdf = bs_pdf.as<float>(); st.aux = aux.as<float2>();
         return hipSuccess;
     }
 };

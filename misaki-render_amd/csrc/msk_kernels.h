@@ -39,7 +39,7 @@ struct DeviceScene {
     const float4 *tri_normals;  // 3 x float4 per triangle (n0 n1 n2) or nullptr
     const float4 *tri_uvs;      // 2 x float4 per triangle (uv0 uv1 | uv2 -) or nullptr
     const int4 *mesh_info;      // {bsdf_id, emitter_id, flags(1=normals,2=texcoords), first_face}
-    const float4 *bsdfs;        // 5 x float4 per bsdf = msk_bsdf_desc verbatim (20 words)
+    const float4 *bsdfs;        // MSK_BSDF_F4 x float4 per bsdf = msk_bsdf_desc verbatim
     const float4 *emitters;     // 2 x float4 per emitter: {c0,c1,c2,inv_area} {mesh,first_face,face_count,cdf_off (uint bits)}
     const float *emitter_d65;   // 95 floats per emitter (d65 * d65_scale)
     const float *cdf;           // concatenated area CDFs (face_count+1 each)
@@ -53,6 +53,8 @@ struct DeviceScene {
     float filter_radius, filter_scale;
     int32_t filter_border;
     float lut[33];
+    int32_t env_emitter;        // index of the constant environment emitter in `emitters`, or -1 (scene.cpp:35-41)
+    float env_radius;           // ConstantBackgroundEmitter::m_bsphere.radius after set_scene (constant.cpp:21-28)
 };
 
 struct PathState {
@@ -64,7 +66,7 @@ struct PathState {
     float4 *contrib;    // NEE contribution added when the shadow ray is unoccluded
     float4 *hit;        // t,u,v,prim
     float *bs_pdf;
-    float *eta;
+    float2 *aux;        // {eta (path.cpp:29), pdf_emitter_direct of the last NEE record (path.cpp:103-106 on an environment hit)}
 };
 
 // Per-region bookkeeping, one record per wave-region, touched only by its owner wave: no atomics
@@ -541,8 +543,8 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
             res = res + from4(st.contrib[i]);
         hit.w = __uint_as_float(__float_as_uint(hit.w) & MSK_PRIM_MASK);
         float bs_pdf = st.bs_pdf[i];
-        float eta = 1.f;                                                   // path.cpp:29, carried only when a BSDF can change it
-        if (!DIFFUSE_ONLY) eta = st.eta[i];
+        float eta = 1.f, nee_pdf = 0.f;                                    // carried only by the general variant
+        if (!DIFFUSE_ONLY) { const float2 a = st.aux[i]; eta = a.x; nee_pdf = a.y; }
         uint32_t depth = id.w & MSK_DEPTH_MASK;
         const f3 rd = mk3(rd4.x, rd4.y, rd4.z);
         const uint32_t pix = id.z;
@@ -554,7 +556,15 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
         spec contrib = splat(0.f);
         bool has_shadow = false;
 
-        if (alive && hit.x == MSK_INF_F) alive = false;                   // path.cpp:34-41 / 96-97, no environment
+        if (alive && hit.x == MSK_INF_F) {                                 // path.cpp:34-41 / 89-97
+            if (!DIFFUSE_ONLY && sc.env_emitter >= 0) {
+                // depth 1: the camera ray left the scene.  depth > 1: the BSDF sample did; its MIS weight uses the NEE
+                // sample's record, which the reference does not re-query on this branch (path.cpp:90-95,103-108).
+                if (depth == 1) { if (!pp.hide_emitters) res = res + thr * emitter_radiance(tb, sc.env_emitter, wl); }
+                else res = res + thr * emitter_radiance(tb, sc.env_emitter, wl) * mis_weight(bs_pdf, nee_pdf);
+            }
+            alive = false;
+        }
         if (alive) {
             Interaction si = make_interaction(tb, hit, rd);
             // twosided.cpp:38-101: the nested BSDF of the side wi is on, with z of wi / wo flipped on the back
@@ -606,6 +616,15 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
                         e = index;
                     }
                     const float4 e0 = tb.emitters[2 * e], e1 = tb.emitters[2 * e + 1];
+                    f3 d; float dist, pdf; spec emitter_val;
+                    if (!DIFFUSE_ONLY && (int) e == sc.env_emitter) {
+                        // constant.cpp:53-72 (radiance at the path's wavelengths, oracle D8)
+                        d = square_to_uniform_sphere(u);
+                        dist = 2.f * sc.env_radius;
+                        pdf = MSK_INV_FOUR_PI_F;
+                        emitter_val = emitter_radiance(tb, (int) e, wl) / pdf;
+                        nee_pdf = pdf;                                     // constant.cpp:74-76
+                    } else {
                     const uint32_t first_face = __float_as_uint(e1.y), n_faces = __float_as_uint(e1.z);
                     const float *cdf = tb.cdf + __float_as_uint(e1.w);
                     // Distribution1D::sample_reuse (core/distribution.h:106-116)
@@ -629,20 +648,21 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
                         ln = normalized(mk3(na.x, na.y, na.z) * (1.f - bc.x - bc.y) + mk3(nb.x, nb.y, nb.z) * bc.x +
                                         mk3(nc.x, nc.y, nc.z) * bc.y);
                     }
-                    float pdf = e0.w;
-                    f3 d = lp - si.p;                                      // shape.cpp:64-78
+                    pdf = e0.w;
+                    d = lp - si.p;                                         // shape.cpp:64-78
                     const float dist2 = dot(d, d);
-                    const float dist = __builtin_sqrtf(dist2);
+                    dist = __builtin_sqrtf(dist2);
                     d = d / dist;
                     const float dp = fabsf(dot(d, ln));
                     pdf *= (dp != 0.f) ? dist2 / dp : 0.f;
-                    spec emitter_val;
+                    if (!DIFFUSE_ONLY) nee_pdf = e0.w * ((dp != 0.f) ? (dist * dist) / dp : 0.f);   // shape.cpp:80-86
                     if (dot(d, ln) < 0.f && pdf != 0.f) {                  // area.cpp:39-44
                         emitter_val = emitter_radiance(tb, (int) e, wl) / pdf;
                     } else {
                         pdf = 0.f; emitter_val = splat(0.f);
                     }
-                    if (n_em > 1) { pdf *= light_sel_pdf; emitter_val = emitter_val * (float) n_em; }
+                    }
+                    if (n_em > 1) { pdf *= light_sel_pdf; emitter_val = emitter_val * (float) n_em; nee_pdf = nee_pdf * (1.f / n_em); }
                     if (pdf != 0.f) {
                         f3 wo = si.sh.to_local(d);
                         if (flipped) wo.z = -wo.z;
@@ -707,7 +727,7 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
             st.wl[o] = to4(wl); st.thr[o] = to4(thr); st.res[o] = to4(res);
             st.ray_o[o] = new_o; st.ray_d[o] = new_d; st.sh[o] = new_sh; st.contrib[o] = to4(contrib);
             st.bs_pdf[o] = bs_pdf;
-            if (!DIFFUSE_ONLY) st.eta[o] = eta;
+            if (!DIFFUSE_ONLY) st.aux[o] = make_float2(eta, nee_pdf);
         }
         cursor += __popcll(m);
     }
@@ -752,7 +772,7 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
         st.ray_d[o] = make_float4(dw.x, dw.y, dw.z, sc.far_clip * inv_z);
         st.sh[o] = make_float4(0, 0, 0, 0); st.contrib[o] = make_float4(0, 0, 0, 0);
         st.bs_pdf[o] = 0.f;
-        if (!DIFFUSE_ONLY) st.eta[o] = 1.f;
+        if (!DIFFUSE_ONLY) st.aux[o] = make_float2(1.f, 0.f);
     }
     if (lane == 0) {
         const uint32_t n_out = cursor + got;

@@ -215,10 +215,12 @@ public:
     const std::vector<ref<Emitter>> &emitters() const { return m_emitters; }
     Sensor *sensor() const { return m_sensor.get(); }
     Integrator *integrator() const { return m_integrator.get(); }
+    const Emitter *environment() const { return m_environment.get(); }
     MSK_DECLARE_CLASS()
 private:
     std::vector<ref<Shape>> m_shapes;
     std::vector<ref<Emitter>> m_emitters;
+    ref<Emitter> m_environment;
     ref<Sensor> m_sensor;
     ref<Integrator> m_integrator;
 };

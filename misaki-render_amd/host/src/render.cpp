@@ -155,6 +155,10 @@ Scene::Scene(const Properties &props) {
             m_shapes.push_back(shape);
         } else if (auto *emitter = dynamic_cast<Emitter *>(obj)) {
             if (!emitter->is_surface()) m_emitters.emplace_back(emitter);
+            if (emitter->is_environment()) {
+                if (m_environment) Throw("Can only have one environment light");
+                m_environment = emitter;
+            }
         } else if (auto *sensor = dynamic_cast<Sensor *>(obj)) {
             if (m_sensor) Throw("Can only have one camera.");
             m_sensor = sensor;
@@ -502,6 +506,28 @@ private:
 MSK_IMPLEMENT_CLASS(AreaLight, Emitter)
 MSK_REGISTER_INSTANCE(AreaLight, "area")
 
+// emitters/constant.cpp:12-19.  set_scene()'s bounding sphere is derived by the back end from the uploaded vertices.
+class ConstantBackgroundEmitter final : public Emitter {
+public:
+    ConstantBackgroundEmitter(const Properties &props) : Emitter(props) { m_radiance = props.texture("radiance", Texture::D65(1.f)); }
+    bool is_environment() const override { return true; }
+    bool flatten(msk_emitter_desc &out) const override {
+        Texture::Flat f;
+        if (!m_radiance->flatten(f) || !f.uses_d65) return false;
+        std::memset(&out, 0, sizeof out);
+        out.type = MSK_EMITTER_CONSTANT;
+        out.mesh_id = -1;
+        std::memcpy(out.radiance, f.coeff, sizeof f.coeff);
+        out.d65_scale = f.d65_scale;
+        return true;
+    }
+    MSK_DECLARE_CLASS()
+private:
+    ref<Texture> m_radiance;
+};
+MSK_IMPLEMENT_CLASS(ConstantBackgroundEmitter, Emitter)
+MSK_REGISTER_INSTANCE(ConstantBackgroundEmitter, "constant")
+
 // sensors/perspective.cpp:8-42
 class PerspectiveCamera final : public ProjectiveCamera {
 public:
@@ -626,7 +652,17 @@ MSK_REGISTER_INSTANCE(OBJMesh, "obj")
 // =========================================================================== flatten
 void flatten_scene(const Scene *scene, const Sensor *sensor, FlatScene &out) {
     out.meshes.clear(); out.bsdfs.clear(); out.emitters.clear(); out.vertices.clear(); out.faces.clear();
+    // Scene::m_emitters order (scene.cpp:27-41) decides which emitter sample_emitter_direct picks (scene.cpp:80-84)
     std::map<const Emitter *, int> emitter_index;
+    for (auto &e : scene->emitters()) {
+        msk_emitter_desc ed;
+        if (!e->flatten(ed))
+            Throw("Emitter \"{}\" cannot be evaluated by the GPU path integrator", e->clazz()->name());
+        if (!e->is_surface() && !e->is_environment())
+            Throw("Emitter \"{}\" is not attached to a shape: not supported by the GPU path integrator", e->clazz()->name());
+        emitter_index[e.get()] = (int) out.emitters.size();
+        out.emitters.push_back(ed);
+    }
     uint32_t nv = 0, nf = 0;
     for (size_t i = 0; i < scene->shapes().size(); ++i) {
         const Shape *shape = scene->shapes()[i].get();
@@ -648,12 +684,8 @@ void flatten_scene(const Scene *scene, const Sensor *sensor, FlatScene &out) {
         out.bsdfs.push_back(bd);
         int eid = -1;
         if (shape->is_emitter()) {
-            msk_emitter_desc ed;
-            if (!shape->emitter()->flatten(ed))
-                Throw("Emitter \"{}\" of shape {} cannot be evaluated by the GPU path integrator", shape->emitter()->clazz()->name(), i);
-            ed.mesh_id = (int32_t) i;
-            eid = (int) out.emitters.size();
-            out.emitters.push_back(ed);
+            eid = emitter_index.at(shape->emitter());
+            out.emitters[eid].mesh_id = (int32_t) i;
         }
         msk_mesh_desc md{nv, mesh->vertex_count(), nf, mesh->face_count(), (int32_t) (out.bsdfs.size() - 1), eid,
                          mesh->has_vertex_normals() ? 1u : 0u, mesh->has_vertex_texcoords() ? 1u : 0u};
@@ -662,8 +694,6 @@ void flatten_scene(const Scene *scene, const Sensor *sensor, FlatScene &out) {
         out.faces.insert(out.faces.end(), mesh->faces(), mesh->faces() + (size_t) mesh->face_count() * 3);
         nv += mesh->vertex_count(); nf += mesh->face_count();
     }
-    for (auto &e : scene->emitters())
-        if (!e->is_surface()) Throw("Emitter \"{}\" is not attached to a shape: not supported by the GPU path integrator", e->clazz()->name());
     msk_scene_desc &d = out.desc;
     std::memset(&d, 0, sizeof d);
     d.abi_version = MSK_ABI_VERSION;

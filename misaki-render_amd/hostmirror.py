@@ -154,7 +154,7 @@ def _bsdf_xml(m, v3):
 
 
 def write_scene_xml(meshes, directory, width, height, spp, camera=None, integrator_props=None, film_type="hdrfilm",
-                    filename="scene.xml"):
+                    filename="scene.xml", env=None):
     """Writes <directory>/meshes/*.obj and a Mitsuba-style scene XML the C++ host (and the reference's
     loader) understands; same structure as results/Figure_1_Pathtrace/scene.xml, $-parameters for spp/size."""
     camera = camera or CBOX_CAMERA
@@ -172,6 +172,14 @@ def write_scene_xml(meshes, directory, width, height, spp, camera=None, integrat
             '        </transform>', '        <sampler type="independent">', '            <integer name="sample_count" value="$spp"/>',
             '        </sampler>', '        <film type="%s">' % film_type, '            <integer name="width" value="$width"/>',
             '            <integer name="height" value="$height"/>', '        </film>', '    </sensor>']
+
+    def env_xml():
+        rad = env.get("radiance")
+        body = ['        <rgb name="radiance" value="%s"/>' % v3(rad)] if rad is not None else \
+               (['        <spectrum name="radiance" value="%r"/>' % float(env["scale"])] if "scale" in env else [])   # D65 * scale
+        return ['    <emitter type="constant">'] + body + ['    </emitter>']
+    if env is not None and env.get("first"):
+        out += env_xml()
     for m in meshes:
         write_obj(m, os.path.join(directory, "meshes", m.name + ".obj"))
         out += ['    <shape type="obj">', '        <string name="filename" value="meshes/%s.obj"/>' % m.name]
@@ -182,6 +190,8 @@ def write_scene_xml(meshes, directory, width, height, spp, camera=None, integrat
         if m.radiance is not None:
             out += ['        <emitter type="area">', '            <rgb name="radiance" value="%s"/>' % v3(m.radiance), '        </emitter>']
         out.append('    </shape>')
+    if env is not None and not env.get("first"):
+        out += env_xml()
     out.append('</scene>')
     path = os.path.join(directory, filename)
     open(path, "w").write("\n".join(out) + "\n")
@@ -310,28 +320,42 @@ class FlatScene:
         self.keep = []
 
 
-def flatten(meshes, width, height, camera=None, filter_stddev=0.5, coeff_lookup=None):
+def _radiance_desc(radiance, fetch, scale_in=1.0):
+    """srgb_d65 (spectra/srgb_d65.cpp:13-31): scale = 2*max(rgb); color /= scale; d65 scale *= scale;
+    d65.cpp:33-34: m_scale *= 1/10568.  radiance None = Texture::D65(scale_in) (constant.cpp:16)."""
+    if radiance is None:
+        return (0.0, 0.0, float("inf")), float(np.float32(scale_in) * (np.float32(1.0) / np.float32(10568.0)))
+    rad = np.asarray(radiance, np.float32)
+    scale = np.float32(rad.max() * np.float32(2.0))
+    col = rad / scale if scale != 0 else rad
+    ce = fetch(tuple(float(x) for x in col))
+    return ce, float(np.float32(np.float32(scale_in) * scale) * (np.float32(1.0) / np.float32(10568.0)))
+
+
+def flatten(meshes, width, height, camera=None, filter_stddev=0.5, coeff_lookup=None, env=None):
     """Scene -> msk_scene_desc, the step the `"path"` plugin's render() performs before calling
     the C ABI.  coeff_lookup(rgb)->(c0,c1,c2) overrides the spectral upsampling
-    (tests pass the reference's own rgb2spec_fetch results); default = this package's rgb2spec."""
+    (tests pass the reference's own rgb2spec_fetch results); default = this package's rgb2spec.
+    env: None, or {"radiance": rgb | None (= D65), "scale": 1.0, "first": False} = a top-level
+    <emitter type="constant"> placed after (or, with first=True, before) the shapes in the XML."""
     from . import rgb2spec
     fetch = coeff_lookup or rgb2spec.srgb_model_fetch
     camera = camera or CBOX_CAMERA
     fs = FlatScene()
     all_v, all_f, md, bd, ed = [], [], [], [], []
     nv = nf = 0
+
+    def env_desc():
+        ce, sc = _radiance_desc(env.get("radiance"), fetch, env.get("scale", 1.0))
+        return abi.EmitterDesc(abi.MSK_EMITTER_CONSTANT, -1, (C.c_float * 3)(*ce), sc)
+    if env is not None and env.get("first"):
+        ed.append(env_desc())
     for i, m in enumerate(meshes):
         v, f = triangulate(m)
         bd.append(_bsdf_desc(m, fetch, len(bd)))
         eid = -1
         if m.radiance is not None:
-            # spectra/srgb_d65.cpp:13-31: scale = 2*max(rgb); color /= scale; d65 scale *= scale;
-            # d65.cpp:33-34: m_scale *= 1/10568
-            rad = np.asarray(m.radiance, np.float32)
-            scale = np.float32(rad.max() * np.float32(2.0))
-            col = rad / scale if scale != 0 else rad
-            ce = fetch(tuple(float(x) for x in col))
-            d65_scale = np.float32(np.float32(1.0) * scale) * (np.float32(1.0) / np.float32(10568.0))
+            ce, d65_scale = _radiance_desc(m.radiance, fetch)
             ed.append(abi.EmitterDesc(abi.MSK_EMITTER_AREA, i, (C.c_float * 3)(*ce), float(d65_scale)))
             eid = len(ed) - 1
         md.append(abi.MeshDesc(nv, len(v), nf, len(f), i, eid, 0, 0))
@@ -339,6 +363,8 @@ def flatten(meshes, width, height, camera=None, filter_stddev=0.5, coeff_lookup=
         all_f.append(f)
         nv += len(v)
         nf += len(f)
+    if env is not None and not env.get("first"):
+        ed.append(env_desc())
     verts = np.ascontiguousarray(np.concatenate(all_v), np.float32)
     faces = np.ascontiguousarray(np.concatenate(all_f), np.uint32)
     cie, d65 = cie_tables()

@@ -91,6 +91,8 @@ struct Scene {
     std::vector<float> mesh_area;          // Mesh::m_surface_area
     std::vector<std::vector<float>> mesh_cdf;  // Distribution1D::m_cdf per mesh
     std::vector<std::vector<float>> emitter_d65;  // RegularSpectrum::m_pdf per emitter
+    int env = -1;                          // Scene::m_environment as an index into emitters
+    float env_radius = 0.f;                // ConstantBackgroundEmitter::m_bsphere.radius after set_scene
 
     std::vector<BVHNode> nodes;
     std::vector<uint32_t> tri_order;
@@ -215,6 +217,20 @@ static Scene *scene_from_desc(const msk_scene_desc *d) {
         sc->emitter_d65[e].resize(MSK_CIE_SAMPLES);
         for (int i = 0; i < MSK_CIE_SAMPLES; ++i)
             sc->emitter_d65[e][i] = sc->d65[i] * sc->emitters[e].d65_scale;
+    }
+    // scene.cpp:35-41 m_environment; constant.cpp:21-28 set_scene: sphere around Scene::bbox() (bbox.h:105-112)
+    for (uint32_t e = 0; e < d->n_emitters; ++e)
+        if (sc->emitters[e].type == MSK_EMITTER_CONSTANT) sc->env = (int) e;
+    if (sc->env >= 0) {
+        V3 pmin = mk3(kInf, kInf, kInf), pmax = mk3(-kInf, -kInf, -kInf);
+        for (uint32_t v = 0; v < d->n_vertices; ++v) {
+            const float *q = &sc->vertices[(size_t) v * 8];
+            pmin = mk3(std::min(pmin.x, q[0]), std::min(pmin.y, q[1]), std::min(pmin.z, q[2]));
+            pmax = mk3(std::max(pmax.x, q[0]), std::max(pmax.y, q[1]), std::max(pmax.z, q[2]));
+        }
+        V3 c = (pmin + pmax) * .5f, r = c - pmax;
+        float radius = std::sqrt(squared_norm(r));
+        sc->env_radius = std::max(kRayEpsilon, radius * (1.f + kRayEpsilon));
     }
     // BVH
     sc->tri_order.resize(d->n_faces);
@@ -472,6 +488,19 @@ static uint32_t distr_sample(const std::vector<float> &cdf, float u) {
 static DirectSample emitter_sample_direct(const Scene &sc, int e, const Interaction &ref, V2 sample,
                                           S4 wl, S4 *spec) {
     const msk_emitter_desc &em = sc.emitters[e];
+    if (em.type == MSK_EMITTER_CONSTANT) {
+        // constant.cpp:53-72.  D8: the reference evaluates the radiance on a default-constructed interaction
+        // (uninitialised wavelengths); the wavelengths of the reference point are used, as area.cpp:35-36 does.
+        DirectSample ds;
+        ds.d = square_to_uniform_sphere(sample);
+        ds.dist = 2.f * sc.env_radius;
+        ds.p = ref.p + ds.d * ds.dist;
+        ds.n = -ds.d;
+        ds.pdf = kInvFourPi;
+        ds.emitter = e;
+        *spec = emitter_radiance(sc, e, wl) / ds.pdf;
+        return ds;
+    }
     uint32_t mesh = (uint32_t) em.mesh_id;
     const std::vector<float> &cdf = sc.mesh_cdf[mesh];
     uint32_t face_idx = distr_sample(cdf, sample.y);
@@ -534,9 +563,14 @@ static DirectSample sample_emitter_direct(const Scene &sc, const Interaction &re
 // scene.cpp:105-112 + shape.cpp:80-86 + mesh.cpp:135-137
 static float pdf_emitter_direct(const Scene &sc, const DirectSample &ds) {
     int e = sc.emitters.size() == 1 ? 0 : ds.emitter;
-    float pdf = 1.f / sc.mesh_area[sc.emitters[e].mesh_id];
-    float dp = std::fabs(dot(ds.d, ds.n));
-    pdf *= (dp != 0.f) ? (ds.dist * ds.dist) / dp : 0.f;
+    float pdf;
+    if (sc.emitters[e].type == MSK_EMITTER_CONSTANT) {
+        pdf = kInvFourPi;                                          // constant.cpp:74-76
+    } else {
+        pdf = 1.f / sc.mesh_area[sc.emitters[e].mesh_id];
+        float dp = std::fabs(dot(ds.d, ds.n));
+        pdf *= (dp != 0.f) ? (ds.dist * ds.dist) / dp : 0.f;
+    }
     return sc.emitters.size() == 1 ? pdf : pdf * (1.f / sc.emitters.size());
 }
 // area.cpp:51-54
@@ -776,7 +810,11 @@ static S4 path_sample(const Scene &sc, Sampler &sampler, Ray ray, S4 wl, const m
     ++cnt.segments;
     Interaction si = compute_interaction(sc, ray, closest_hit(sc, ray));
     for (int depth = 1; depth <= max_depth || max_depth < 0; depth++) {
-        if (!si.valid()) break;                                    // no environment on this path
+        if (!si.valid()) {                                         // path.cpp:34-41
+            if (depth == 1 && (!hide_emitter || scattered) && sc.env >= 0)
+                result = result + throughput * emitter_radiance(sc, sc.env, wl);
+            break;
+        }
         int emitter = sc.meshes[si.mesh].emitter_id;
         if (emitter >= 0 && depth == 1 && (!hide_emitter || scattered))
             result = result + throughput * emitter_eval(sc, emitter, si, wl);
@@ -828,8 +866,12 @@ static S4 path_sample(const Scene &sc, Sampler &sampler, Ray ray, S4 wl, const m
                 ds.p = si_bsdf.p; ds.n = si_bsdf.sh.n; ds.emitter = em; ds.d = ray.d; ds.dist = si_bsdf.t;
                 hit_emitter = true;
             }
+        } else if (sc.env >= 0) {                                  // path.cpp:90-95
+            if (hide_emitter && !scattered) break;
+            value = emitter_radiance(sc, sc.env, wl);
+            hit_emitter = true;            // `ds` is NOT re-queried: the MIS weight below uses the NEE sample's record
         } else {
-            break;                                                 // path.cpp:96-97 (no environment)
+            break;                                                 // path.cpp:96-97
         }
         throughput = throughput * bsdf_val;
         eta *= bs_eta;

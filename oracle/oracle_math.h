@@ -297,6 +297,14 @@ static inline V2 square_to_uniform_triangle(V2 sample) {
     float t = safe_sqrt(1.f - sample.x);
     return V2{1.f - t, t * sample.y};
 }
+// core/warp.h:7-9,46-53
+static inline V3 square_to_uniform_sphere(V2 sample) {
+    float z = -2.f * sample.y + 1.f, r = safe_sqrt(-z * z + 1.f);
+    float t = (2.f * kPi) * sample.x;
+    float s, c; det_sincos(t, &s, &c);
+    return mk3(r * c, r * s, z);
+}
+static const float kInvFourPi = float(0.07957747154594766788);
 // core/warp.h:17-32
 static inline V2 square_to_uniform_disk_concentric(V2 sample) {
     float x = 2.f * sample.x - 1.f;

@@ -1,0 +1,149 @@
+"""SURVEY §8(f) row 2, second half: the constant environment emitter (emitters/constant.cpp, scene.cpp:35-41,
+path.cpp:34-41,89-108).  The oracle is pinned by closed-form radiometry (a convex Lambertian body in a uniform
+environment leaves exactly albedo * L in every direction); the GPU is compared with the oracle bit for bit."""
+import importlib
+
+import numpy as np
+import pytest
+
+
+def sphere_scene(hostmirror, w, h, env, rho=(0.5, 0.5, 0.5), with_light=False):
+    ball = hostmirror.blob_mesh("ball", (278, 273, 280), 150, 16, 24, rho, bump=0.0)        # convex: a UV sphere
+    meshes = [ball]
+    if with_light:
+        meshes = hostmirror.cbox_meshes()[:6] + [ball]
+    return hostmirror.flatten(meshes, w, h, env=env)
+
+
+def test_descriptor_and_emitter_order(hostmirror, abi):
+    flat = sphere_scene(hostmirror, 16, 16, {"radiance": None}, with_light=True)
+    d = flat.desc
+    assert d.n_emitters == 2 and d.emitters[0].type == abi.MSK_EMITTER_AREA and d.emitters[1].type == abi.MSK_EMITTER_CONSTANT
+    e = d.emitters[1]
+    assert e.mesh_id == -1 and np.isinf(e.radiance[2]) and e.d65_scale == np.float32(1.0) / np.float32(10568.0)   # Texture::D65(1)
+    flat = sphere_scene(hostmirror, 16, 16, {"radiance": (0.2, 0.4, 0.8), "first": True}, with_light=True)
+    d = flat.desc
+    assert d.emitters[0].type == abi.MSK_EMITTER_CONSTANT and d.emitters[1].mesh_id == 0 and d.meshes[0].emitter_id == 1
+    assert np.isclose(d.emitters[0].d65_scale, 1.6 / 10568.0)                              # srgb_d65.cpp:18-26
+
+
+@pytest.mark.parametrize("max_depth", [-1, 2])
+def test_convex_lambertian_body_in_a_uniform_environment(oracle, hostmirror, abi, max_depth):
+    """Furnace: every path from the ball ends in the environment, so L_o = rho * L exactly (NEE + BSDF sampling with MIS
+    must add up to one full estimate).  With grey rho = 0.5 the spectral upsampling is exact (S == 0.5)."""
+    flat = sphere_scene(hostmirror, 48, 48, {"radiance": None})
+    sc = oracle.scene(flat)
+    film, st = sc.render(abi.render_params(64, seed=3, max_depth=max_depth), threads=8)
+    img = hostmirror.develop(film)[..., :3]
+    yy, xx = np.mgrid[0:48, 0:48]
+    # ball of radius 150 at distance 1080 seen with fov 49.3: ~ 7.3 px radius at 48 px
+    r = np.hypot(xx - 23.5, yy - 23.5)
+    inside, outside = img[r < 4.5], img[r > 12]
+    # the background is L = D65 -> sRGB white, up to the colour noise of 4 sampled wavelengths per path
+    assert np.allclose(outside.mean(0), 1.0, atol=0.01) and outside.std(0).max() < 0.06
+    ratio = inside.mean(0) / outside.mean(0)
+    assert np.allclose(ratio, 0.5, rtol=0.02), ratio
+    assert st.segments / st.samples < 1.1 and st.shadow_rays > 0
+    # hide_emitters removes the directly visible environment only (path.cpp:36)
+    film2, _ = sc.render(abi.render_params(16, seed=3, hide_emitters=1), threads=8)
+    img2 = hostmirror.develop(film2)[..., :3]
+    assert np.all(img2[r > 12] == 0) and img2[r < 4.5].mean() > 0.4 * outside.mean()
+    sc.close()
+
+
+def test_environment_first_or_last_same_expectation(oracle, hostmirror, abi):
+    imgs = []
+    for first in (False, True):
+        flat = sphere_scene(hostmirror, 32, 32, {"radiance": (0.3, 0.5, 0.9), "first": first}, rho=(0.6, 0.5, 0.3), with_light=True)
+        sc = oracle.scene(flat)
+        film, _ = sc.render(abi.render_params(64, seed=9), threads=8)
+        imgs.append(hostmirror.develop(film)[..., :3])
+        sc.close()
+    assert not np.array_equal(imgs[0], imgs[1])                       # different emitter index -> different sample stream
+    assert abs(imgs[0].mean() - imgs[1].mean()) < 0.03 * imgs[0].mean()
+
+
+def test_xml_round_trip_through_the_host_library(hostmirror, tmp_path, abi):
+    import __graft_entry__ as ge
+    ge.build_gpu_library()
+    ge.build_host_library()
+    hostlib = importlib.import_module("misaki-render_amd.hostlib")
+    meshes = hostmirror.cbox_meshes()[:3]
+    for env in ({"radiance": None}, {"scale": 2.5}, {"radiance": (0.2, 0.4, 0.8), "first": True}):
+        xml = hostmirror.write_scene_xml(meshes, str(tmp_path), 16, 16, 1, env=env)
+        d = hostlib.HostScene(xml).flatten().desc
+        r = hostmirror.flatten(meshes, 16, 16, env=env).desc
+        assert d.n_emitters == r.n_emitters == 2
+        for i in range(2):
+            a, b = d.emitters[i], r.emitters[i]
+            assert (a.type, a.mesh_id) == (b.type, b.mesh_id) and np.isclose(a.d65_scale, b.d65_scale, rtol=1e-6)
+            assert np.allclose(a.radiance[:], b.radiance[:], rtol=2e-4, atol=2e-6)
+        assert [d.meshes[i].emitter_id for i in range(3)] == [r.meshes[i].emitter_id for i in range(3)]
+    xml = hostmirror.write_scene_xml(meshes, str(tmp_path), 16, 16, 1, env={"radiance": None})
+    text = open(xml).read().replace("</scene>", '<emitter type="constant"/></scene>')
+    (tmp_path / "two.xml").write_text(text)
+    with pytest.raises(hostlib.HostError) as e:
+        hostlib.HostScene(str(tmp_path / "two.xml"))
+    assert "Can only have one environment light" in str(e.value)
+
+
+def open_box_scene(hostmirror, golden_lookup, w, h):
+    """The Cornell box without its back wall, in a bluish environment, with a glass blob: area + environment emitters,
+    every BSDF type, paths that leave through the hole."""
+    r2s = importlib.import_module("misaki-render_amd.rgb2spec")
+
+    def look(rgb):
+        try:
+            return golden_lookup(rgb)
+        except KeyError:
+            return r2s.srgb_model_fetch(rgb)
+    meshes = hostmirror.cbox_meshes()
+    del meshes[3]                                                       # back wall
+    meshes[6].bsdf = {"type": "roughconductor", "alpha": 0.2, "eta": (0.2, 0.92, 1.1), "k": (3.9, 2.45, 2.14), "twosided": True}
+    blob = hostmirror.blob_mesh("blob", (185, 240, 170), 75, 24, 24, hostmirror.WHITE, seed=3)
+    blob.bsdf = {"type": "roughdielectric", "alpha": 0.1, "int_ior": 1.5, "ext_ior": 1.0}
+    return hostmirror.flatten(meshes + [blob], w, h, coeff_lookup=look, env={"radiance": (0.25, 0.4, 0.8)})
+
+
+def test_oracle_renders_the_open_box(oracle, hostmirror, golden_lookup, abi):
+    flat = open_box_scene(hostmirror, golden_lookup, 40, 40)
+    sc = oracle.scene(flat)
+    film, st = sc.render(abi.render_params(8, seed=2), threads=4)
+    assert np.isfinite(film).all() and film.min() >= -1e-4 and film[..., :3].min() > 0      # the environment lights everything
+    sc.set_bvh(0)
+    film2, _ = sc.render(abi.render_params(8, seed=2), threads=4)
+    assert np.array_equal(film, film2)
+    sc.close()
+
+
+def test_abi_rejects_bad_environment_descriptors(abi, hostmirror):
+    """CPU-only: validation happens before any device work, but needs a context -> covered on the GPU box; here the
+    struct layout only."""
+    assert abi.MSK_EMITTER_CONSTANT == 1 and abi.MSK_EMITTER_AREA == 0
+
+
+@pytest.mark.gpu
+def test_gpu_matches_oracle_with_an_environment(gpu_ctx, oracle, hostmirror, golden_lookup, abi):
+    for flat in (open_box_scene(hostmirror, golden_lookup, 96, 96), sphere_scene(hostmirror, 64, 64, {"radiance": None}),
+                 sphere_scene(hostmirror, 64, 64, {"radiance": (0.3, 0.5, 0.9), "first": True}, with_light=True)):
+        g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+        w = flat.desc.film.width
+        prm = abi.render_params(spp=16, seed=11)
+        rng = np.random.RandomState(4)
+        pixels = np.concatenate([rng.randint(0, w, (40, 2)), [[w // 2, w // 2], [3, 3]]]).astype(np.int32)
+        gx, gp = g.sample_pixels(prm, pixels)
+        ox, op = o.sample_pixels(prm, pixels)
+        assert np.array_equal(gp, op)
+        bad = (gx.view(np.uint32) != ox.view(np.uint32)).any(-1)
+        assert not bad.any(), (int(bad.sum()), gx[bad][:3], ox[bad][:3])
+        for kw in (dict(), dict(hide_emitters=1), dict(max_depth=2)):
+            film, st = g.render(abi.render_params(spp=4, seed=5, **kw))
+            ref, rst = o.render(abi.render_params(spp=4, seed=5, **kw), threads=8)
+            assert np.array_equal(film.view(np.uint32), ref.view(np.uint32)), kw
+        g.close()
+        o.close()
+    # two environment emitters / an environment with a mesh are rejected (scene.cpp:38-39)
+    flat = sphere_scene(hostmirror, 16, 16, {"radiance": None})
+    flat.desc.emitters[0].mesh_id = 0
+    with pytest.raises(abi.MskError):
+        abi.Scene(gpu_ctx, flat)
