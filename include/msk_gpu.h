@@ -52,6 +52,14 @@ extern "C" {
 #define MSK_EMITTER_AREA       0   /* "area"     emitters/area.cpp:61          */
 #define MSK_EMITTER_CONSTANT   1   /* "constant" emitters/constant.cpp:95 (environment; mesh_id = -1, at most one) */
 
+/* AOV channel groups of the "aov" integrator (integrators/aov.cpp:21-28,87-144); channels per type: 1 3 2 3 3 4 */
+#define MSK_AOV_DEPTH          0   /* si.t, 0 on a miss                                  (aov.cpp:97-99)   */
+#define MSK_AOV_POSITION       1   /* si.p                                               (aov.cpp:101-105) */
+#define MSK_AOV_UV             2   /* si.uv                                              (aov.cpp:107-110) */
+#define MSK_AOV_GEO_NORMAL     3   /* si.n                                               (aov.cpp:112-116) */
+#define MSK_AOV_SH_NORMAL      4   /* si.sh_frame.n                                      (aov.cpp:118-122) */
+#define MSK_AOV_PATH_RGBA      5   /* nested "path" integrator: xyz_to_srgb(XYZ of its sample), 1 (aov.cpp:124-141) */
+
 /* RNG semantics (the reference's own seeding is not reproducible) */
 #define MSK_RNG_PCG_BLOCK      0   /* one PCG32 stream per 32x32 block; CPU oracle only */
 #define MSK_RNG_COUNTER        1   /* stateless hash of (seed,pixel,sample,dim); GPU + oracle */
@@ -220,6 +228,19 @@ int  msk_gpu_render(msk_scene *scene, const msk_render_params *params,
    returns after the work is complete on that stream. */
 int  msk_gpu_render_device(msk_scene *scene, const msk_render_params *params,
                            float *d_film_xyzaw, void *hip_stream, msk_stats *stats);
+
+/*
+ * AOVIntegrator::render (integrators/aov.cpp:87-144 through SamplingIntegrator::render, integrator.cpp:31-80):
+ * the same job with extra film channels.  aov_types: n_aovs values MSK_AOV_*, in the order of the plugin's
+ * m_aov_types; at most one MSK_AOV_PATH_RGBA (the nested "path" integrator whose sample also becomes the
+ * XYZ result, aov.cpp:138-139; without one XYZ is 0 — the reference returns an uninitialised Spectrum there).
+ * Every AOV value of a camera ray that misses the scene is 0 (the reference reads an uninitialised
+ * SceneInteraction for all but depth).  film: height*width*(5 + msk_gpu_aov_channels()) floats, host,
+ * the weighted sums HDRFilm's storage holds (channels X,Y,Z,A,W, then the AOV channels in order).
+ */
+uint32_t msk_gpu_aov_channels(const int32_t *aov_types, uint32_t n_aovs);   /* 0 if a type is invalid */
+int  msk_gpu_render_aov(msk_scene *scene, const msk_render_params *params,
+                        const int32_t *aov_types, uint32_t n_aovs, float *film, msk_stats *stats);
 
 /* ---- sub-stage entry points (parity tests bind these) ---------------------- */
 /*

@@ -105,7 +105,11 @@ LIB_PATH = os.path.join(_PKG_DIR, "lib", "libmsk_gpu.so")
 # every symbol include/msk_gpu.h declares
 EXPORTS = ["msk_gpu_init", "msk_gpu_shutdown", "msk_gpu_last_error", "msk_gpu_scene_create",
            "msk_gpu_scene_destroy", "msk_gpu_render", "msk_gpu_render_device", "msk_gpu_trace_closest",
-           "msk_gpu_trace_any", "msk_gpu_sample_pixels", "msk_gpu_describe"]
+           "msk_gpu_trace_any", "msk_gpu_sample_pixels", "msk_gpu_describe", "msk_gpu_render_aov", "msk_gpu_aov_channels"]
+
+# integrators/aov.cpp:21-28
+MSK_AOV_DEPTH, MSK_AOV_POSITION, MSK_AOV_UV, MSK_AOV_GEO_NORMAL, MSK_AOV_SH_NORMAL, MSK_AOV_PATH_RGBA = range(6)
+AOV_WIDTH = (1, 3, 2, 3, 3, 4)
 
 _lib = None
 
@@ -142,6 +146,10 @@ def load_library(path=None):
     lib.msk_gpu_trace_any.restype = C.c_int
     lib.msk_gpu_sample_pixels.argtypes = [vp, C.POINTER(RenderParams), u64, vp, vp, vp]
     lib.msk_gpu_sample_pixels.restype = C.c_int
+    lib.msk_gpu_render_aov.argtypes = [vp, C.POINTER(RenderParams), vp, C.c_uint32, vp, C.POINTER(Stats)]
+    lib.msk_gpu_render_aov.restype = C.c_int
+    lib.msk_gpu_aov_channels.argtypes = [vp, C.c_uint32]
+    lib.msk_gpu_aov_channels.restype = C.c_uint32
     lib.msk_gpu_describe.argtypes = [vp, C.c_char_p, u64]
     lib.msk_gpu_describe.restype = C.c_int
     if path is None:
@@ -207,6 +215,15 @@ class Scene:
         film = np.empty((self.height, self.width, 5), np.float32)
         st = Stats()
         self.ctx.check(self.ctx.lib.msk_gpu_render(self.handle, C.byref(params), _ptr(film), C.byref(st)))
+        return film, st
+
+    def render_aov(self, params, aov_types):
+        """The "aov" integrator: -> (film float32[H,W,5+C] of weighted sums {X,Y,Z,A,W, aov channels...}, Stats)."""
+        types = np.ascontiguousarray(aov_types, np.int32)
+        n_ch = self.ctx.lib.msk_gpu_aov_channels(_ptr(types), len(types)) if len(types) else 0
+        film = np.empty((self.height, self.width, 5 + n_ch), np.float32)
+        st = Stats()
+        self.ctx.check(self.ctx.lib.msk_gpu_render_aov(self.handle, C.byref(params), _ptr(types), len(types), _ptr(film), C.byref(st)))
         return film, st
 
     def render_device(self, params, device_ptr, stream=None):

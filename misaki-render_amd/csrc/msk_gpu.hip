@@ -368,6 +368,16 @@ struct StateBufs {
 struct Workspace {
     StateBufs sb;
     DevBuf block_buf, blocks, block_of, spiral, pix, rec_a, rec_b, film;
+    DevBuf aov_rec[MSK_MAX_AOV_GROUPS + 1], aov_block_buf[MSK_MAX_AOV_GROUPS + 1];   // [n_groups] = the nested path's RGB
+};
+
+// what msk_gpu_render_aov asked for, in record groups of three channels (see AovParams)
+struct AovPlan {
+    uint32_t n_channels = 0;                 // film channels after X,Y,Z,A,W
+    uint32_t n_groups = 0;                   // primary-hit groups
+    uint32_t code[MSK_MAX_AOV_GROUPS] = {};
+    int32_t out_ch[MSK_MAX_AOV_GROUPS + 1][5];   // film channel of each block channel, -1 = unused
+    bool rgba = false;                       // group n_groups: nested path integrator R,G,B (+ A = the weight sum)
 };
 
 static uint32_t env_u32(const char *name, uint32_t def) {
@@ -396,7 +406,8 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
                          const uint4 *d_pix, uint64_t n_pix, float4 *rec_a, float *rec_b, StateBufs &sb,
                          uint32_t region_size, uint32_t n_regions, msk_stats *stats, EventPool &ev,
                          std::vector<std::pair<hipEvent_t, hipEvent_t>> &ev_trace,
-                         std::vector<std::pair<hipEvent_t, hipEvent_t>> &ev_shade) {
+                         std::vector<std::pair<hipEvent_t, hipEvent_t>> &ev_shade,
+                         const AovParams *aov = nullptr, float4 *aov_rgb = nullptr) {
     msk_ctx *ctx = sc->ctx;
     const unsigned long long total = (unsigned long long) n_pix * spp_owned;
     // static, interleaved partition of the pass's samples over the regions (see RegionCtl)
@@ -417,6 +428,8 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     pp.rr_depth = prm->rr_depth; pp.max_depth = prm->max_depth; pp.hide_emitters = prm->hide_emitters;
     pp.pix_table = d_pix; pp.rec_a = rec_a; pp.rec_b = rec_b;
     pp.region_size = region_size; pp.n_regions = n_regions; pp.regions = sb.counts.as<RegionCtl>();
+    pp.aov_rgb = aov_rgb;
+    const bool diffuse_only = sc->all_diffuse && !aov_rgb;      // the AOV RGB record lives in the general shading variant
     const uint32_t grid = (n_regions * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
     const uint32_t group = env_u32("MSK_SYNC_GROUP", 8);
     const bool timing = stats != nullptr;
@@ -426,11 +439,12 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
             hipEvent_t a = nullptr, b = nullptr, c = nullptr;
             if (timing) { a = ev.get(); b = ev.get(); c = ev.get(); (void) hipEventRecord(a, stream); }
 #define MSK_SHADE(L, D) hipLaunchKernelGGL((k_shade_gen<L, D>), dim3(grid), dim3(MSK_BLOCK), (L) ? sc->shade_lds_bytes : 0, stream, sc->dev, sb.st, pp)
-            if (sc->lds_tables) { if (sc->all_diffuse) MSK_SHADE(true, true); else MSK_SHADE(true, false); }
-            else { if (sc->all_diffuse) MSK_SHADE(false, true); else MSK_SHADE(false, false); }
+            if (sc->lds_tables) { if (diffuse_only) MSK_SHADE(true, true); else MSK_SHADE(true, false); }
+            else { if (diffuse_only) MSK_SHADE(false, true); else MSK_SHADE(false, false); }
 #undef MSK_SHADE
             if (timing) (void) hipEventRecord(b, stream);
             launch_trace(sc, stream, sb.st, pp);
+            if (aov && aov->n_groups) hipLaunchKernelGGL(k_aov_primary, dim3(grid), dim3(MSK_BLOCK), 0, stream, sc->dev, sb.st, pp, *aov);
             if (timing) { (void) hipEventRecord(c, stream); ev_shade.push_back({a, b}); ev_trace.push_back({b, c}); }
         }
         hipLaunchKernelGGL(k_reduce_ctl, dim3(1), dim3(MSK_BLOCK), 0, stream, sb.counts.as<RegionCtl>(), n_regions, sb.ctrl.as<Ctrl>());
@@ -486,7 +500,8 @@ static void sum_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, float 
     for (auto &p : v) { float t = 0; if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) *ms += t; }
 }
 
-static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_film, hipStream_t user_stream, msk_stats *stats) {
+static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_film, hipStream_t user_stream, msk_stats *stats,
+                       const AovPlan *aov = nullptr) {
     msk_ctx *ctx = sc->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int border = sc->dev.filter_border;
@@ -519,6 +534,12 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     Workspace &ws = *sc->ws;
     DevBuf &d_block_buf = ws.block_buf, &d_blocks = ws.blocks, &d_block_of = ws.block_of, &d_spiral = ws.spiral;
     HIP_TRY(ctx, d_block_buf.reserve(std::max<size_t>(owned.size(), 1) * buf_stride * 4));
+    const uint32_t n_aov_bufs = aov ? aov->n_groups + (aov->rgba ? 1u : 0u) : 0u;
+    for (uint32_t g = 0; g < n_aov_bufs; ++g) {
+        const uint32_t slot = g < aov->n_groups ? g : MSK_MAX_AOV_GROUPS;
+        HIP_TRY(ctx, ws.aov_block_buf[slot].reserve(std::max<size_t>(owned.size(), 1) * buf_stride * 4));
+    }
+    const size_t rec_bytes = 20 + 16 * (size_t) n_aov_bufs;      // per sample
     // ---- plan passes: consecutive owned blocks whose records fit the budget
     size_t free_b = 0, total_b = 0;
     HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -532,7 +553,7 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     free_b += held;
     size_t budget = getenv("MSK_RECORD_BUDGET_MB") ? (size_t) atoll(getenv("MSK_RECORD_BUDGET_MB")) << 20
                                                    : (free_b > state_bytes ? (size_t) ((free_b - state_bytes) * 0.8) : 0);
-    const size_t rec_bytes_per_block_max = (size_t) bs * bs * spp_owned * 20;
+    const size_t rec_bytes_per_block_max = (size_t) bs * bs * spp_owned * rec_bytes;
     if (!owned.empty() && budget < rec_bytes_per_block_max)
         return fail(ctx, MSK_ERR_OOM, "not enough HBM for one block of sample records (%zu B needed, %zu B budget)",
                     rec_bytes_per_block_max, budget);
@@ -540,7 +561,7 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     for (size_t b0 = 0; b0 < owned.size();) {
         size_t b1 = b0, bytes = 0; uint32_t pixel_base = 0;
         while (b1 < owned.size()) {
-            const size_t add = (size_t) owned[b1].size_x * owned[b1].size_y * spp_owned * 20;
+            const size_t add = (size_t) owned[b1].size_x * owned[b1].size_y * spp_owned * rec_bytes;
             if (b1 > b0 && bytes + add > budget) break;
             owned[b1].pixel_base = pixel_base; pixel_base += (uint32_t) (owned[b1].size_x * owned[b1].size_y);
             bytes += add; ++b1;
@@ -566,8 +587,19 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
         const uint64_t n_rec = (uint64_t) pix.size() * spp_owned;
         HIP_TRY(ctx, d_pix.upload(pix));
         HIP_TRY(ctx, d_rec_a.reserve(n_rec * 16)); HIP_TRY(ctx, d_rec_b.reserve(n_rec * 4));
+        AovParams ap;
+        std::memset(&ap, 0, sizeof ap);
+        float4 *aov_rgb = nullptr;
+        if (aov) {
+            ap.n_groups = aov->n_groups;
+            for (uint32_t g = 0; g < aov->n_groups; ++g) {
+                HIP_TRY(ctx, ws.aov_rec[g].reserve(n_rec * 16));
+                ap.rec[g] = ws.aov_rec[g].as<float4>(); ap.code[g] = aov->code[g];
+            }
+            if (aov->rgba) { HIP_TRY(ctx, ws.aov_rec[MSK_MAX_AOV_GROUPS].reserve(n_rec * 16)); aov_rgb = ws.aov_rec[MSK_MAX_AOV_GROUPS].as<float4>(); }
+        }
         rc = run_wavefront(sc, stream, prm, spp_owned, d_pix.as<uint4>(), pix.size(), d_rec_a.as<float4>(),
-                           d_rec_b.as<float>(), sb, region_size, n_regions, stats, ev, ev_trace, ev_shade);
+                           d_rec_b.as<float>(), sb, region_size, n_regions, stats, ev, ev_trace, ev_shade, aov ? &ap : nullptr, aov_rgb);
         if (rc) return rc;
         const uint32_t nb = (uint32_t) (ps.second - ps.first);
         // tile of film pixels per thread: 1 wide (adjacent lanes read adjacent records -> full cache lines),
@@ -579,14 +611,20 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
         (void) hipEventRecord(a, stream);
         const dim3 rgrid((uint32_t) ((threads + MSK_BLOCK - 1) / MSK_BLOCK));
 #define MSK_RESOLVE(TX, TY) hipLaunchKernelGGL((k_resolve_blocks<TX, TY>), rgrid, dim3(MSK_BLOCK), 0, stream, sc->dev,      \
-                           d_blocks.as<BlockInfo>() + ps.first, nb, d_rec_a.as<float4>(), d_rec_b.as<float>(), spp_owned,  \
-                           d_block_buf.as<float>(), buf_stride, tiles_x, tiles_y)
-        if (tile_x == 2 && tile_y == 2) MSK_RESOLVE(2, 2);
-        else if (tile_x == 1 && tile_y == 1) MSK_RESOLVE(1, 1);
-        else if (tile_x == 1 && tile_y == 2) MSK_RESOLVE(1, 2);
-        else if (tile_x == 1 && tile_y == 3) MSK_RESOLVE(1, 3);
-        else if (tile_x == 1 && tile_y == 6) MSK_RESOLVE(1, 6);
-        else MSK_RESOLVE(1, 4);
+                           d_blocks.as<BlockInfo>() + ps.first, nb, res_rec, d_rec_b.as<float>(), spp_owned,               \
+                           res_buf, buf_stride, tiles_x, tiles_y)
+        // the XYZAW records, then every AOV record group through the same ordered replay (same weights, same order)
+        for (uint32_t g = 0; g <= n_aov_bufs; ++g) {
+            const uint32_t slot = g == 0 ? 0 : (g - 1 < (aov ? aov->n_groups : 0u) ? g - 1 : MSK_MAX_AOV_GROUPS);
+            const float4 *res_rec = g == 0 ? d_rec_a.as<float4>() : ws.aov_rec[slot].as<float4>();
+            float *res_buf = g == 0 ? d_block_buf.as<float>() : ws.aov_block_buf[slot].as<float>();
+            if (tile_x == 2 && tile_y == 2) MSK_RESOLVE(2, 2);
+            else if (tile_x == 1 && tile_y == 1) MSK_RESOLVE(1, 1);
+            else if (tile_x == 1 && tile_y == 2) MSK_RESOLVE(1, 2);
+            else if (tile_x == 1 && tile_y == 3) MSK_RESOLVE(1, 3);
+            else if (tile_x == 1 && tile_y == 6) MSK_RESOLVE(1, 6);
+            else MSK_RESOLVE(1, 4);
+        }
 #undef MSK_RESOLVE
         (void) hipEventRecord(b, stream);
         ev_resolve.push_back({a, b});
@@ -596,9 +634,15 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     {
         hipEvent_t a = ev.get(), b = ev.get();
         (void) hipEventRecord(a, stream);
-        hipLaunchKernelGGL(k_film_put, dim3((uint32_t) (((size_t) W * H + MSK_BLOCK - 1) / MSK_BLOCK)), dim3(MSK_BLOCK), 0, stream,
-                           sc->dev, d_blocks.as<BlockInfo>(), d_block_of.as<int32_t>(), d_spiral.as<uint32_t>(), nbx, nby, bs,
-                           d_block_buf.as<float>(), buf_stride, d_film);
+        for (uint32_t g = 0; g <= n_aov_bufs; ++g) {
+            const uint32_t slot = g == 0 ? 0 : (g - 1 < (aov ? aov->n_groups : 0u) ? g - 1 : MSK_MAX_AOV_GROUPS);
+            FilmOut fo;
+            fo.film = d_film; fo.stride = 5 + (int32_t) (aov ? aov->n_channels : 0u);
+            for (int c = 0; c < 5; ++c) fo.ch[c] = g == 0 ? c : aov->out_ch[g - 1 < aov->n_groups ? g - 1 : MSK_MAX_AOV_GROUPS][c];
+            hipLaunchKernelGGL(k_film_put, dim3((uint32_t) (((size_t) W * H + MSK_BLOCK - 1) / MSK_BLOCK)), dim3(MSK_BLOCK), 0, stream,
+                               sc->dev, d_blocks.as<BlockInfo>(), d_block_of.as<int32_t>(), d_spiral.as<uint32_t>(), nbx, nby, bs,
+                               g == 0 ? d_block_buf.as<float>() : ws.aov_block_buf[slot].as<float>(), buf_stride, fo);
+        }
         (void) hipEventRecord(b, stream);
         ev_resolve.push_back({a, b});
     }
@@ -630,6 +674,61 @@ extern "C" int msk_gpu_render(msk_scene *scene, const msk_render_params *params,
     int rc = render_impl(scene, params, film.as<float>(), nullptr, stats);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpy(film_xyzaw, film.p, bytes, hipMemcpyDeviceToHost));
+    return MSK_OK;
+}
+
+static const int kAovWidth[6] = {1, 3, 2, 3, 3, 4};
+extern "C" uint32_t msk_gpu_aov_channels(const int32_t *aov_types, uint32_t n_aovs) {
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < n_aovs; ++i) {
+        if (!aov_types || aov_types[i] < 0 || aov_types[i] > MSK_AOV_PATH_RGBA) return 0;
+        n += (uint32_t) kAovWidth[aov_types[i]];
+    }
+    return n;
+}
+
+extern "C" int msk_gpu_render_aov(msk_scene *scene, const msk_render_params *params, const int32_t *aov_types, uint32_t n_aovs,
+                                  float *film, msk_stats *stats) {
+    if (!scene || !film || !params || (n_aovs && !aov_types))
+        return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_render_aov: NULL argument");
+    msk_ctx *ctx = scene->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    AovPlan plan;
+    for (auto &row : plan.out_ch) for (int &c : row) c = -1;
+    // selectors of the primary-hit channels, in film order (AovParams::code)
+    static const int first_code[5] = {1, 2, 5, 7, 10};
+    std::vector<std::pair<int, int>> prim;        // (selector, film channel)
+    int ch = 5;
+    for (uint32_t i = 0; i < n_aovs; ++i) {
+        const int t = aov_types[i];
+        if (t < 0 || t > MSK_AOV_PATH_RGBA) return fail(ctx, MSK_ERR_INVALID_ARG, "Invalid AOV type %d!", t);
+        if (t == MSK_AOV_PATH_RGBA) {
+            if (plan.rgba) return fail(ctx, MSK_ERR_UNSUPPORTED, "at most one nested integrator is supported by the \"aov\" integrator of this back end");
+            plan.rgba = true;
+            for (int c = 0; c < 4; ++c) plan.out_ch[MSK_MAX_AOV_GROUPS][c] = ch + c;     // block channel 3 = the weight sum = A
+        } else {
+            for (int c = 0; c < kAovWidth[t]; ++c) prim.push_back({first_code[t] + c, ch + c});
+        }
+        ch += kAovWidth[t];
+    }
+    plan.n_channels = (uint32_t) ch - 5;
+    if (prim.size() > 3 * MSK_MAX_AOV_GROUPS)
+        return fail(ctx, MSK_ERR_UNSUPPORTED, "too many AOV channels (%zu, at most %d besides the nested integrator)", prim.size(), 3 * MSK_MAX_AOV_GROUPS);
+    plan.n_groups = (uint32_t) ((prim.size() + 2) / 3);
+    for (size_t k = 0; k < prim.size(); ++k) {
+        plan.code[k / 3] |= (uint32_t) prim[k].first << (8 * (k % 3));
+        plan.out_ch[k / 3][k % 3] = prim[k].second;
+    }
+    msk_render_params p = *params;
+    if (!plan.rgba) p.max_depth = 0;      // no nested integrator: only the camera ray is traced and XYZ stays 0 (aov.cpp:91)
+    if (!scene->ws) scene->ws = new Workspace();
+    DevBuf &d_film = scene->ws->film;
+    const size_t bytes = (size_t) scene->dev.width * scene->dev.height * (5 + plan.n_channels) * 4;
+    HIP_TRY(ctx, d_film.reserve(bytes));
+    HIP_TRY(ctx, hipMemsetAsync(d_film.p, 0, bytes, ctx->stream));
+    int rc = render_impl(scene, &p, d_film.as<float>(), nullptr, stats, &plan);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(film, d_film.p, bytes, hipMemcpyDeviceToHost));
     return MSK_OK;
 }
 

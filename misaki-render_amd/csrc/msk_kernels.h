@@ -94,7 +94,17 @@ struct PassParams {
     float *rec_b;                 // per sample pos.y           i.e. [block][sample][pixel], pixel fastest
     uint32_t region_size, n_regions;
     RegionCtl *regions;
+    float4 *aov_rgb;              // nullptr, or per sample {R,G,B,pos.x} of the nested path integrator (aov.cpp:124-141)
 };
+
+// AOV channels read off the primary hit (integrators/aov.cpp:95-122), three per record group
+#define MSK_MAX_AOV_GROUPS 8
+struct AovParams {
+    uint32_t n_groups;
+    float4 *rec[MSK_MAX_AOV_GROUPS];       // per sample {a, b, c, pos.x}, same indexing as PassParams::rec_a
+    uint32_t code[MSK_MAX_AOV_GROUPS];     // three 8-bit selectors: 0 none, 1 t, 2-4 p, 5-6 uv, 7-9 n, 10-12 sh.n
+};
+struct FilmOut { float *film; int32_t stride; int32_t ch[5]; };   // block channel c -> film channel ch[c] (or -1)
 
 // ------------------------------------------------------------------------------------------
 // traversal
@@ -560,7 +570,9 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
             if (!DIFFUSE_ONLY && sc.env_emitter >= 0) {
                 // depth 1: the camera ray left the scene.  depth > 1: the BSDF sample did; its MIS weight uses the NEE
                 // sample's record, which the reference does not re-query on this branch (path.cpp:90-95,103-108).
-                if (depth == 1) { if (!pp.hide_emitters) res = res + thr * emitter_radiance(tb, sc.env_emitter, wl); }
+                if (depth == 1) {
+                    if (!pp.hide_emitters && pp.max_depth != 0) res = res + thr * emitter_radiance(tb, sc.env_emitter, wl);   // path.cpp:33
+                }
                 else res = res + thr * emitter_radiance(tb, sc.env_emitter, wl) * mis_weight(bs_pdf, nee_pdf);
             }
             alive = false;
@@ -714,6 +726,13 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
             const size_t r = (((size_t) pt.z << 32) | pt.y) + (size_t) id.y * pt.w;
             pp.rec_a[r] = make_float4(X, Y, Z, px);
             pp.rec_b[r] = py;
+            if (!DIFFUSE_ONLY && pp.aov_rgb) {                             // aov.cpp:124-136: the sample before ray_weight
+                float x0, y0, z0;
+                spectrum_to_xyz(tb.cie, res, wl, &x0, &y0, &z0);
+                pp.aov_rgb[r] = make_float4(3.240479f * x0 + (-1.537150f * y0 + -0.498535f * z0),
+                                            -0.969256f * x0 + (1.875991f * y0 + 0.041556f * z0),
+                                            0.055648f * x0 + (-0.204043f * y0 + 1.057311f * z0), px);
+            }
         }
         // ---- in-place compaction of the survivors (wave ballot + prefix popcount)
         const unsigned long long m = __ballot(alive);
@@ -779,6 +798,66 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
         rc.count = n_out; rc.next_sample = first + got;
         rc.segments += n_out; rc.shadow_rays += n_shadow; rc.samples_done += n_done;
         pp.regions[wave] = rc;
+    }
+}
+
+// AOVIntegrator::sample's primary-hit channels (aov.cpp:89-122): runs after k_trace, picks the slots whose camera ray
+// has just been traced (depth 1) and writes their record groups.  A miss writes zeros.
+__global__ void __launch_bounds__(MSK_BLOCK)
+k_aov_primary(DeviceScene sc, PathState st, PassParams pp, AovParams ap) {
+    const uint32_t wave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
+    const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
+    if (wave >= pp.n_regions) return;
+    const uint32_t n_in = pp.regions[wave].count;
+    const size_t base = (size_t) wave * pp.region_size;
+    for (uint32_t c = lane; c < n_in; c += MSK_WAVE) {
+        const size_t i = base + c;
+        const uint4 id = st.id[i];
+        if ((id.w & MSK_DEPTH_MASK) != 1u) continue;
+        const float4 hit = st.hit[i];
+        float val[13];
+#pragma unroll
+        for (int k = 0; k < 13; ++k) val[k] = 0.f;
+        if (hit.x != MSK_INF_F) {
+            const uint32_t prim = __float_as_uint(hit.w) & MSK_PRIM_MASK;
+            const float4 a = sc.tri_verts[(size_t) prim * 3], b = sc.tri_verts[(size_t) prim * 3 + 1], cc = sc.tri_verts[(size_t) prim * 3 + 2];
+            const int4 mi = sc.mesh_info[__float_as_uint(a.w)];
+            const f3 p0 = mk3(a.x, a.y, a.z), p1 = mk3(b.x, b.y, b.z), p2 = mk3(cc.x, cc.y, cc.z);
+            const float b1 = hit.y, b2 = hit.z, b0 = 1.f - b1 - b2;                 // mesh.cpp:53-65
+            const f3 p = p0 * b0 + p1 * b1 + p2 * b2;
+            const f3 n = normalized(cross(p1 - p0, p2 - p0));
+            f3 ns = n;
+            float u = hit.y, v = hit.z;
+            if (mi.z & 2) {                                                         // mesh.cpp:68-71
+                const float4 ua = sc.tri_uvs[(size_t) prim * 2], ub = sc.tri_uvs[(size_t) prim * 2 + 1];
+                u = ua.x * b0 + ua.z * b1 + ub.x * b2; v = ua.y * b0 + ua.w * b1 + ub.y * b2;
+            }
+            if (mi.z & 1) {                                                         // mesh.cpp:81-96
+                const float4 na = sc.tri_normals[(size_t) prim * 3], nb = sc.tri_normals[(size_t) prim * 3 + 1],
+                             nc = sc.tri_normals[(size_t) prim * 3 + 2];
+                ns = normalized(mk3(na.x, na.y, na.z) * b0 + mk3(nb.x, nb.y, nb.z) * b1 + mk3(nc.x, nc.y, nc.z) * b2);
+            }
+            val[1] = hit.x; val[2] = p.x; val[3] = p.y; val[4] = p.z; val[5] = u; val[6] = v;
+            val[7] = n.x; val[8] = n.y; val[9] = n.z; val[10] = ns.x; val[11] = ns.y; val[12] = ns.z;
+        }
+        const uint32_t pix = id.z;
+        const uint64_t key = counter_key(pp.seed, pix, pp.sample_first + id.y * pp.sample_stride);
+        const float px = (float) (pix % (uint32_t) sc.width) + counter_pair(key, 0).x;
+        const uint4 pt = pp.pix_table[id.x];
+        const size_t r = (((size_t) pt.z << 32) | pt.y) + (size_t) id.y * pt.w;
+        for (uint32_t g = 0; g < ap.n_groups; ++g) {
+            const uint32_t code = ap.code[g];
+            float o[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t sel = (code >> (8 * k)) & 0xffu;
+                float x = 0.f;
+#pragma unroll
+                for (int q = 1; q < 13; ++q) x = sel == (uint32_t) q ? val[q] : x;
+                o[k] = x;
+            }
+            ap.rec[g][r] = make_float4(o[0], o[1], o[2], px);
+        }
     }
 }
 
@@ -896,7 +975,7 @@ k_resolve_blocks(DeviceScene sc, const BlockInfo *blocks, uint32_t n_blocks, con
 // by this rank), spiral_id gives the order.
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_film_put(DeviceScene sc, const BlockInfo *blocks, const int32_t *block_of, const uint32_t *spiral_id, int nbx, int nby,
-           int block_size, const float *block_buf, uint32_t buf_stride, float *film) {
+           int block_size, const float *block_buf, uint32_t buf_stride, FilmOut out) {
     const uint32_t gid = blockIdx.x * MSK_BLOCK + threadIdx.x;
     if (gid >= (uint32_t) (sc.width * sc.height)) return;
     const int x = (int) (gid % (uint32_t) sc.width), y = (int) (gid / (uint32_t) sc.width);
@@ -926,9 +1005,9 @@ k_film_put(DeviceScene sc, const BlockInfo *blocks, const int32_t *block_of, con
 #pragma unroll
         for (int c = 0; c < 5; ++c) acc[c] += src[c];
     }
-    float *o = film + (size_t) gid * 5;
+    float *o = out.film + (size_t) gid * out.stride;
 #pragma unroll
-    for (int c = 0; c < 5; ++c) o[c] = acc[c];
+    for (int c = 0; c < 5; ++c) if (out.ch[c] >= 0) o[out.ch[c]] = acc[c];
 }
 
 // records of listed pixels ([sample][pixel] on device) -> {X,Y,Z} + position, [pixel][sample]

@@ -68,7 +68,8 @@ public:
     virtual void put(const ImageBlock *block) = 0;
     virtual void set_destination_file(const std::string &filename) = 0;
     virtual void develop() = 0;
-    virtual std::vector<float> image() = 0;            // RGBA float, row-major
+    virtual std::vector<float> image() = 0;            // R,G,B,A (+ AOV channels) float, row-major
+    virtual std::vector<std::string> image_channels() const { return {"R", "G", "B", "A"}; }
     virtual const ImageBlock *storage() const = 0;
     const Vector2i &size() const { return m_size; }
     const Vector2i &crop_size() const { return m_crop_size; }
@@ -192,6 +193,7 @@ protected:
 
 class SamplingIntegrator : public Integrator {
 public:
+    virtual std::vector<std::string> aov_names() const { return {}; }   // integrator.cpp:28
     MSK_DECLARE_CLASS()
 protected:
     SamplingIntegrator(const Properties &props);   // integrator.cpp:18-24

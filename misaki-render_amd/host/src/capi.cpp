@@ -6,6 +6,8 @@
 namespace misaki {
 void path_fill_params(const Integrator *integ, const Sensor *sensor, msk_render_params &p);
 bool path_last_stats(const Integrator *integ, msk_stats &st);
+std::vector<std::string> integrator_aov_names(const Integrator *integ);
+std::vector<int32_t> integrator_aov_types(const Integrator *integ);
 }
 using namespace misaki;
 
@@ -66,6 +68,28 @@ int msk_host_render(msk_host_scene *h, float *film_xyzaw, float *rgba, const cha
         if (develop_to && *develop_to) { film->set_destination_file(develop_to); film->develop(); }
         if (stats) path_last_stats(scene->integrator(), *stats);
         return 0;
+    } catch (const std::exception &e) { return fail(e); }
+}
+
+// aov_names() of the scene's integrator, '\n'-separated; returns the number of names or -1
+int msk_host_aov_names(msk_host_scene *h, char *buf, size_t cap) {
+    try {
+        auto names = integrator_aov_names(h->scene->integrator());
+        std::string all;
+        for (auto &n : names) { all += n; all += '\n'; }
+        if (all.size() + 1 > cap) Throw("msk_host_aov_names: buffer too small");
+        std::memcpy(buf, all.c_str(), all.size() + 1);
+        return (int) names.size();
+    } catch (const std::exception &e) { return fail(e); }
+}
+
+// MSK_AOV_* of the "aov" integrator in order (what it passes to msk_gpu_render_aov); returns the count or -1
+int msk_host_aov_types(msk_host_scene *h, int32_t *out, size_t cap) {
+    try {
+        auto t = integrator_aov_types(h->scene->integrator());
+        if (t.size() > cap) Throw("msk_host_aov_types: buffer too small");
+        std::copy(t.begin(), t.end(), out);
+        return (int) t.size();
     } catch (const std::exception &e) { return fail(e); }
 }
 

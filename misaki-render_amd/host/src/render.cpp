@@ -296,17 +296,24 @@ public:
         if (!m_storage) Throw("HDRFilm::image(): the film was never prepared");
         const int w = m_storage->size().x, h = m_storage->size().y;
         const size_t cc = m_channels.size();
-        std::vector<float> out((size_t) w * h * 4);
+        const size_t oc = cc - 1;                        // R,G,B,A + the AOV channels (hdrfilm.cpp:52-59)
+        std::vector<float> out((size_t) w * h * oc);
         static const float M[9] = {3.240479f, -1.537150f, -0.498535f, -0.969256f, 1.875991f, 0.041556f, 0.055648f, -0.204043f, 1.057311f};
         for (int y = 0; y < h; ++y)
             for (int x = 0; x < w; ++x) {
                 const float *p = &m_storage->data()[((size_t) y * w + x) * cc];
                 const float weight = p[4], inv = weight != 0 ? 1.f / weight : 0.f;
-                float *o = &out[((size_t) y * w + x) * 4];
+                float *o = &out[((size_t) y * w + x) * oc];
                 for (int r = 0; r < 3; ++r) o[r] = (M[r * 3] * p[0] + (M[r * 3 + 1] * p[1] + M[r * 3 + 2] * p[2])) * inv;
                 o[3] = p[3] * inv;
+                for (size_t ch = 5; ch < cc; ++ch) o[ch - 1] = p[ch] * inv;       // hdrfilm.cpp:82-85
             }
         return out;
+    }
+    std::vector<std::string> image_channels() const override {
+        std::vector<std::string> names = {"R", "G", "B", "A"};
+        for (size_t i = 5; i < m_channels.size(); ++i) names.push_back(m_channels[i]);
+        return names;
     }
     void develop() override {                           // hdrfilm.cpp:92-112
         if (m_dest_file.empty()) Throw("Destination file not specified, cannot develop.");
@@ -318,10 +325,11 @@ public:
         Log(Info, "Developing \"{}\" ..", filename);
         std::vector<float> img = image();
         const int w = m_storage->size().x, h = m_storage->size().y;
-        if (ext == ".exr") write_exr(filename, w, h, {"R", "G", "B", "A"}, img.data());
+        const size_t oc = m_channels.size() - 1;
+        if (ext == ".exr") write_exr(filename, w, h, image_channels(), img.data());
         else if (ext == ".pfm") {
             std::vector<float> rgb((size_t) w * h * 3);
-            for (size_t i = 0; i < (size_t) w * h; ++i) for (int c = 0; c < 3; ++c) rgb[i * 3 + c] = img[i * 4 + c];
+            for (size_t i = 0; i < (size_t) w * h; ++i) for (int c = 0; c < 3; ++c) rgb[i * 3 + c] = img[i * oc + c];
             write_pfm(filename, w, h, 3, rgb.data());
         } else Throw("file_format \"{}\" is not supported by this build (use openexr or pfm)", m_file_format);
     }
@@ -770,17 +778,111 @@ private:
 MSK_IMPLEMENT_CLASS(PathTracer, MonteCarloIntegrator)
 MSK_REGISTER_INSTANCE(PathTracer, "path")
 
+// integrators/aov.cpp:19-144 — same plugin name, "aovs" string and nested-integrator convention; render() runs the
+// primary-hit channels and the nested path integrator on the MI355X in one job.
+class AOVIntegrator final : public MonteCarloIntegrator {
+public:
+    AOVIntegrator(const Properties &props) : MonteCarloIntegrator(props) {
+        m_device = props.int_("gpu_device", 0);
+        for (const std::string &token : string::tokenize(props.string("aovs", ""))) {
+            std::vector<std::string> item = string::tokenize(token, ":");
+            if (item.size() != 2 || item[0].empty() || item[1].empty()) {
+                Log(Warn, "Invalid AOV specification: require <name>:<type> pair");
+                continue;
+            }
+            auto add = [&](int32_t type, std::initializer_list<const char *> suffixes) {
+                m_types.push_back(type);
+                for (const char *sfx : suffixes) m_names.push_back(item[0] + sfx);
+            };
+            if (item[1] == "depth") add(MSK_AOV_DEPTH, {""});
+            else if (item[1] == "position") add(MSK_AOV_POSITION, {".X", ".Y", ".Z"});
+            else if (item[1] == "uv") add(MSK_AOV_UV, {".U", ".V"});
+            else if (item[1] == "geo_normal") add(MSK_AOV_GEO_NORMAL, {".X", ".Y", ".Z"});
+            else if (item[1] == "sh_normal") add(MSK_AOV_SH_NORMAL, {".X", ".Y", ".Z"});
+            else Throw("Invalid AOV type \"{}\"!", item[1]);
+        }
+        for (auto &kv : props.objects()) {
+            auto *integrator = dynamic_cast<SamplingIntegrator *>(kv.second.get());
+            if (!integrator) Throw("Child objects must be of type 'SamplingIntegrator'!");
+            auto *path = dynamic_cast<PathTracer *>(integrator);
+            if (!path) Throw("aov: nested integrator \"{}\" is not the \"path\" integrator: not supported by the GPU back end", kv.first);
+            if (m_path) Throw("aov: at most one nested integrator is supported by the GPU back end");
+            m_path = path;
+            m_types.push_back(MSK_AOV_PATH_RGBA);
+            for (auto &name : integrator->aov_names()) m_names.push_back(kv.first + "." + name);
+            for (const char *sfx : {".R", ".G", ".B", ".A"}) m_names.push_back(kv.first + sfx);
+        }
+        if (m_names.empty()) Log(Warn, "No AOVs were specified!");
+    }
+    ~AOVIntegrator() { if (m_ctx) msk_gpu_shutdown(m_ctx); }
+    std::vector<std::string> aov_names() const override { return m_names; }
+    const std::vector<int32_t> &aov_types() const { return m_types; }
+    void fill_params(const Sensor *sensor, msk_render_params &p) const {
+        if (m_path) m_path->fill_params(sensor, p);
+        else {
+            std::memset(&p, 0, sizeof p);
+            p.spp = (uint32_t) sensor->sampler()->sample_count(); p.seed = sensor->sampler()->base_seed();
+            p.rng_mode = MSK_RNG_COUNTER; p.rr_depth = 5; p.max_depth = -1; p.block_stride = 1; p.sample_stride = 1;
+        }
+        p.block_size = (int32_t) m_block_size;      // the tile loop is the outer integrator's (integrator.cpp:45)
+    }
+
+    bool render(Scene *scene, Sensor *sensor) override {           // integrator.cpp:31-80
+        ref<Film> film = sensor->film();
+        const Vector2i size = film->size();
+        std::vector<std::string> channels = {"X", "Y", "Z", "A", "W"};
+        channels.insert(channels.end(), m_names.begin(), m_names.end());
+        film->prepare(channels);
+        Log(Info, "Starting render job ({}x{}, {} sample)", size.x, size.y, sensor->sampler()->sample_count());
+        FlatScene flat;
+        flatten_scene(scene, sensor, flat);
+        fill_params(sensor, flat.params);
+        if (!m_ctx && msk_gpu_init(&m_device, 1, &m_ctx) != MSK_OK) Throw("{}", msk_gpu_last_error(nullptr));
+        msk_scene *gs = nullptr;
+        if (msk_gpu_scene_create(m_ctx, &flat.desc, &gs) != MSK_OK) Throw("{}", msk_gpu_last_error(m_ctx));
+        ref<ImageBlock> whole = new ImageBlock(size, channels.size());
+        msk_stats st;
+        const int rc = msk_gpu_render_aov(gs, &flat.params, m_types.data(), (uint32_t) m_types.size(), whole->data().data(), &st);
+        msk_gpu_scene_destroy(gs);
+        if (rc != MSK_OK) Throw("{}", msk_gpu_last_error(m_ctx));
+        film->put(whole);
+        m_last_stats = st;
+        Log(Info, "Rendering finished. (device {} ms)", st.ms_total);
+        return true;
+    }
+    const msk_stats &last_stats() const { return m_last_stats; }
+    MSK_DECLARE_CLASS()
+private:
+    std::vector<int32_t> m_types;
+    std::vector<std::string> m_names;
+    ref<PathTracer> m_path;
+    int m_device = 0;
+    msk_ctx *m_ctx = nullptr;
+    msk_stats m_last_stats{};
+};
+MSK_IMPLEMENT_CLASS(AOVIntegrator, MonteCarloIntegrator)
+MSK_REGISTER_INSTANCE(AOVIntegrator, "aov")
+
+std::vector<int32_t> integrator_aov_types(const Integrator *integ) {
+    auto *av = dynamic_cast<const AOVIntegrator *>(integ);
+    return av ? av->aov_types() : std::vector<int32_t>{};
+}
+std::vector<std::string> integrator_aov_names(const Integrator *integ) {
+    auto *si = dynamic_cast<const SamplingIntegrator *>(integ);
+    return si ? si->aov_names() : std::vector<std::string>{};
+}
+
 // used by capi.cpp
 void path_fill_params(const Integrator *integ, const Sensor *sensor, msk_render_params &p) {
+    if (auto *av = dynamic_cast<const AOVIntegrator *>(integ)) { av->fill_params(sensor, p); return; }
     auto *pt = dynamic_cast<const PathTracer *>(integ);
-    if (!pt) Throw("the scene's integrator is not the GPU path integrator");
+    if (!pt) Throw("the scene's integrator is not a GPU integrator (\"path\" or \"aov\")");
     pt->fill_params(sensor, p);
 }
 bool path_last_stats(const Integrator *integ, msk_stats &st) {
-    auto *pt = dynamic_cast<const PathTracer *>(integ);
-    if (!pt) return false;
-    st = pt->last_stats();
-    return true;
+    if (auto *pt = dynamic_cast<const PathTracer *>(integ)) { st = pt->last_stats(); return true; }
+    if (auto *av = dynamic_cast<const AOVIntegrator *>(integ)) { st = av->last_stats(); return true; }
+    return false;
 }
 
 }  // namespace misaki

@@ -30,6 +30,8 @@ def load():
         lib.msk_host_flatten.argtypes = [vp, C.POINTER(abi.SceneDesc), C.POINTER(abi.RenderParams)]
         lib.msk_host_render.argtypes = [vp, vp, vp, C.c_char_p, C.POINTER(abi.Stats)]
         lib.msk_host_film_size.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.msk_host_aov_names.argtypes = [vp, C.c_char_p, C.c_size_t]
+        lib.msk_host_aov_types.argtypes = [vp, vp, C.c_size_t]
         lib.msk_host_srgb_model_fetch.argtypes = [vp, vp]
         lib.msk_host_write_image.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, vp]
         lib.msk_host_set_log_level.argtypes = [C.c_int]
@@ -70,10 +72,26 @@ class HostScene:
         _check(self.lib.msk_host_flatten(self.h, C.byref(d), C.byref(p)))
         return HostFlat(d, p, self)
 
+    def aov_names(self):
+        buf = C.create_string_buffer(1 << 16)
+        n = self.lib.msk_host_aov_names(self.h, buf, len(buf))
+        if n < 0:
+            _check(n)
+        return [s for s in buf.value.decode().split("\n") if s]
+
+    def aov_types(self):
+        buf = np.zeros(64, np.int32)
+        n = self.lib.msk_host_aov_types(self.h, buf.ctypes.data_as(C.c_void_p), len(buf))
+        if n < 0:
+            _check(n)
+        return [int(x) for x in buf[:n]]
+
     def render(self, develop_to=None):
-        """scene->integrator()->render(scene, sensor) on the GPU -> (film[H,W,5], rgba[H,W,4], Stats)."""
+        """scene->integrator()->render(scene, sensor) on the GPU -> (film[H,W,5+C], image[H,W,4+C], Stats);
+        C = the integrator's AOV channel count (0 for "path")."""
         w, h, _ = self.film_size()
-        film, rgba, st = np.zeros((h, w, 5), np.float32), np.zeros((h, w, 4), np.float32), abi.Stats()
+        c = len(self.aov_names())
+        film, rgba, st = np.zeros((h, w, 5 + c), np.float32), np.zeros((h, w, 4 + c), np.float32), abi.Stats()
         _check(self.lib.msk_host_render(self.h, film.ctypes.data_as(C.c_void_p), rgba.ctypes.data_as(C.c_void_p),
                                         (develop_to or "").encode(), C.byref(st)))
         return film, rgba, st

@@ -48,6 +48,22 @@
  *   D6       blocks are added to the film in spiral-id order (the reference
  *            adds them in arrival order under a mutex, hdrfilm.cpp:43-46).
  *   D7       transcendental functions: rule R3 of oracle_math.h.
+ *   D8       ConstantBackgroundEmitter::sample_direct evaluates its radiance on a
+ *            default-constructed interaction whose wavelengths are uninitialised
+ *            (constant.cpp:68-71); the wavelengths of the reference point are
+ *            used, as AreaLight::sample_direct does (area.cpp:35-36).
+ *   D9       rough conductor / rough dielectric / twosided are not in the
+ *            reference's build and need small repairs to compile
+ *            (roughdielectric.cpp:67 multiplies an Eigen float vector by a double;
+ *            Color3 weights become 4-wavelength spectra).  They are restated as
+ *            written otherwise, including: only the GGX branches exist
+ *            (microfacet.h:115-118,135-137 leave Beckmann empty); "sample_visible"
+ *            changes the weight but still draws m from D(m)cos (microfacet.h:19-41);
+ *            sample() omits specular_transmittance (roughdielectric.cpp:95-100);
+ *            a BSDF sample that leaves the scene keeps the NEE record for its MIS
+ *            weight (path.cpp:90-95,103-108).  These paths are pinned by closed-form
+ *            properties (tests/test_rough_*.py, tests/test_environment.py), not by
+ *            reference outputs: "parity unpinned" applies to them.
  */
 #include "oracle_math.h"
 #include "msk_gpu.h"
@@ -976,8 +992,14 @@ static std::vector<BlockDesc> spiral_blocks(int w, int h, int block_size) {
 // ===========================================================================
 // a2  render_sample (integrator.cpp:103-126), returns the {X,Y,Z} handed to put
 // ===========================================================================
+struct AovSpec {
+    std::vector<int32_t> types;
+    int channels = 0;
+    static int width(int32_t t) { static const int w[6] = {1, 3, 2, 3, 3, 4}; return t >= 0 && t < 6 ? w[t] : -1; }
+};
+// integrators/aov.cpp:87-144 (aov == nullptr: the plain "path" integrator); aovs receives spec.channels floats
 static void render_sample(const Scene &sc, Sampler &sampler, V2 pos, const msk_render_params &prm,
-                          Counters &cnt, V2 *position_sample, float xyz[3]) {
+                          Counters &cnt, V2 *position_sample, float xyz[3], const AovSpec *aov = nullptr, float *aovs = nullptr) {
     float jx, jy; sampler.pair(0, &jx, &jy);
     *position_sample = V2{pos.x + jx, pos.y + jy};
     float wavelength_sample = sampler.single(1, 0);
@@ -985,12 +1007,41 @@ static void render_sample(const Scene &sc, Sampler &sampler, V2 pos, const msk_r
     S4 wl, ray_weight;
     Ray ray = camera_ray(sc, wavelength_sample, *position_sample, &wl, &ray_weight);
     ++cnt.samples;
-    S4 result = path_sample(sc, sampler, ray, wl, prm, cnt) * ray_weight;
+    S4 result;
+    if (!aov) {
+        result = path_sample(sc, sampler, ray, wl, prm, cnt);
+    } else {
+        result = s4(0.f);                                          // aov.cpp:91 leaves it uninitialised without a nested integrator
+        Interaction si = compute_interaction(sc, ray, closest_hit(sc, ray));   // aov.cpp:89
+        const bool hit = si.valid();
+        for (int32_t type : aov->types) {
+            switch (type) {
+                case MSK_AOV_DEPTH: *aovs++ = hit ? si.t : 0.f; break;
+                case MSK_AOV_POSITION: *aovs++ = hit ? si.p.x : 0.f; *aovs++ = hit ? si.p.y : 0.f; *aovs++ = hit ? si.p.z : 0.f; break;
+                case MSK_AOV_UV: *aovs++ = hit ? si.uv.x : 0.f; *aovs++ = hit ? si.uv.y : 0.f; break;
+                case MSK_AOV_GEO_NORMAL: *aovs++ = hit ? si.n.x : 0.f; *aovs++ = hit ? si.n.y : 0.f; *aovs++ = hit ? si.n.z : 0.f; break;
+                case MSK_AOV_SH_NORMAL: *aovs++ = hit ? si.sh.n.x : 0.f; *aovs++ = hit ? si.sh.n.y : 0.f; *aovs++ = hit ? si.sh.n.z : 0.f; break;
+                case MSK_AOV_PATH_RGBA: {
+                    S4 spec = path_sample(sc, sampler, ray, wl, prm, cnt);
+                    float c[3]; spectrum_to_xyz(sc, spec, wl, c);
+                    // core/spectrum.h:138-143 xyz_to_srgb (Eigen 3x3 * vector: a0 + (a1 + a2) per row)
+                    *aovs++ = 3.240479f * c[0] + (-1.537150f * c[1] + -0.498535f * c[2]);
+                    *aovs++ = -0.969256f * c[0] + (1.875991f * c[1] + 0.041556f * c[2]);
+                    *aovs++ = 0.055648f * c[0] + (-0.204043f * c[1] + 1.057311f * c[2]);
+                    *aovs++ = 1.f;
+                    result = spec;
+                } break;
+            }
+        }
+    }
+    result = result * ray_weight;
     spectrum_to_xyz(sc, result, wl, xyz);
 }
 
 // a1/a2  SamplingIntegrator::render + render_block (integrator.cpp:31-101)
-static void render(const Scene &sc, const msk_render_params &prm, float *film, Counters *total, int n_threads) {
+static void render(const Scene &sc, const msk_render_params &prm, float *film, Counters *total, int n_threads,
+                   const AovSpec *aov = nullptr) {
+    const int n_ch = 5 + (aov ? aov->channels : 0);
     const int W = sc.film.width, H = sc.film.height;
     std::vector<BlockDesc> blocks = spiral_blocks(W, H, prm.block_size);
     std::vector<ImageBlock> done(blocks.size());
@@ -1005,8 +1056,9 @@ static void render(const Scene &sc, const msk_render_params &prm, float *film, C
             if (id % bstride != prm.block_first) continue;
             const BlockDesc &bd = blocks[id];
             ImageBlock blk;
-            blk.off_x = bd.off_x; blk.off_y = bd.off_y;
+            blk.off_x = bd.off_x; blk.off_y = bd.off_y; blk.channels = n_ch;
             blk.init(bd.size_x, bd.size_y, &sc.film, true);
+            std::vector<float> v((size_t) n_ch);
             Sampler sampler; sampler.mode = prm.rng_mode;
             if (prm.rng_mode == MSK_RNG_PCG_BLOCK)                // D2; independent.cpp:20-26
                 sampler.rng.seed(0x853c49e6748fea9bULL + prm.seed, 0xda3e39cb94b95bdbULL);
@@ -1017,10 +1069,10 @@ static void render(const Scene &sc, const msk_render_params &prm, float *film, C
                         if (s % sstride != prm.sample_first) continue;
                         if (prm.rng_mode == MSK_RNG_COUNTER)
                             sampler.key = counter_key(prm.seed, (uint32_t) ((y + bd.off_y) * W + (x + bd.off_x)), s);
-                        V2 ps; float v[5];
-                        render_sample(sc, sampler, pos, prm, cnt, &ps, v);
+                        V2 ps;
+                        render_sample(sc, sampler, pos, prm, cnt, &ps, v.data(), aov, v.data() + 5);
                         v[3] = 1.f; v[4] = 1.f;                    // integrator.cpp:119-123
-                        blk.put(ps, v);
+                        blk.put(ps, v.data());
                     }
                 }
             done[id] = std::move(blk);
@@ -1031,7 +1083,7 @@ static void render(const Scene &sc, const msk_render_params &prm, float *film, C
     std::vector<std::thread> pool;
     for (int i = 0; i < std::max(1, n_threads); ++i) pool.emplace_back(worker);
     for (auto &t : pool) t.join();
-    std::fill(film, film + (size_t) W * H * 5, 0.f);               // hdrfilm.cpp:37-39
+    std::fill(film, film + (size_t) W * H * n_ch, 0.f);            // hdrfilm.cpp:37-39
     for (size_t id = 0; id < blocks.size(); ++id)                  // D6
         if (!done[id].data.empty()) film_put(film, W, H, done[id]);
 }
@@ -1059,6 +1111,20 @@ int msk_oracle_render(void *s, const msk_render_params *prm, float *film, msk_st
         stats->samples = c.samples; stats->segments = c.segments; stats->shadow_rays = c.shadow_rays;
         stats->ms_total = std::chrono::duration<float, std::milli>(t1 - t0).count();
     }
+    return 0;
+}
+
+int msk_oracle_render_aov(void *s, const msk_render_params *prm, const int32_t *aov_types, uint32_t n_aovs, float *film,
+                          msk_stats *stats, int n_threads) {
+    AovSpec spec;
+    for (uint32_t i = 0; i < n_aovs; ++i) {
+        int w = AovSpec::width(aov_types[i]);
+        if (w < 0) return -1;
+        spec.types.push_back(aov_types[i]); spec.channels += w;
+    }
+    Counters c;
+    render(*(Scene *) s, *prm, film, &c, n_threads, &spec);
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->samples = c.samples; stats->segments = c.segments; stats->shadow_rays = c.shadow_rays; }
     return 0;
 }
 

@@ -23,6 +23,7 @@ class Oracle:
         lib.msk_oracle_scene_destroy.argtypes = [vp]
         lib.msk_oracle_set_bvh.argtypes = [vp, C.c_int]
         lib.msk_oracle_render.argtypes = [vp, C.POINTER(abi.RenderParams), vp, C.POINTER(abi.Stats), C.c_int]
+        lib.msk_oracle_render_aov.argtypes = [vp, C.POINTER(abi.RenderParams), vp, C.c_uint32, vp, C.POINTER(abi.Stats), C.c_int]
         lib.msk_oracle_sample_pixels.argtypes = [vp, C.POINTER(abi.RenderParams), C.c_uint64, vp, vp, vp]
         lib.msk_oracle_trace_closest.argtypes = [vp, C.c_uint64, vp, vp]
         lib.msk_oracle_trace_any.argtypes = [vp, C.c_uint64, vp, vp]
@@ -172,6 +173,16 @@ class OracleScene:
         film = np.zeros((d.film.height, d.film.width, 5), np.float32)
         st = self.abi.Stats()
         rc = self.orc.lib.msk_oracle_render(self.h, C.byref(params), _p(film), C.byref(st), threads)
+        assert rc == 0
+        return film, st
+
+    def render_aov(self, params, aov_types, threads=8):
+        d = self.flat.desc
+        types = np.ascontiguousarray(aov_types, np.int32)
+        n_ch = sum(self.abi.AOV_WIDTH[t] for t in types)
+        film = np.zeros((d.film.height, d.film.width, 5 + n_ch), np.float32)
+        st = self.abi.Stats()
+        rc = self.orc.lib.msk_oracle_render_aov(self.h, C.byref(params), _p(types), len(types), _p(film), C.byref(st), threads)
         assert rc == 0
         return film, st
 
