@@ -40,7 +40,14 @@ struct Built {
     std::vector<float> tris;    // 16 floats per triangle, leaf order
     uint32_t root_ref = 0;      // packed child ref of the root
     int max_depth = 0;
+    // 4-wide form of the same tree for scenes that do not fit LDS (collapse4): 32 floats (128 B = one L2 line) per node,
+    //   [lo.x x4] [lo.y x4] [lo.z x4] [hi.x x4] [hi.y x4] [hi.z x4] [child refs x4 (uint bits)] [unused]
+    // child ref as above, or kEmpty4 for an unused slot.  Same padded boxes, same leaves, same triangles.
+    std::vector<float> nodes4;
+    uint32_t root_ref4 = 0;
+    int max_depth4 = 0;
 };
+static constexpr uint32_t kEmpty4 = 0xfffffffeu;
 
 struct Builder {
     const float *pos;           // 9 floats per triangle: p0 p1 p2 (scene-global order)
@@ -163,6 +170,63 @@ static inline Built build(const float *pos, uint32_t n) {
         t[12] = ng[0]; t[13] = ng[1]; t[14] = ng[2]; t[15] = 0;
     }
     return out;
+}
+
+// Collapses the binary tree into 4-wide nodes: a node's two children are replaced by their own children, largest
+// surface area first, until four slots are filled or only leaves remain.
+struct Collapser {
+    const std::vector<float> &n2;
+    std::vector<float> out;
+    int max_depth = 0;
+    struct Slot { uint32_t ref; float lo[3], hi[3]; };
+    static float area(const Slot &s) {
+        float dx = s.hi[0] - s.lo[0], dy = s.hi[1] - s.lo[1], dz = s.hi[2] - s.lo[2];
+        return 2.f * (dx * dy + dy * dz + dz * dx);
+    }
+    void children(uint32_t node, Slot *a, Slot *b) const {
+        const float *n = &n2[(size_t) node * 16];
+        uint32_t meta[4]; std::memcpy(meta, &n[12], 16);
+        a->ref = meta[0]; b->ref = meta[1];
+        a->lo[0] = n[0]; a->lo[1] = n[1]; a->lo[2] = n[2]; a->hi[0] = n[3]; a->hi[1] = n[4]; a->hi[2] = n[5];
+        b->lo[0] = n[6]; b->lo[1] = n[7]; b->lo[2] = n[8]; b->hi[0] = n[9]; b->hi[1] = n[10]; b->hi[2] = n[11];
+    }
+    uint32_t collapse(uint32_t node, int depth) {
+        max_depth = std::max(max_depth, depth);
+        Slot s[4]; int ns = 2;
+        children(node, &s[0], &s[1]);
+        while (ns < 4) {
+            int best = -1; float best_area = -1.f;
+            for (int i = 0; i < ns; ++i)
+                if (!(s[i].ref & 0x80000000u) && area(s[i]) > best_area) { best = i; best_area = area(s[i]); }
+            if (best < 0) break;
+            Slot a, b; children(s[best].ref, &a, &b);
+            s[best] = a; s[ns++] = b;
+        }
+        const uint32_t me = (uint32_t) (out.size() / 32);
+        out.resize(out.size() + 32, 0.f);
+        uint32_t refs[4];
+        for (int i = 0; i < 4; ++i) {
+            if (i >= ns) refs[i] = kEmpty4;
+            else if (s[i].ref & 0x80000000u) refs[i] = s[i].ref;
+            else refs[i] = collapse(s[i].ref, depth + 1);
+        }
+        float *o = &out[(size_t) me * 32];
+        for (int i = 0; i < 4; ++i)
+            for (int a = 0; a < 3; ++a) {
+                o[a * 4 + i] = i < ns ? s[i].lo[a] : 0.f;
+                o[12 + a * 4 + i] = i < ns ? s[i].hi[a] : 0.f;
+            }
+        std::memcpy(&o[24], refs, 16);
+        return me;
+    }
+};
+static inline void collapse4(Built &b) {
+    b.nodes4.clear(); b.root_ref4 = b.root_ref; b.max_depth4 = 0;
+    if (b.root_ref & 0x80000000u) return;            // a single leaf: nothing to collapse
+    Collapser c{b.nodes, {}, 0};
+    b.root_ref4 = c.collapse(b.root_ref, 1);
+    b.nodes4 = std::move(c.out);
+    b.max_depth4 = c.max_depth;
 }
 
 }  // namespace mskbvh

@@ -55,13 +55,15 @@ struct DevBuf {
     template <typename T> T *as() const { return (T *) p; }
 };
 
+static uint32_t env_u32(const char *name, uint32_t def);
 struct Workspace;
 struct msk_scene {
     msk_ctx *ctx = nullptr;
     Workspace *ws = nullptr;           // render buffers, kept between calls (hipMalloc/hipFree of GBs costs milliseconds)
     DeviceScene dev;
-    DevBuf nodes, tris, tri_verts, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
+    DevBuf nodes, nodes4, tris, tri_verts, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
     bool lds_scene = false, lds_tables = false, all_diffuse = true;
+    int trace_mode = 0;                // 0 binary tree in LDS, 1 binary tree in HBM/L2, 2 4-wide tree in HBM/L2
     size_t trace_lds_bytes = 0, shade_lds_bytes = 0;
     int bvh_depth = 0;
     uint32_t n_tris = 0;
@@ -295,6 +297,17 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     const size_t lds_cap = getenv("MSK_LDS_SCENE_KB") ? (size_t) atoi(getenv("MSK_LDS_SCENE_KB")) * 1024 : 48 * 1024;
     s->lds_scene = scene_bytes <= lds_cap && stack_bytes + scene_bytes <= 64 * 1024;
     s->trace_lds_bytes = stack_bytes + (s->lds_scene ? scene_bytes : 0);
+    s->trace_mode = s->lds_scene ? 0 : 1;
+    if (!s->lds_scene && env_u32("MSK_WIDE_BVH", 1) && !(bvh.root_ref & MSK_LEAF_BIT)) {
+        // the tree stays in HBM/L2: walk it four children at a time, one 128-byte line per visit
+        mskbvh::collapse4(bvh);
+        hipError_t e4 = s->nodes4.upload(bvh.nodes4);
+        if (e4 != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(e4)); }
+        ds.nodes4 = s->nodes4.as<float4>(); ds.root_ref4 = bvh.root_ref4;
+        ds.stack_entries = (uint32_t) ((3 * bvh.max_depth4 + 2 + 3) & ~3);     // up to three pushes per level
+        s->trace_lds_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4;
+        s->trace_mode = 2;
+    }
     // LDS plan of k_shade_gen: the small lookup tables (tri_verts, mesh/bsdf/emitter records, cdf, d65, cie)
     const size_t table_bytes = ((size_t) ds.n_tris * 3 + ds.n_meshes + ds.n_bsdfs * MSK_BSDF_F4 + ds.n_emitters * 2 +
                                 (ds.n_emitters * 95 + 3) / 4 + (ds.cdf_len + 3) / 4 + 72) * 16;
@@ -397,8 +410,9 @@ void free_workspace(msk_scene *scene) { delete scene->ws; scene->ws = nullptr; }
 
 static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st, const PassParams &pp) {
     const uint32_t grid = (pp.n_regions * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
-    if (sc->lds_scene) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp);
-    else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp);
+    if (sc->trace_mode == 0) hipLaunchKernelGGL(k_trace<0>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp);
+    else if (sc->trace_mode == 1) hipLaunchKernelGGL(k_trace<1>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp);
+    else hipLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp);
 }
 
 // Renders the samples of `pix` (pass pixel table, host) into records; leaves records on device.
@@ -779,11 +793,14 @@ static int trace_batch(msk_scene *scene, uint64_t n, const float *rays, float *o
     const uint32_t grid = (uint32_t) std::min<uint64_t>((n + MSK_BLOCK - 1) / MSK_BLOCK, 4096);
     float4 *oh = out_any ? nullptr : d_out.as<float4>();
     uint8_t *oa = out_any ? d_out.as<uint8_t>() : nullptr;
-    if (scene->lds_scene)
-        hipLaunchKernelGGL(k_trace_batch<true>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
+    if (scene->trace_mode == 0)
+        hipLaunchKernelGGL(k_trace_batch<0>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
+                           d_rays.as<float4>(), n, oh, oa);
+    else if (scene->trace_mode == 1)
+        hipLaunchKernelGGL(k_trace_batch<1>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
                            d_rays.as<float4>(), n, oh, oa);
     else
-        hipLaunchKernelGGL(k_trace_batch<false>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
+        hipLaunchKernelGGL(k_trace_batch<2>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
                            d_rays.as<float4>(), n, oh, oa);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -34,6 +34,8 @@ namespace msk {
 
 struct DeviceScene {
     const float4 *nodes;        // 4 x float4 per node (msk_bvh.h)
+    const float4 *nodes4;       // 8 x float4 per 4-wide node, or nullptr (scenes whose BVH is staged in LDS use `nodes`)
+    uint32_t root_ref4;
     const float4 *tris;         // 4 x float4 per triangle, leaf order
     const float4 *tri_verts;    // 3 x float4 per triangle, scene-global order: p0|mesh p1|- p2|-
     const float4 *tri_normals;  // 3 x float4 per triangle (n0 n1 n2) or nullptr
@@ -203,6 +205,68 @@ MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict
     return false;
 }
 
+// The same traversal over the 4-wide nodes of msk_bvh.h (one 128-byte line per visit, half the dependent round trips
+// of the binary tree); used when the tree lives in HBM/L2.  Hit selection is by (t, prim), so the result is the binary
+// tree's, bit for bit.
+#define MSK_EMPTY4 0xfffffffeu
+template <bool ANY>
+MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restrict__ tris, uint32_t root_ref,
+                       uint32_t n_tris, f3 o, f3 d, float tmin, float tmax, uint32_t *stack, float *best_t, float *best_u,
+                       float *best_v, uint32_t *best_prim) {
+    float bt = tmax, bu = 0.f, bv = 0.f;
+    uint32_t bp = MSK_NO_PRIM;
+    *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
+    if (n_tris == 0) return false;
+    const f3 idir = mk3(fminf(fmaxf(1.f / d.x, -1e25f), 1e25f), fminf(fmaxf(1.f / d.y, -1e25f), 1e25f),
+                        fminf(fmaxf(1.f / d.z, -1e25f), 1e25f));
+    const f3 oi = mk3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
+    int sp = 0;
+    uint32_t cur = root_ref;
+    const uint32_t DONE = 0xffffffffu;
+    while (cur != DONE) {
+        while (!(cur & MSK_LEAF_BIT)) {
+            const float4 *n = nodes + (size_t) cur * 8;
+            const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], rf = n[6];
+            float t0, t1, t2, t3;
+            const bool h0 = box_test(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, idir, oi, tmin, bt, &t0);
+            const bool h1 = box_test(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, idir, oi, tmin, bt, &t1);
+            const bool h2 = box_test(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, idir, oi, tmin, bt, &t2);
+            const bool h3 = box_test(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, idir, oi, tmin, bt, &t3);
+            uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
+            // misses and empty slots sort to the end
+            t0 = (h0 && r0 != MSK_EMPTY4) ? t0 : MSK_INF_F; t1 = (h1 && r1 != MSK_EMPTY4) ? t1 : MSK_INF_F;
+            t2 = (h2 && r2 != MSK_EMPTY4) ? t2 : MSK_INF_F; t3 = (h3 && r3 != MSK_EMPTY4) ? t3 : MSK_INF_F;
+#define MSK_CSWAP(ta, ra, tb, rb) { const bool s_ = tb < ta; const float tt_ = s_ ? tb : ta; const uint32_t rr_ = s_ ? rb : ra; \
+                                    tb = s_ ? ta : tb; rb = s_ ? ra : rb; ta = tt_; ra = rr_; }
+            MSK_CSWAP(t0, r0, t1, r1) MSK_CSWAP(t2, r2, t3, r3) MSK_CSWAP(t0, r0, t2, r2) MSK_CSWAP(t1, r1, t3, r3) MSK_CSWAP(t1, r1, t2, r2)
+#undef MSK_CSWAP
+            if (t0 != MSK_INF_F) {
+                // nearest child next, the others on the stack, farthest first
+                if (t3 != MSK_INF_F) { stack[sp * MSK_BLOCK] = r3; sp += 1; }
+                if (t2 != MSK_INF_F) { stack[sp * MSK_BLOCK] = r2; sp += 1; }
+                if (t1 != MSK_INF_F) { stack[sp * MSK_BLOCK] = r1; sp += 1; }
+                cur = r0;
+            } else if (sp > 0) { sp -= 1; cur = stack[sp * MSK_BLOCK]; }
+            else { cur = DONE; break; }
+        }
+        if (cur == DONE) break;
+        const uint32_t first = (cur & 0x7fffffffu) >> 5, cnt = cur & 31u;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const float4 *q = tris + (size_t) (first + i) * 4;
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            float t, u, v;
+            if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v)) {
+                if (ANY) return true;
+                const uint32_t prim = __float_as_uint(q0.w);
+                if (t < bt || (t == bt && prim < bp)) { bt = t; bu = u; bv = v; bp = prim; }
+            }
+        }
+        if (sp > 0) { sp -= 1; cur = stack[sp * MSK_BLOCK]; } else cur = DONE;
+    }
+    *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
+    return false;
+}
+
 struct TraceLds {
     const float4 *nodes, *tris;
 };
@@ -233,9 +297,18 @@ MSK_DEV TraceLds stage_scene(const DeviceScene &sc, float4 *lds, bool use_lds) {
 // between the phases — the compiler otherwise runs one side of a divergent region past the other's writes.
 #define MSK_HIT_UNOCCLUDED 0x80000000u
 #define MSK_PRIM_MASK 0x7fffffffu
-template <bool LDS_SCENE>
+// MODE 0: binary tree staged in LDS; 1: binary tree in HBM/L2; 2: 4-wide tree in HBM/L2
+template <int MODE, bool ANY>
+MSK_DEV bool traverse_scene(const DeviceScene &sc, const TraceLds &g, f3 o, f3 d, float tmin, float tmax, uint32_t *stack,
+                            float *bt, float *bu, float *bv, uint32_t *bp) {
+    if (MODE == 2) return traverse4<ANY>(sc.nodes4, g.tris, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+    return traverse<ANY>(g.nodes, g.tris, sc.root_ref, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+}
+
+template <int MODE>
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_trace(DeviceScene sc, PathState st, PassParams pp) {
+    constexpr bool LDS_SCENE = MODE == 0;
     extern __shared__ float4 lds_dyn[];
     uint32_t *stack_base = (uint32_t *) lds_dyn;                         // stack_entries * MSK_BLOCK words
     float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
@@ -255,21 +328,20 @@ k_trace(DeviceScene sc, PathState st, PassParams pp) {
         uint32_t unocc = 0;
         if (fl & MSK_FLAG_SHADOW) {
             const float4 s = st.sh[i];
-            const bool occ = traverse<true>(g.nodes, g.tris, sc.root_ref, sc.n_tris, o, mk3(s.x, s.y, s.z), ro.w, s.w,
-                                            stack, &bt, &bu, &bv, &bp);
+            const bool occ = traverse_scene<MODE, true>(sc, g, o, mk3(s.x, s.y, s.z), ro.w, s.w, stack, &bt, &bu, &bv, &bp);
             unocc = occ ? 0u : MSK_HIT_UNOCCLUDED;
         }
-        traverse<false>(g.nodes, g.tris, sc.root_ref, sc.n_tris, o, mk3(rd.x, rd.y, rd.z), ro.w, rd.w, stack,
-                        &bt, &bu, &bv, &bp);
+        traverse_scene<MODE, false>(sc, g, o, mk3(rd.x, rd.y, rd.z), ro.w, rd.w, stack, &bt, &bu, &bv, &bp);
         const bool valid = (bp != MSK_NO_PRIM) && (bt != rd.w);           // scene.cpp:234 tfar != maxt
         st.hit[i] = make_float4(valid ? bt : MSK_INF_F, bu, bv, __uint_as_float((valid ? bp : MSK_PRIM_MASK) | unocc));
     }
 }
 
 // batch entry points for the sub-stage parity tests (msk_gpu_trace_closest / _any)
-template <bool LDS_SCENE>
+template <int MODE>
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_trace_batch(DeviceScene sc, const float4 *rays, uint64_t n, float4 *out_hit, uint8_t *out_any) {
+    constexpr bool LDS_SCENE = MODE == 0;
     extern __shared__ float4 lds_dyn[];
     uint32_t *stack_base = (uint32_t *) lds_dyn;
     float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
@@ -279,11 +351,10 @@ k_trace_batch(DeviceScene sc, const float4 *rays, uint64_t n, float4 *out_hit, u
         const float4 ro = rays[2 * i], rd = rays[2 * i + 1];
         float bt, bu, bv; uint32_t bp;
         if (out_any) {
-            out_any[i] = traverse<true>(g.nodes, g.tris, sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z),
-                                        mk3(rd.x, rd.y, rd.z), ro.w, rd.w, stack, &bt, &bu, &bv, &bp) ? 1 : 0;
+            out_any[i] = traverse_scene<MODE, true>(sc, g, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, stack,
+                                                    &bt, &bu, &bv, &bp) ? 1 : 0;
         } else {
-            traverse<false>(g.nodes, g.tris, sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z),
-                            ro.w, rd.w, stack, &bt, &bu, &bv, &bp);
+            traverse_scene<MODE, false>(sc, g, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, stack, &bt, &bu, &bv, &bp);
             const bool valid = (bp != MSK_NO_PRIM) && (bt != rd.w);
             out_hit[i] = make_float4(valid ? bt : MSK_INF_F, valid ? bu : 0.f, valid ? bv : 0.f,
                                      __uint_as_float(valid ? bp : MSK_NO_PRIM));
