@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MSK_ABI_VERSION 2
+#define MSK_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------- */
 #define MSK_OK                 0

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-MSK_ABI_VERSION = 2
+MSK_ABI_VERSION = 3
 MSK_OK = 0
 MSK_ERR_INVALID_ARG, MSK_ERR_NO_DEVICE, MSK_ERR_HIP, MSK_ERR_OOM, MSK_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 MSK_BSDF_DIFFUSE, MSK_BSDF_ROUGHCONDUCTOR, MSK_BSDF_ROUGHDIELECTRIC = 0, 1, 2
