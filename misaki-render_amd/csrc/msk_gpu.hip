@@ -410,6 +410,17 @@ void free_workspace(msk_scene *scene) { delete scene->ws; scene->ws = nullptr; }
 
 static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st, const PassParams &pp) {
     const uint32_t grid = (pp.n_regions * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
+    // Lane replacement pays when rays are long (tree in HBM/L2: trace -35 % on the 70 k-triangle scene) and costs when they
+    // are short (LDS-resident cbox: +50 %): on by default for modes 1 and 2 only.  MSK_TRACE_REFILL=0 turns it off.
+    static const int refill_env = getenv("MSK_TRACE_REFILL") ? atoi(getenv("MSK_TRACE_REFILL")) : -1;
+    static const int max_inner = (int) env_u32("MSK_TRACE_QUANTUM", 2);
+    const int refill = refill_env >= 0 ? refill_env : (sc->trace_mode == 0 ? 0 : 16);
+    if (refill > 0) {        // k_trace_r
+        if (sc->trace_mode == 0) hipLaunchKernelGGL(k_trace_r<0>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp, refill, max_inner);
+        else if (sc->trace_mode == 1) hipLaunchKernelGGL(k_trace_r<1>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp, refill, max_inner);
+        else hipLaunchKernelGGL(k_trace_r<2>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp, refill, max_inner);
+        return;
+    }
     if (sc->trace_mode == 0) hipLaunchKernelGGL(k_trace<0>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp);
     else if (sc->trace_mode == 1) hipLaunchKernelGGL(k_trace<1>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp);
     else hipLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp);
@@ -501,9 +512,13 @@ static uint32_t owned_spp(const msk_render_params *p) {
     return p->sample_first < p->spp ? (p->spp - p->sample_first + ss - 1) / ss : 0;
 }
 
-static void pool_shape(uint64_t total_samples, uint32_t *region_size, uint32_t *n_regions) {
-    uint32_t rs = env_u32("MSK_REGION_SIZE", 256), nr = env_u32("MSK_REGIONS", 32768);
+// 8 M path slots either way.  Short rays (LDS-resident scene): many small regions, one chunk loop per wave.  Long rays
+// (k_trace_r): few large regions, so that lane replacement has a long list of rays to keep the lanes busy with.
+static void pool_shape(const msk_scene *sc, uint64_t total_samples, uint32_t *region_size, uint32_t *n_regions) {
+    const bool big = sc->trace_mode != 0;
+    uint32_t rs = env_u32("MSK_REGION_SIZE", big ? 2048 : 256), nr = env_u32("MSK_REGIONS", big ? 4096 : 32768);
     rs = std::max(64u, (rs + 63u) & ~63u);
+    while (rs > 256 && total_samples / rs < nr) rs = std::max(256u, rs / 2);       // small jobs: keep the GPU full first
     const uint64_t need = (total_samples + rs - 1) / rs;
     if (need < nr) nr = (uint32_t) std::max<uint64_t>(need, 1);
     nr = (nr + 3u) & ~3u;
@@ -560,7 +575,7 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     uint32_t region_size, n_regions;
     uint64_t all_samples = 0;
     for (auto &b : owned) all_samples += (uint64_t) b.size_x * b.size_y * spp_owned;
-    pool_shape(all_samples, &region_size, &n_regions);
+    pool_shape(sc, all_samples, &region_size, &n_regions);
     const size_t n_slots = (size_t) region_size * n_regions;
     const size_t state_bytes = n_slots * 148 + 4096;
     const size_t held = ws.rec_a.bytes + ws.rec_b.bytes + ws.sb.id.bytes * 148 / 16;    // reusable: counts as free
@@ -765,7 +780,7 @@ extern "C" int msk_gpu_sample_pixels(msk_scene *scene, const msk_render_params *
     msk_render_params p = *prm; p.sample_first = 0; p.sample_stride = 1;
     const uint64_t n_rec = n_pixels * p.spp;
     uint32_t region_size, n_regions;
-    pool_shape(n_rec, &region_size, &n_regions);
+    pool_shape(scene, n_rec, &region_size, &n_regions);
     StateBufs sb; DevBuf d_pix, ra, rb, ox, op;
     HIP_TRY(ctx, sb.alloc((size_t) region_size * n_regions, n_regions));
     HIP_TRY(ctx, d_pix.upload(pix)); HIP_TRY(ctx, ra.alloc(n_rec * 16)); HIP_TRY(ctx, rb.alloc(n_rec * 4));

@@ -337,6 +337,152 @@ k_trace(DeviceScene sc, PathState st, PassParams pp) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_trace_r: the same rays with lane replacement.  Every lane is a small state machine {slot, phase (shadow / closest),
+// traversal cursor}; a lane whose ray is finished takes the region's next slot once at least MSK_REFILL lanes are idle
+// (or nothing else is running), so a long ray no longer idles the 63 lanes that shared its chunk.  Each lane's
+// arithmetic is exactly traverse()'s: same hit, bit for bit.
+// ------------------------------------------------------------------------------------------
+struct TravState {
+    f3 o, d, idir, oi;
+    float tmin, tmax, bt, bu, bv;
+    uint32_t bp, cur;
+    int sp;
+};
+MSK_DEV void trav_begin(TravState &t, uint32_t root_ref, uint32_t n_tris, f3 o, f3 d, float tmin, float tmax) {
+    t.o = o; t.d = d; t.tmin = tmin; t.tmax = tmax;
+    t.idir = mk3(fminf(fmaxf(1.f / d.x, -1e25f), 1e25f), fminf(fmaxf(1.f / d.y, -1e25f), 1e25f), fminf(fmaxf(1.f / d.z, -1e25f), 1e25f));
+    t.oi = mk3(o.x * t.idir.x, o.y * t.idir.y, o.z * t.idir.z);
+    t.bt = tmax; t.bu = 0.f; t.bv = 0.f; t.bp = MSK_NO_PRIM; t.sp = 0;
+    t.cur = n_tris ? root_ref : 0xffffffffu;
+}
+// one work quantum: up to `max_inner` inner nodes, then (if the lane holds one) a leaf.  Returns true when an any-hit
+// query found its hit.  t.cur == 0xffffffff afterwards means the traversal is complete.
+template <int MODE, bool ANY>
+MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t, uint32_t *stack, int max_inner) {
+    const uint32_t DONE = 0xffffffffu;
+    int steps = 0;
+    while (!(t.cur & MSK_LEAF_BIT) && steps < max_inner) {
+        ++steps;
+        if (MODE == 2) {
+            const float4 *n = sc.nodes4 + (size_t) t.cur * 8;
+            const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], rf = n[6];
+            float t0, t1, t2, t3;
+            const bool h0 = box_test(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t.idir, t.oi, t.tmin, t.bt, &t0);
+            const bool h1 = box_test(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t.idir, t.oi, t.tmin, t.bt, &t1);
+            const bool h2 = box_test(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t.idir, t.oi, t.tmin, t.bt, &t2);
+            const bool h3 = box_test(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t.idir, t.oi, t.tmin, t.bt, &t3);
+            uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
+            t0 = (h0 && r0 != MSK_EMPTY4) ? t0 : MSK_INF_F; t1 = (h1 && r1 != MSK_EMPTY4) ? t1 : MSK_INF_F;
+            t2 = (h2 && r2 != MSK_EMPTY4) ? t2 : MSK_INF_F; t3 = (h3 && r3 != MSK_EMPTY4) ? t3 : MSK_INF_F;
+#define MSK_CSWAP(ta, ra, tb, rb) { const bool s_ = tb < ta; const float tt_ = s_ ? tb : ta; const uint32_t rr_ = s_ ? rb : ra; \
+                                    tb = s_ ? ta : tb; rb = s_ ? ra : rb; ta = tt_; ra = rr_; }
+            MSK_CSWAP(t0, r0, t1, r1) MSK_CSWAP(t2, r2, t3, r3) MSK_CSWAP(t0, r0, t2, r2) MSK_CSWAP(t1, r1, t3, r3) MSK_CSWAP(t1, r1, t2, r2)
+#undef MSK_CSWAP
+            if (t0 != MSK_INF_F) {
+                if (t3 != MSK_INF_F) { stack[t.sp * MSK_BLOCK] = r3; t.sp += 1; }
+                if (t2 != MSK_INF_F) { stack[t.sp * MSK_BLOCK] = r2; t.sp += 1; }
+                if (t1 != MSK_INF_F) { stack[t.sp * MSK_BLOCK] = r1; t.sp += 1; }
+                t.cur = r0;
+            } else if (t.sp > 0) { t.sp -= 1; t.cur = stack[t.sp * MSK_BLOCK]; }
+            else { t.cur = DONE; }
+        } else {
+            const float4 *n = g.nodes + (size_t) t.cur * 4;
+            const float4 a = n[0], b = n[1], c = n[2], m = n[3];
+            float t0, t1;
+            const bool h0 = box_test(a.x, a.y, a.z, a.w, b.x, b.y, t.idir, t.oi, t.tmin, t.bt, &t0);
+            const bool h1 = box_test(b.z, b.w, c.x, c.y, c.z, c.w, t.idir, t.oi, t.tmin, t.bt, &t1);
+            const uint32_t c0 = __float_as_uint(m.x), c1 = __float_as_uint(m.y);
+            if (h0 && h1) {
+                const bool swap = t1 < t0;
+                t.cur = swap ? c1 : c0;
+                stack[t.sp * MSK_BLOCK] = swap ? c0 : c1; t.sp += 1;
+            } else if (h0) { t.cur = c0; }
+            else if (h1) { t.cur = c1; }
+            else if (t.sp > 0) { t.sp -= 1; t.cur = stack[t.sp * MSK_BLOCK]; }
+            else { t.cur = DONE; }
+        }
+    }
+    if (t.cur != DONE && (t.cur & MSK_LEAF_BIT)) {
+        const uint32_t first = (t.cur & 0x7fffffffu) >> 5, cnt = t.cur & 31u;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const float4 *q = g.tris + (size_t) (first + i) * 4;
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            float tt, u, v;
+            if (tri_test(q0, q1, q2, q3, t.o, t.d, t.tmin, t.tmax, &tt, &u, &v)) {
+                if (ANY) return true;
+                const uint32_t prim = __float_as_uint(q0.w);
+                if (tt < t.bt || (tt == t.bt && prim < t.bp)) { t.bt = tt; t.bu = u; t.bv = v; t.bp = prim; }
+            }
+        }
+        if (t.sp > 0) { t.sp -= 1; t.cur = stack[t.sp * MSK_BLOCK]; } else t.cur = DONE;
+    }
+    return false;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(MSK_BLOCK)
+k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner) {
+    constexpr bool LDS_SCENE = MODE == 0;
+    extern __shared__ float4 lds_dyn[];
+    uint32_t *stack_base = (uint32_t *) lds_dyn;
+    float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
+    TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE);
+    uint32_t *stack = stack_base + threadIdx.x;
+    const uint32_t wave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
+    const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
+    if (wave >= pp.n_regions) return;
+    const uint32_t n = pp.regions[wave].count;
+    const size_t base = (size_t) wave * pp.region_size;
+    uint32_t next = 0;                       // wave-uniform: first slot nobody has taken yet
+    bool active = false, shadow_phase = false;
+    size_t slot = 0;
+    float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 0, 0);
+    uint32_t unocc = 0;
+    TravState t;
+    t.cur = 0xffffffffu; t.sp = 0;
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        if (next < n && idle != 0ull && ((int) __popcll(idle) >= refill || idle == ~0ull)) {
+            if (!active) {
+                const uint32_t c = next + (uint32_t) __popcll(idle & ((1ull << lane) - 1ull));
+                if (c < n) {
+                    slot = base + c;
+                    ro = st.ray_o[slot]; rd = st.ray_d[slot];
+                    const uint32_t fl = st.id[slot].w;
+                    unocc = 0; active = true;
+                    shadow_phase = (fl & MSK_FLAG_SHADOW) != 0;
+                    if (shadow_phase) {
+                        const float4 s = st.sh[slot];
+                        trav_begin(t, MODE == 2 ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(s.x, s.y, s.z), ro.w, s.w);
+                    } else {
+                        trav_begin(t, MODE == 2 ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+                    }
+                }
+            }
+            next += (uint32_t) __popcll(idle);
+        }
+        if (__ballot(active) == 0ull) break;          // next >= n here: an all-idle wave always refills while slots remain
+        if (active) {
+            if (shadow_phase) {
+                const bool occ = trav_quantum<MODE, true>(sc, g, t, stack, max_inner);
+                if (occ || t.cur == 0xffffffffu) {
+                    unocc = occ ? 0u : MSK_HIT_UNOCCLUDED;
+                    shadow_phase = false;
+                    trav_begin(t, MODE == 2 ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+                }
+            } else {
+                trav_quantum<MODE, false>(sc, g, t, stack, max_inner);
+                if (t.cur == 0xffffffffu) {
+                    const bool valid = (t.bp != MSK_NO_PRIM) && (t.bt != rd.w);
+                    st.hit[slot] = make_float4(valid ? t.bt : MSK_INF_F, t.bu, t.bv, __uint_as_float((valid ? t.bp : MSK_PRIM_MASK) | unocc));
+                    active = false;
+                }
+            }
+        }
+    }
+}
+
 // batch entry points for the sub-stage parity tests (msk_gpu_trace_closest / _any)
 template <int MODE>
 __global__ void __launch_bounds__(MSK_BLOCK)
