@@ -5,7 +5,8 @@
 reads  gpurun_out/prof_kt/**/**_kernel_stats.csv        (--kernel-trace --stats of bench.py)
        gpurun_out/prof_fetch/**/*_counter_collection.csv (--pmc FETCH_SIZE)
        gpurun_out/prof_write/**/*_counter_collection.csv (--pmc WRITE_SIZE)
-writes profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json and profiles/pmc_summary.json
+       gpurun_out/prof_sq/**/*_counter_collection.csv    (--pmc SQ_WAVE_CYCLES SQ_WAIT_ANY ... of tools/prof_run.py)
+writes profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json, profiles/<tag>_sq.json and profiles/pmc_summary.json
 HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE is in KiB and, on gfx950, reports exactly half of
 the bytes of wide coalesced reads -> bytes = 2 * 1024 * FETCH_SIZE; WRITE_SIZE (KiB) is exact.
 """
@@ -52,3 +53,19 @@ for k in sorted(set(fetch) | set(write)):
 json.dump(summary, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
+
+# SQ pass (one run, 8 counters): per-wave fractions of SQ_WAVE_CYCLES (all in quad-cycles, MI355X_MICROARCH.md)
+sq_files = glob.glob(os.path.join(root, "gpurun_out", "prof_sq", "**", "*_counter_collection.csv"), recursive=True)
+if sq_files:
+    tot = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(max(sq_files, key=os.path.getmtime))):
+        tot[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    sq = {}
+    for k, v in sorted(tot.items()):
+        if not k.startswith("k_"):
+            continue
+        wc = v.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+        sq[k] = {"SQ_WAVE_CYCLES": v.get("SQ_WAVE_CYCLES", 0.0)}
+        sq[k].update({c + "/WAVE_CYCLES": round(x / wc, 4) for c, x in v.items() if c != "SQ_WAVE_CYCLES"})
+    json.dump(sq, open(os.path.join(out, f"{tag}_sq.json"), "w"), indent=1)
+    print(json.dumps(sq, indent=1))
