@@ -413,7 +413,7 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
     // Lane replacement pays when rays are long (tree in HBM/L2: trace -35 % on the 70 k-triangle scene) and costs when they
     // are short (LDS-resident cbox: +50 %): on by default for modes 1 and 2 only.  MSK_TRACE_REFILL=0 turns it off.
     static const int refill_env = getenv("MSK_TRACE_REFILL") ? atoi(getenv("MSK_TRACE_REFILL")) : -1;
-    static const int max_inner = (int) env_u32("MSK_TRACE_QUANTUM", 2);
+    static const int max_inner = (int) env_u32("MSK_TRACE_QUANTUM", 4);
     const int refill = refill_env >= 0 ? refill_env : (sc->trace_mode == 0 ? 0 : 16);
     if (refill > 0) {        // k_trace_r
         if (sc->trace_mode == 0) hipLaunchKernelGGL(k_trace_r<0>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp, refill, max_inner);
@@ -516,7 +516,7 @@ static uint32_t owned_spp(const msk_render_params *p) {
 // (k_trace_r): few large regions, so that lane replacement has a long list of rays to keep the lanes busy with.
 static void pool_shape(const msk_scene *sc, uint64_t total_samples, uint32_t *region_size, uint32_t *n_regions) {
     const bool big = sc->trace_mode != 0;
-    uint32_t rs = env_u32("MSK_REGION_SIZE", big ? 2048 : 256), nr = env_u32("MSK_REGIONS", big ? 4096 : 32768);
+    uint32_t rs = env_u32("MSK_REGION_SIZE", big ? 2048 : 512), nr = env_u32("MSK_REGIONS", big ? 4096 : 16384);
     rs = std::max(64u, (rs + 63u) & ~63u);
     while (rs > 256 && total_samples / rs < nr) rs = std::max(256u, rs / 2);       // small jobs: keep the GPU full first
     const uint64_t need = (total_samples + rs - 1) / rs;

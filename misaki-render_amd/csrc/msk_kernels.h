@@ -136,6 +136,12 @@ MSK_DEV bool tri_test(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, fl
     return true;
 }
 
+// Reciprocal direction of the slab test: v_rcp_f32 (1 ulp) instead of an IEEE division (11 instructions each).  The slab
+// test only culls, behind boxes padded by 1e-4 of the scene diagonal — seven orders of magnitude more than this error.
+MSK_DEV f3 slab_idir(f3 d) {
+    return mk3(fminf(fmaxf(__builtin_amdgcn_rcpf(d.x), -1e25f), 1e25f), fminf(fmaxf(__builtin_amdgcn_rcpf(d.y), -1e25f), 1e25f),
+               fminf(fmaxf(__builtin_amdgcn_rcpf(d.z), -1e25f), 1e25f));
+}
 // conservative slab test, fma form t = b*idir - o*idir with idir clamped to +-1e25 by the caller
 // (no infinities -> no NaNs; an axis-parallel ray sees +-huge instead of +-inf)
 MSK_DEV bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 idir, f3 oi,
@@ -162,8 +168,7 @@ MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict
     uint32_t bp = MSK_NO_PRIM;
     *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
     if (n_tris == 0) return false;
-    const f3 idir = mk3(fminf(fmaxf(1.f / d.x, -1e25f), 1e25f), fminf(fmaxf(1.f / d.y, -1e25f), 1e25f),
-                        fminf(fmaxf(1.f / d.z, -1e25f), 1e25f));
+    const f3 idir = slab_idir(d);
     const f3 oi = mk3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
     int sp = 0;
     uint32_t cur = root_ref;
@@ -217,8 +222,7 @@ MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restric
     uint32_t bp = MSK_NO_PRIM;
     *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
     if (n_tris == 0) return false;
-    const f3 idir = mk3(fminf(fmaxf(1.f / d.x, -1e25f), 1e25f), fminf(fmaxf(1.f / d.y, -1e25f), 1e25f),
-                        fminf(fmaxf(1.f / d.z, -1e25f), 1e25f));
+    const f3 idir = slab_idir(d);
     const f3 oi = mk3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
     int sp = 0;
     uint32_t cur = root_ref;
@@ -351,17 +355,20 @@ struct TravState {
 };
 MSK_DEV void trav_begin(TravState &t, uint32_t root_ref, uint32_t n_tris, f3 o, f3 d, float tmin, float tmax) {
     t.o = o; t.d = d; t.tmin = tmin; t.tmax = tmax;
-    t.idir = mk3(fminf(fmaxf(1.f / d.x, -1e25f), 1e25f), fminf(fmaxf(1.f / d.y, -1e25f), 1e25f), fminf(fmaxf(1.f / d.z, -1e25f), 1e25f));
+    t.idir = slab_idir(d);
     t.oi = mk3(o.x * t.idir.x, o.y * t.idir.y, o.z * t.idir.z);
     t.bt = tmax; t.bu = 0.f; t.bv = 0.f; t.bp = MSK_NO_PRIM; t.sp = 0;
     t.cur = n_tris ? root_ref : 0xffffffffu;
 }
 // one work quantum: up to `max_inner` inner nodes, then (if the lane holds one) a leaf.  Returns true when an any-hit
 // query found its hit.  t.cur == 0xffffffff afterwards means the traversal is complete.
-template <int MODE, bool ANY>
-MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t, uint32_t *stack, int max_inner) {
+// `any` is a per-lane run-time flag on purpose: lanes in the shadow phase and lanes in the closest-hit phase share one
+// instruction stream instead of executing two instantiations one after the other.
+template <int MODE>
+MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t, uint32_t *stack, int max_inner, bool any) {
     const uint32_t DONE = 0xffffffffu;
     int steps = 0;
+    bool found = false;
     while (!(t.cur & MSK_LEAF_BIT) && steps < max_inner) {
         ++steps;
         if (MODE == 2) {
@@ -410,14 +417,14 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             float tt, u, v;
             if (tri_test(q0, q1, q2, q3, t.o, t.d, t.tmin, t.tmax, &tt, &u, &v)) {
-                if (ANY) return true;
+                if (any) { found = true; break; }
                 const uint32_t prim = __float_as_uint(q0.w);
                 if (tt < t.bt || (tt == t.bt && prim < t.bp)) { t.bt = tt; t.bu = u; t.bv = v; t.bp = prim; }
             }
         }
-        if (t.sp > 0) { t.sp -= 1; t.cur = stack[t.sp * MSK_BLOCK]; } else t.cur = DONE;
+        if (t.sp > 0 && !found) { t.sp -= 1; t.cur = stack[t.sp * MSK_BLOCK]; } else t.cur = DONE;
     }
-    return false;
+    return found;
 }
 
 template <int MODE>
@@ -464,16 +471,13 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
         }
         if (__ballot(active) == 0ull) break;          // next >= n here: an all-idle wave always refills while slots remain
         if (active) {
-            if (shadow_phase) {
-                const bool occ = trav_quantum<MODE, true>(sc, g, t, stack, max_inner);
-                if (occ || t.cur == 0xffffffffu) {
+            const bool occ = trav_quantum<MODE>(sc, g, t, stack, max_inner, shadow_phase);
+            if (t.cur == 0xffffffffu) {
+                if (shadow_phase) {
                     unocc = occ ? 0u : MSK_HIT_UNOCCLUDED;
                     shadow_phase = false;
                     trav_begin(t, MODE == 2 ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
-                }
-            } else {
-                trav_quantum<MODE, false>(sc, g, t, stack, max_inner);
-                if (t.cur == 0xffffffffu) {
+                } else {
                     const bool valid = (t.bp != MSK_NO_PRIM) && (t.bt != rd.w);
                     st.hit[slot] = make_float4(valid ? t.bt : MSK_INF_F, t.bu, t.bv, __uint_as_float((valid ? t.bp : MSK_PRIM_MASK) | unocc));
                     active = false;
