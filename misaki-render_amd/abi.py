@@ -100,7 +100,7 @@ class MskError(RuntimeError):
 
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "lib", "libmsk_gpu.so")
+LIB_PATH = os.environ.get("MSK_GPU_LIB") or os.path.join(_PKG_DIR, "lib", "libmsk_gpu.so")   # override: A/B experiments
 
 # every symbol include/msk_gpu.h declares
 EXPORTS = ["msk_gpu_init", "msk_gpu_shutdown", "msk_gpu_last_error", "msk_gpu_scene_create",

@@ -2,7 +2,8 @@
 // traversal kernels read.  Replaces rtcCommitScene (reference: src/librender/scene.cpp:201-212).
 //
 // Layout (all float4, 16-byte aligned, 64 B per record so one record = one half cache line):
-//   node  n : [lo0.xyz, hi0.x] [hi0.yz, lo1.xy] [lo1.z, hi1.xyz] [c0, c1, -, - (uint bits)]
+//   node  n : [lo0.x lo1.x lo0.y lo1.y] [lo0.z lo1.z hi0.x hi1.x] [hi0.y hi1.y hi0.z hi1.z] [c0, c1, -, - (uint bits)]
+//             (the two children's bounds interleaved: each pair feeds one v_pk_fma_f32 of the slab test)
 //             child ref c: 0x80000000 | first_tri << 5 | count for a leaf (count <= 8),
 //             otherwise the index of an inner node.
 //   tri   t : [v0.xyz, prim (uint bits)] [e1.xyz, 0] [e2.xyz, 0] [Ng.xyz, 0]
@@ -126,9 +127,9 @@ struct Builder {
         Box a = l.box, b = r.box;
         a.lo = {a.lo.x - pad, a.lo.y - pad, a.lo.z - pad}; a.hi = {a.hi.x + pad, a.hi.y + pad, a.hi.z + pad};
         b.lo = {b.lo.x - pad, b.lo.y - pad, b.lo.z - pad}; b.hi = {b.hi.x + pad, b.hi.y + pad, b.hi.z + pad};
-        n[0] = a.lo.x; n[1] = a.lo.y; n[2] = a.lo.z; n[3] = a.hi.x;
-        n[4] = a.hi.y; n[5] = a.hi.z; n[6] = b.lo.x; n[7] = b.lo.y;
-        n[8] = b.lo.z; n[9] = b.hi.x; n[10] = b.hi.y; n[11] = b.hi.z;
+        n[0] = a.lo.x; n[1] = b.lo.x; n[2] = a.lo.y; n[3] = b.lo.y;
+        n[4] = a.lo.z; n[5] = b.lo.z; n[6] = a.hi.x; n[7] = b.hi.x;
+        n[8] = a.hi.y; n[9] = b.hi.y; n[10] = a.hi.z; n[11] = b.hi.z;
         uint32_t meta[4] = {pack(l), pack(r), 0u, 0u};
         std::memcpy(&n[12], meta, 16);
     }
@@ -187,8 +188,8 @@ struct Collapser {
         const float *n = &n2[(size_t) node * 16];
         uint32_t meta[4]; std::memcpy(meta, &n[12], 16);
         a->ref = meta[0]; b->ref = meta[1];
-        a->lo[0] = n[0]; a->lo[1] = n[1]; a->lo[2] = n[2]; a->hi[0] = n[3]; a->hi[1] = n[4]; a->hi[2] = n[5];
-        b->lo[0] = n[6]; b->lo[1] = n[7]; b->lo[2] = n[8]; b->hi[0] = n[9]; b->hi[1] = n[10]; b->hi[2] = n[11];
+        a->lo[0] = n[0]; a->lo[1] = n[2]; a->lo[2] = n[4]; a->hi[0] = n[6]; a->hi[1] = n[8]; a->hi[2] = n[10];
+        b->lo[0] = n[1]; b->lo[1] = n[3]; b->lo[2] = n[5]; b->hi[0] = n[7]; b->hi[1] = n[9]; b->hi[2] = n[11];
     }
     uint32_t collapse(uint32_t node, int depth) {
         max_depth = std::max(max_depth, depth);

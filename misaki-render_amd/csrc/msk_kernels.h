@@ -155,6 +155,33 @@ MSK_DEV bool box_test(float lox, float loy, float loz, float hix, float hiy, flo
     return t0 <= t1 * 1.0000004f;
 }
 
+// The same test for two boxes at once; lo*/hi* hold child 0 in .x and child 1 in .y.  With MSK_PK_SLAB=1 the six
+// multiply-adds of each box pair up into v_pk_fma_f32 — measured SLOWER on gfx950 (cbox trace +6 %, 70 k-triangle scene
+// +6 %: the packed op saves no issue cycles and costs register shuffles), so the scalar form is the default.
+typedef float f2v __attribute__((ext_vector_type(2)));
+#ifndef MSK_PK_SLAB
+#define MSK_PK_SLAB 0
+#endif
+MSK_DEV void box_test2(f2v lox, f2v loy, f2v loz, f2v hix, f2v hiy, f2v hiz, f3 idir, f3 oi, float tmin, float tcur,
+                       float *tn0, float *tn1, bool *h0, bool *h1) {
+#if !MSK_PK_SLAB
+    *h0 = box_test(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, idir, oi, tmin, tcur, tn0);
+    *h1 = box_test(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, idir, oi, tmin, tcur, tn1);
+    return;
+#endif
+    const f2v ix = {idir.x, idir.x}, iy = {idir.y, idir.y}, iz = {idir.z, idir.z};
+    const f2v ox = {-oi.x, -oi.x}, oy = {-oi.y, -oi.y}, oz = {-oi.z, -oi.z};
+    const f2v ax = __builtin_elementwise_fma(lox, ix, ox), bx = __builtin_elementwise_fma(hix, ix, ox);
+    const f2v ay = __builtin_elementwise_fma(loy, iy, oy), by = __builtin_elementwise_fma(hiy, iy, oy);
+    const f2v az = __builtin_elementwise_fma(loz, iz, oz), bz = __builtin_elementwise_fma(hiz, iz, oz);
+    const float t00 = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fmaxf(fminf(az.x, bz.x), tmin));
+    const float t01 = fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fminf(fmaxf(az.x, bz.x), tcur));
+    const float t10 = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fmaxf(fminf(az.y, bz.y), tmin));
+    const float t11 = fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fminf(fmaxf(az.y, bz.y), tcur));
+    *tn0 = t00; *tn1 = t10;
+    *h0 = t00 <= t01 * 1.0000004f; *h1 = t10 <= t11 * 1.0000004f;
+}
+
 // ANY: returns true on the first accepted triangle.  Closest: keeps (t, prim)-minimal hit.
 // nodes/tris may point into LDS or HBM.  stack: this lane's LDS stack, stride MSK_BLOCK.
 // "while-while" form: the inner loop walks inner nodes until the lane holds a leaf (or runs out of
@@ -178,9 +205,9 @@ MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict
         while (!(cur & MSK_LEAF_BIT)) {
             const float4 *n = nodes + (size_t) cur * 4;
             const float4 a = n[0], b = n[1], c = n[2], m = n[3];
-            float t0, t1;
-            const bool h0 = box_test(a.x, a.y, a.z, a.w, b.x, b.y, idir, oi, tmin, bt, &t0);
-            const bool h1 = box_test(b.z, b.w, c.x, c.y, c.z, c.w, idir, oi, tmin, bt, &t1);
+            float t0, t1; bool h0, h1;
+            box_test2(f2v{a.x, a.y}, f2v{a.z, a.w}, f2v{b.x, b.y}, f2v{b.z, b.w}, f2v{c.x, c.y}, f2v{c.z, c.w}, idir, oi, tmin, bt,
+                      &t0, &t1, &h0, &h1);
             const uint32_t c0 = __float_as_uint(m.x), c1 = __float_as_uint(m.y);
             if (h0 && h1) {
                 const bool swap = t1 < t0;            // nearer child first, the other one on the stack
@@ -231,11 +258,11 @@ MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restric
         while (!(cur & MSK_LEAF_BIT)) {
             const float4 *n = nodes + (size_t) cur * 8;
             const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], rf = n[6];
-            float t0, t1, t2, t3;
-            const bool h0 = box_test(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, idir, oi, tmin, bt, &t0);
-            const bool h1 = box_test(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, idir, oi, tmin, bt, &t1);
-            const bool h2 = box_test(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, idir, oi, tmin, bt, &t2);
-            const bool h3 = box_test(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, idir, oi, tmin, bt, &t3);
+            float t0, t1, t2, t3; bool h0, h1, h2, h3;
+            box_test2(f2v{lx.x, lx.y}, f2v{ly.x, ly.y}, f2v{lz.x, lz.y}, f2v{hx.x, hx.y}, f2v{hy.x, hy.y}, f2v{hz.x, hz.y}, idir, oi,
+                      tmin, bt, &t0, &t1, &h0, &h1);
+            box_test2(f2v{lx.z, lx.w}, f2v{ly.z, ly.w}, f2v{lz.z, lz.w}, f2v{hx.z, hx.w}, f2v{hy.z, hy.w}, f2v{hz.z, hz.w}, idir, oi,
+                      tmin, bt, &t2, &t3, &h2, &h3);
             uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
             // misses and empty slots sort to the end
             t0 = (h0 && r0 != MSK_EMPTY4) ? t0 : MSK_INF_F; t1 = (h1 && r1 != MSK_EMPTY4) ? t1 : MSK_INF_F;
@@ -374,11 +401,11 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
         if (MODE == 2) {
             const float4 *n = sc.nodes4 + (size_t) t.cur * 8;
             const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], rf = n[6];
-            float t0, t1, t2, t3;
-            const bool h0 = box_test(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t.idir, t.oi, t.tmin, t.bt, &t0);
-            const bool h1 = box_test(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t.idir, t.oi, t.tmin, t.bt, &t1);
-            const bool h2 = box_test(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t.idir, t.oi, t.tmin, t.bt, &t2);
-            const bool h3 = box_test(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t.idir, t.oi, t.tmin, t.bt, &t3);
+            float t0, t1, t2, t3; bool h0, h1, h2, h3;
+            box_test2(f2v{lx.x, lx.y}, f2v{ly.x, ly.y}, f2v{lz.x, lz.y}, f2v{hx.x, hx.y}, f2v{hy.x, hy.y}, f2v{hz.x, hz.y}, t.idir,
+                      t.oi, t.tmin, t.bt, &t0, &t1, &h0, &h1);
+            box_test2(f2v{lx.z, lx.w}, f2v{ly.z, ly.w}, f2v{lz.z, lz.w}, f2v{hx.z, hx.w}, f2v{hy.z, hy.w}, f2v{hz.z, hz.w}, t.idir,
+                      t.oi, t.tmin, t.bt, &t2, &t3, &h2, &h3);
             uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
             t0 = (h0 && r0 != MSK_EMPTY4) ? t0 : MSK_INF_F; t1 = (h1 && r1 != MSK_EMPTY4) ? t1 : MSK_INF_F;
             t2 = (h2 && r2 != MSK_EMPTY4) ? t2 : MSK_INF_F; t3 = (h3 && r3 != MSK_EMPTY4) ? t3 : MSK_INF_F;
@@ -396,9 +423,9 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
         } else {
             const float4 *n = g.nodes + (size_t) t.cur * 4;
             const float4 a = n[0], b = n[1], c = n[2], m = n[3];
-            float t0, t1;
-            const bool h0 = box_test(a.x, a.y, a.z, a.w, b.x, b.y, t.idir, t.oi, t.tmin, t.bt, &t0);
-            const bool h1 = box_test(b.z, b.w, c.x, c.y, c.z, c.w, t.idir, t.oi, t.tmin, t.bt, &t1);
+            float t0, t1; bool h0, h1;
+            box_test2(f2v{a.x, a.y}, f2v{a.z, a.w}, f2v{b.x, b.y}, f2v{b.z, b.w}, f2v{c.x, c.y}, f2v{c.z, c.w}, t.idir, t.oi, t.tmin,
+                      t.bt, &t0, &t1, &h0, &h1);
             const uint32_t c0 = __float_as_uint(m.x), c1 = __float_as_uint(m.y);
             if (h0 && h1) {
                 const bool swap = t1 < t0;
