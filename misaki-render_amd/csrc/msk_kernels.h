@@ -707,13 +707,14 @@ MSK_DEV spec roughdielectric_sample(const BsdfRec &b, f3 wi, float sample1, f2 s
 }
 
 // eval + pdf with wi on the front side (roughconductor.cpp:82-117 / diffuse.cpp:35-57)
+// `refl` = the diffuse reflectance spectrum at wl, evaluated once per bounce by the caller (used by eval and by sample)
 template <bool DIFFUSE_ONLY>
-MSK_DEV void bsdf_eval_pdf(const BsdfRec &b, f3 wi, f3 wo, spec wl, spec *val, float *pdf) {
+MSK_DEV void bsdf_eval_pdf(const BsdfRec &b, f3 wi, f3 wo, spec wl, spec refl, spec *val, float *pdf) {
     *val = splat(0.f); *pdf = 0.f;
     const float cos_i = wi.z, cos_o = wo.z;
     if (DIFFUSE_ONLY || __float_as_int(b.a.x) == 0) {
         if (cos_i > 0.f && cos_o > 0.f) {
-            *val = srgb_model_eval(b.a.z, b.a.w, b.b.x, wl) * MSK_INV_PI_F * cos_o;
+            *val = refl * MSK_INV_PI_F * cos_o;
             *pdf = MSK_INV_PI_F * wo.z;
         }
         return;
@@ -742,7 +743,8 @@ MSK_DEV void bsdf_eval_pdf(const BsdfRec &b, f3 wi, f3 wo, spec wl, spec *val, f
 }
 // sample with wi on the front side; returns the weight, fills wo / pdf / ok (= a direction was produced)
 template <bool DIFFUSE_ONLY>
-MSK_DEV spec bsdf_sample(const BsdfRec &b, f3 wi, float sample1, f2 sample, spec wl, f3 *wo, float *pdf, float *eta_out, bool *ok) {
+MSK_DEV spec bsdf_sample(const BsdfRec &b, f3 wi, float sample1, f2 sample, spec wl, spec refl, f3 *wo, float *pdf, float *eta_out,
+                         bool *ok) {
     *wo = mk3(0.f, 0.f, 0.f); *pdf = 0.f; *ok = false; *eta_out = 1.f;
     if (!DIFFUSE_ONLY && __float_as_int(b.a.x) == MSK_BSDF_ROUGHDIELECTRIC)
         return roughdielectric_sample(b, wi, sample1, sample, wl, wo, pdf, eta_out, ok);
@@ -752,7 +754,7 @@ MSK_DEV spec bsdf_sample(const BsdfRec &b, f3 wi, float sample1, f2 sample, spec
     if (DIFFUSE_ONLY || __float_as_int(b.a.x) == 0) {
         *wo = square_to_cosine_hemisphere(sample);
         *pdf = MSK_INV_PI_F * wo->z;
-        return *pdf > 0.f ? srgb_model_eval(b.a.z, b.a.w, b.b.x, wl) : splat(0.f);
+        return *pdf > 0.f ? refl : splat(0.f);
     }
     const float au = clamp_alpha(b.b.y), av = clamp_alpha(b.b.z);
     const f3 m = sample_ggx(sample, au, av, pdf);
@@ -835,10 +837,14 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
                 const int back = __float_as_int(bs.a.y);
                 if (back >= 0 && wi_s.z < 0.f) { wi_s.z = -wi_s.z; flipped = true; if (back != si.bsdf_id) bs = load_bsdf(tb, back); }
             }
+            // AreaLight::eval at this hit (area.cpp:51-54): used by the MIS term of the previous bounce or by the directly
+            // visible emitter, never both
+            spec le_hit = splat(0.f);
+            if (si.emitter_id >= 0 && si.wi.z > 0.f) le_hit = emitter_radiance(tb, si.emitter_id, wl);
             if (depth > 1) {
                 // ---- tail of the previous bounce: emitter hit by the BSDF sample (path.cpp:82-88,103-108)
                 if (si.emitter_id >= 0) {
-                    const spec value = si.wi.z > 0.f ? emitter_radiance(tb, si.emitter_id, wl) : splat(0.f);
+                    const spec value = le_hit;
                     // set_query (records.cpp:7-14) + pdf_emitter_direct (scene.cpp:105-112, shape.cpp:80-86)
                     float pdf = tb.emitters[2 * si.emitter_id].w;
                     const float dp = fabsf(dot(rd, si.sh.n));
@@ -857,12 +863,13 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
             // loop condition of the bounce that starts now (path.cpp:33)
             if (alive && !((int) depth <= pp.max_depth || pp.max_depth < 0)) alive = false;
             if (alive && depth == 1 && si.emitter_id >= 0 && !pp.hide_emitters) {   // path.cpp:42-47
-                const spec le = si.wi.z > 0.f ? emitter_radiance(tb, si.emitter_id, wl) : splat(0.f);
-                res = res + thr * le;
+                res = res + thr * le_hit;
             }
             if (alive && (int) depth >= pp.max_depth && pp.max_depth > 0) alive = false;   // path.cpp:48-49
             if (alive) {
                 const uint32_t pb = 3 + 3 * (depth - 1);
+                spec refl = splat(0.f);                  // SmoothDiffuse::m_reflectance->eval(si) (diffuse.cpp:31,44): once per bounce
+                if (DIFFUSE_ONLY || __float_as_int(bs.a.x) == 0) refl = srgb_model_eval(bs.a.z, bs.a.w, bs.b.x, wl);
                 // ---- next-event estimation (path.cpp:56-67, scene.cpp:68-103)
                 if (n_em > 0) {
                     f2 u = counter_pair(key, pb + 0);
@@ -927,7 +934,7 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
                         f3 wo = si.sh.to_local(d);
                         if (flipped) wo.z = -wo.z;
                         spec bsdf_val; float bsdf_pdf;
-                        bsdf_eval_pdf<DIFFUSE_ONLY>(bs, wi_s, wo, wl, &bsdf_val, &bsdf_pdf);
+                        bsdf_eval_pdf<DIFFUSE_ONLY>(bs, wi_s, wo, wl, refl, &bsdf_val, &bsdf_pdf);
                         const float w = mis_weight(pdf, bsdf_pdf);
                         contrib = thr * emitter_val * bsdf_val * w;
                         if (any_nonzero(contrib)) {
@@ -941,7 +948,7 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
                     const f2 u2 = counter_pair(key, pb + 2);
                     f3 wo_l; bool ok; float bs_eta;
                     const float sample1 = DIFFUSE_ONLY ? 0.f : counter_pair(key, pb + 1).x;
-                    const spec bsdf_val = bsdf_sample<DIFFUSE_ONLY>(bs, wi_s, sample1, u2, wl, &wo_l, &bs_pdf, &bs_eta, &ok);
+                    const spec bsdf_val = bsdf_sample<DIFFUSE_ONLY>(bs, wi_s, sample1, u2, wl, refl, &wo_l, &bs_pdf, &bs_eta, &ok);
                     if (!ok) {
                         alive = false;         // failed sample: zero direction, the reference's ray misses (no NEE either)
                     } else {
