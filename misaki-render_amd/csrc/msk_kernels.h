@@ -1166,13 +1166,14 @@ k_resolve_blocks(DeviceScene sc, const BlockInfo *blocks, uint32_t n_blocks, con
     const float radius = sc.filter_radius, scale = sc.filter_scale;
     // a sample of source pixel x lands on bordered targets within border-r-.5 .. border+r+.5 of x
     const int span = (int) ceilf(radius + 0.5f);
-    float acc[TY][TX][5];
+    // channels X, Y, Z and one accumulator for A and W (both receive w * 1, integrator.cpp:119-123: identical sums)
+    float acc[TY][TX][4];
 #pragma unroll
     for (int j = 0; j < TY; ++j)
 #pragma unroll
         for (int i = 0; i < TX; ++i)
 #pragma unroll
-            for (int c = 0; c < 5; ++c) acc[j][i][c] = 0.f;
+            for (int c = 0; c < 4; ++c) acc[j][i][c] = 0.f;
     const int y_lo = max(0, ty0 - border - span), y_hi = min(b.size_y - 1, ty0 + TY - 1 - border + span);
     const int x_lo = max(0, tx0 - border - span), x_hi = min(b.size_x - 1, tx0 + TX - 1 - border + span);
     const float offx = (float) (b.off_x - border), offy = (float) (b.off_y - border);
@@ -1193,22 +1194,31 @@ k_resolve_blocks(DeviceScene sc, const BlockInfo *blocks, uint32_t n_blocks, con
                 for (int k = 0; k < U; ++k) {
                     if (s0 + (uint32_t) k >= spp_owned) break;
                     const float px = ra[k].w - 0.5f - offx, py = rb[k] - 0.5f - offy;
-                    const int lox = max((int) ceilf(px - radius), 0), loy = max((int) ceilf(py - radius), 0);
-                    const int hix = min((int) floorf(px + radius), sx - 1), hiy = min((int) floorf(py + radius), sy - 1);
+                    // imageblock.cpp:66-72: lo = max(ceil(pos - r), 0), hi = min(floor(pos + r), size - 1).  For an integer
+                    // target t inside the block, lo <= t <= hi  <=>  (pos - r) <= t <= (pos + r) with the same fp32 sums.
+                    const float xm = px - radius, xp = px + radius, ym = py - radius, yp = py + radius;
                     float wx[TX], wy[TY];
+                    bool inx[TX], iny[TY];
 #pragma unroll
-                    for (int i = 0; i < TX; ++i) wx[i] = lut[min((int) fabsf(((float) (tx0 + i) - px) * scale), 32)];
+                    for (int i = 0; i < TX; ++i) {
+                        const float ft = (float) (tx0 + i);
+                        wx[i] = lut[min((int) fabsf((ft - px) * scale), 32)];
+                        inx[i] = ft >= xm && ft <= xp;
+                    }
 #pragma unroll
-                    for (int j = 0; j < TY; ++j) wy[j] = lut[min((int) fabsf(((float) (ty0 + j) - py) * scale), 32)];
+                    for (int j = 0; j < TY; ++j) {
+                        const float ft = (float) (ty0 + j);
+                        wy[j] = lut[min((int) fabsf((ft - py) * scale), 32)];
+                        iny[j] = ft >= ym && ft <= yp;
+                    }
 #pragma unroll
                     for (int j = 0; j < TY; ++j)
 #pragma unroll
                         for (int i = 0; i < TX; ++i) {
-                            const int tx = tx0 + i, ty = ty0 + j;
-                            if (tx < lox || tx > hix || ty < loy || ty > hiy) continue;
+                            if (!(inx[i] && iny[j])) continue;
                             const float w = wx[i] * wy[j];
                             acc[j][i][0] += w * ra[k].x; acc[j][i][1] += w * ra[k].y; acc[j][i][2] += w * ra[k].z;
-                            acc[j][i][3] += w * 1.f; acc[j][i][4] += w * 1.f;
+                            acc[j][i][3] += w * 1.f;
                         }
                 }
             }
@@ -1220,8 +1230,7 @@ k_resolve_blocks(DeviceScene sc, const BlockInfo *blocks, uint32_t n_blocks, con
             const int tx = tx0 + i, ty = ty0 + j;
             if (tx >= sx || ty >= sy) continue;
             float *o = block_buf + (size_t) b.slot * buf_stride + (size_t) (ty * sx + tx) * 5;
-#pragma unroll
-            for (int c = 0; c < 5; ++c) o[c] = acc[j][i][c];
+            o[0] = acc[j][i][0]; o[1] = acc[j][i][1]; o[2] = acc[j][i][2]; o[3] = acc[j][i][3]; o[4] = acc[j][i][3];
         }
 }
 
