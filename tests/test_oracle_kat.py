@@ -94,6 +94,14 @@ def test_det_math_within_one_ulp_of_libm(oracle):
         ulp = np.abs(np.spacing(ref.astype(np.float32))).astype(np.float64)
         worst = np.maximum(worst, np.abs(d - ref) / ulp)
     assert worst.max() <= 0.5 + 1e-6, worst     # correctly rounded
+    # cosh over the whole range the wavelength weights use (|0.0072 (lambda - 538)| <= 2.11) and beyond the series' 2.5
+    for x in np.concatenate([rng.uniform(-2.2, 2.2, 1500), rng.uniform(-9, 9, 300), [2.5, -2.5, 2.5000002]]).astype(np.float32):
+        got, ref = float(oracle.det_math(float(x))[3]), np.cosh(float(x))
+        assert abs(got - ref) <= (0.5 + 1e-6) * abs(np.spacing(np.float32(ref))), x
+    # atanh towards the ends of (-1, 1): exponent bookkeeping of the single-division form
+    for x in np.concatenate([rng.uniform(-0.999999, 0.999999, 1500), [0.99999994, -0.99999994, 5.9604645e-8, -3e-7]]).astype(np.float32):
+        got, ref = float(oracle.det_math(float(x))[2]), np.arctanh(float(x))
+        assert abs(got - ref) <= (0.5 + 1e-6) * abs(np.spacing(np.float32(ref))), x
     # angles beyond the first quadrant (quadrant reduction)
     for x in np.linspace(-20, 20, 401, dtype=np.float32):
         d = oracle.det_math(float(np.float32(x) * np.float32(0.999)))
