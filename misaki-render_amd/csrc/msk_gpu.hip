@@ -412,8 +412,8 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
     const uint32_t grid = (pp.n_regions * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
     // Lane replacement pays when rays are long (tree in HBM/L2: trace -35 % on the 70 k-triangle scene) and costs when they
     // are short (LDS-resident cbox: +50 %): on by default for modes 1 and 2 only.  MSK_TRACE_REFILL=0 turns it off.
-    static const int refill_env = getenv("MSK_TRACE_REFILL") ? atoi(getenv("MSK_TRACE_REFILL")) : -1;
-    static const int max_inner = (int) env_u32("MSK_TRACE_QUANTUM", 4);
+    const int refill_env = getenv("MSK_TRACE_REFILL") ? atoi(getenv("MSK_TRACE_REFILL")) : -1;
+    const int max_inner = (int) env_u32("MSK_TRACE_QUANTUM", 4);
     const int refill = refill_env >= 0 ? refill_env : (sc->trace_mode == 0 ? 0 : 16);
     if (refill > 0) {        // k_trace_r
         if (sc->trace_mode == 0) hipLaunchKernelGGL(k_trace_r<0>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp, refill, max_inner);
@@ -457,13 +457,14 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     const bool diffuse_only = sc->all_diffuse && !aov_rgb;      // the AOV RGB record lives in the general shading variant
     const uint32_t grid = (n_regions * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
     const uint32_t group = env_u32("MSK_SYNC_GROUP", 8);
+    static const size_t shade_pad_lds = (size_t) env_u32("MSK_SHADE_PAD_LDS_KB", 0) * 1024;   // occupancy experiments only
     const bool timing = stats != nullptr;
     uint32_t it = 0;
     for (;;) {
         for (uint32_t g = 0; g < group; ++g, ++it) {
             hipEvent_t a = nullptr, b = nullptr, c = nullptr;
             if (timing) { a = ev.get(); b = ev.get(); c = ev.get(); (void) hipEventRecord(a, stream); }
-#define MSK_SHADE(L, D) hipLaunchKernelGGL((k_shade_gen<L, D>), dim3(grid), dim3(MSK_BLOCK), (L) ? sc->shade_lds_bytes : 0, stream, sc->dev, sb.st, pp)
+#define MSK_SHADE(L, D) hipLaunchKernelGGL((k_shade_gen<L, D>), dim3(grid), dim3(MSK_BLOCK), ((L) ? sc->shade_lds_bytes : 0) + shade_pad_lds, stream, sc->dev, sb.st, pp)
             if (sc->lds_tables) { if (diffuse_only) MSK_SHADE(true, true); else MSK_SHADE(true, false); }
             else { if (diffuse_only) MSK_SHADE(false, true); else MSK_SHADE(false, false); }
 #undef MSK_SHADE

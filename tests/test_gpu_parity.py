@@ -188,6 +188,59 @@ def test_large_mesh_uses_hbm_bvh(gpu_ctx, abi, hostmirror, oracle, golden_lookup
     o.close()
 
 
+@pytest.mark.parametrize("env", [dict(MSK_TRACE_REFILL="0"), dict(MSK_WIDE_BVH="0"), dict(MSK_WIDE_BVH="0", MSK_TRACE_REFILL="0"),
+                                 dict(MSK_TRACE_REFILL="48", MSK_TRACE_QUANTUM="1"), dict(MSK_LDS_SCENE_KB="0", MSK_WIDE_BVH="0")])
+def test_every_traversal_kernel_gives_the_same_film(gpu_ctx, abi, hostmirror, oracle, golden_lookup, monkeypatch, env):
+    """k_trace<0|1|2> (chunk loop) and k_trace_r<0|1|2> (lane replacement), binary and 4-wide trees: hit selection is by
+    (t, prim), so every one of them must reproduce the oracle's film bit for bit."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    blob = hostmirror.blob_mesh("blob", (370, 420, 250), 70, 40, 40, hostmirror.WHITE, seed=2)
+    big = cbox(hostmirror, golden_lookup, 64, 64, extra=[blob])
+    small = cbox(hostmirror, golden_lookup, 64, 64)
+    prm = abi.render_params(spp=4, seed=6)
+    for flat, extra_env in ((big, {}), (small, dict(MSK_TRACE_REFILL=env.get("MSK_TRACE_REFILL", "16")))):
+        for k, v in extra_env.items():
+            monkeypatch.setenv(k, v)                  # the LDS-resident scene only uses k_trace_r when asked to
+        g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+        film, _ = g.render(prm)
+        ref, _ = o.render(prm, threads=8)
+        assert np.array_equal(film.view(np.uint32), ref.view(np.uint32)), (env, flat.desc.n_faces)
+        g.close()
+        o.close()
+
+
+def test_full_hd_ragged_tiles_bit_exact(gpu_ctx, abi, hostmirror, oracle, golden_lookup):
+    """BASELINE config 4's film (1920x1080: 60 x 34 tiles, the last row 24 px high, imageblock.cpp:206-208) at 2 spp."""
+    flat = cbox(hostmirror, golden_lookup, 1920, 1080)
+    g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+    prm = abi.render_params(spp=2, seed=1)
+    film, st = g.render(prm)
+    ref, rst = o.render(prm, threads=8)
+    assert st.samples == rst.samples == 1920 * 1080 * 2
+    assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+    g.close()
+    o.close()
+
+
+def test_headline_size_properties(gpu_ctx, abi, hostmirror, golden_lookup):
+    """BASELINE config 2 at full size (512^2 x 512 spp, too long for the scalar oracle): size-independent properties.
+    (i) the weight channels depend on the film positions only, so they equal those of a depth-0 render bit for bit;
+    (ii) the film is linear in the sample set: two sample-index shards sum to the whole; (iii) a second run is identical."""
+    flat = cbox(hostmirror, golden_lookup, 512, 512)
+    g = abi.Scene(gpu_ctx, flat)
+    full, st = g.render(abi.render_params(spp=512, seed=3))
+    assert st.samples == 512 * 512 * 512 and np.isfinite(full).all() and full[..., :3].min() >= 0
+    flat0, _ = g.render(abi.render_params(spp=512, seed=3, max_depth=0))
+    assert np.array_equal(full[..., 3:].view(np.uint32), flat0[..., 3:].view(np.uint32)) and not flat0[..., :3].any()
+    assert np.array_equal(full[..., 3], full[..., 4])
+    halves = [g.render(abi.render_params(spp=512, seed=3, sample_first=r, sample_stride=2))[0] for r in range(2)]
+    assert np.allclose(halves[0] + halves[1], full, rtol=1e-4, atol=1e-4)
+    again, _ = g.render(abi.render_params(spp=512, seed=3))
+    assert np.array_equal(again.view(np.uint32), full.view(np.uint32))
+    g.close()
+
+
 def test_two_emitters(gpu_ctx, abi, hostmirror, oracle, golden_lookup):
     """Multi-emitter selection path of Scene::sample_emitter_direct (scene.cpp:78-88)."""
     second = hostmirror.MeshSpec("lamp2", [((100, 300, 558), (200, 300, 558), (200, 400, 558), (100, 400, 558))],
