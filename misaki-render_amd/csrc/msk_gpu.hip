@@ -473,7 +473,9 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
             if (aov && aov->n_groups) hipLaunchKernelGGL(k_aov_primary, dim3(grid), dim3(MSK_BLOCK), 0, stream, sc->dev, sb.st, pp, *aov);
             if (timing) { (void) hipEventRecord(c, stream); ev_shade.push_back({a, b}); ev_trace.push_back({b, c}); }
         }
-        hipLaunchKernelGGL(k_reduce_ctl, dim3(1), dim3(MSK_BLOCK), 0, stream, sb.counts.as<RegionCtl>(), n_regions, sb.ctrl.as<Ctrl>());
+        HIP_TRY(ctx, hipMemsetAsync(sb.ctrl.p, 0, sizeof(Ctrl), stream));
+        hipLaunchKernelGGL(k_reduce_ctl, dim3(std::min(64u, (n_regions + MSK_BLOCK - 1) / MSK_BLOCK)), dim3(MSK_BLOCK), 0, stream,
+                           sb.counts.as<RegionCtl>(), n_regions, sb.ctrl.as<Ctrl>());
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctrl, sb.ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
         HIP_TRY(ctx, hipStreamSynchronize(stream));

@@ -1116,11 +1116,12 @@ k_aov_primary(DeviceScene sc, PathState st, PassParams pp, AovParams ap) {
     }
 }
 
-// sums the per-region records for the host (termination test + statistics); one block
+// sums the per-region records for the host (termination test + statistics): each block reduces its slice and adds five
+// totals to *out (zeroed by the host before the launch) — 5 atomics per block, a few dozen per launch
 __global__ void __launch_bounds__(MSK_BLOCK) k_reduce_ctl(const RegionCtl *regions, uint32_t n_regions, Ctrl *out) {
     __shared__ unsigned long long sh[5][MSK_BLOCK];
     unsigned long long a[5] = {0, 0, 0, 0, 0};
-    for (uint32_t i = threadIdx.x; i < n_regions; i += MSK_BLOCK) {
+    for (uint32_t i = blockIdx.x * MSK_BLOCK + threadIdx.x; i < n_regions; i += gridDim.x * MSK_BLOCK) {
         const RegionCtl r = regions[i];
         a[0] += r.count; a[1] += r.end_sample - r.next_sample; a[2] += r.segments; a[3] += r.shadow_rays; a[4] += r.samples_done;
     }
@@ -1130,7 +1131,10 @@ __global__ void __launch_bounds__(MSK_BLOCK) k_reduce_ctl(const RegionCtl *regio
         if (threadIdx.x < s) for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out->live = sh[0][0]; out->remaining = sh[1][0]; out->segments = sh[2][0]; out->shadow_rays = sh[3][0]; out->samples_done = sh[4][0]; }
+    if (threadIdx.x == 0) {
+        atomicAdd(&out->live, sh[0][0]); atomicAdd(&out->remaining, sh[1][0]); atomicAdd(&out->segments, sh[2][0]);
+        atomicAdd(&out->shadow_rays, sh[3][0]); atomicAdd(&out->samples_done, sh[4][0]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
