@@ -408,6 +408,10 @@ struct EventPool {
 
 void free_workspace(msk_scene *scene) { delete scene->ws; scene->ws = nullptr; }
 
+static void sum_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, float *ms) {
+    for (auto &p : v) { float t = 0; if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) *ms += t; }
+}
+
 static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st, const PassParams &pp) {
     const uint32_t grid = (pp.n_regions * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
     // Lane replacement pays when rays are long (tree in HBM/L2: trace -35 % on the 70 k-triangle scene) and costs when they
@@ -460,6 +464,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     static const size_t shade_pad_lds = (size_t) env_u32("MSK_SHADE_PAD_LDS_KB", 0) * 1024;   // occupancy experiments only
     const bool timing = stats != nullptr;
     uint32_t it = 0;
+    const size_t ev_mark = ev.next;        // the group's events are read at its sync point and reused by the next group
     for (;;) {
         for (uint32_t g = 0; g < group; ++g, ++it) {
             hipEvent_t a = nullptr, b = nullptr, c = nullptr;
@@ -479,6 +484,11 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctrl, sb.ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
         HIP_TRY(ctx, hipStreamSynchronize(stream));
+        if (timing) {
+            sum_events(ev_shade, &stats->ms_shade); sum_events(ev_trace, &stats->ms_trace);
+            stats->n_shade_launches += (uint32_t) ev_shade.size(); stats->n_trace_launches += (uint32_t) ev_trace.size();
+            ev_shade.clear(); ev_trace.clear(); ev.next = ev_mark;
+        }
         const Ctrl &h = *ctx->h_ctrl;
         if (h.remaining == 0 && h.live == 0) break;
         if (it > 100000000u) return fail(ctx, MSK_ERR_HIP, "wavefront loop did not terminate");
@@ -528,9 +538,6 @@ static void pool_shape(const msk_scene *sc, uint64_t total_samples, uint32_t *re
     *region_size = rs; *n_regions = nr;
 }
 
-static void sum_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, float *ms) {
-    for (auto &p : v) { float t = 0; if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) *ms += t; }
-}
 
 static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_film, hipStream_t user_stream, msk_stats *stats,
                        const AovPlan *aov = nullptr) {
@@ -683,8 +690,7 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     if (stats) {
         (void) hipEventElapsedTime(&stats->ms_total, t_begin, t_end);
-        sum_events(ev_trace, &stats->ms_trace); sum_events(ev_shade, &stats->ms_shade); sum_events(ev_resolve, &stats->ms_resolve);
-        stats->n_trace_launches = (uint32_t) ev_trace.size(); stats->n_shade_launches = (uint32_t) ev_shade.size();
+        sum_events(ev_resolve, &stats->ms_resolve);      // trace / shade were summed group by group in run_wavefront
     }
     return MSK_OK;
 }
