@@ -300,3 +300,32 @@ def test_error_behaviour(scene256, gpu_ctx, abi, hostmirror, golden_lookup):
         abi.Scene(gpu_ctx, bad)
     with pytest.raises(abi.MskError):
         g.sample_pixels(abi.render_params(spp=1), np.array([[300, 2]], np.int32))
+
+
+def test_scene_lifecycle_releases_device_memory(gpu_ctx, abi, hostmirror, golden_lookup):
+    """create / render / destroy in a loop: every DevBuf and the cached workspace go back to the allocator, a second
+    context on the same device works side by side, and results do not depend on what ran before."""
+    import torch
+    flat = cbox(hostmirror, golden_lookup, 128, 96)
+    prm = abi.render_params(spp=4, seed=9)
+    first = None
+    free0 = None
+    for i in range(12):
+        g = abi.Scene(gpu_ctx, flat)
+        film, _ = g.render(prm)
+        if i % 3 == 0:
+            g.render_aov(prm, [abi.MSK_AOV_DEPTH, abi.MSK_AOV_PATH_RGBA])
+        g.close()
+        if first is None:
+            first = film
+        assert np.array_equal(film.view(np.uint32), first.view(np.uint32))
+        free, total = torch.cuda.mem_get_info(0)
+        if i == 1:
+            free0 = free
+        if i > 1:
+            assert free >= free0 - (64 << 20), (i, free0, free)          # no growth from iteration to iteration
+    other = abi.Context(0)
+    g2 = abi.Scene(other, flat)
+    assert np.array_equal(g2.render(prm)[0].view(np.uint32), first.view(np.uint32))
+    g2.close()
+    other.close()
