@@ -305,8 +305,15 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         if (e4 != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(e4)); }
         ds.nodes4 = s->nodes4.as<float4>(); ds.root_ref4 = bvh.root_ref4;
         ds.stack_entries = (uint32_t) ((3 * bvh.max_depth4 + 2 + 3) & ~3);     // up to three pushes per level
-        s->trace_lds_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4;
         s->trace_mode = 2;
+    }
+    ds.stack_total = ds.stack_entries;
+    if (s->trace_mode != 0) {
+        // trees in HBM: only the first MSK_STACK_CAP entries of a lane's stack live in LDS, the rest in an HBM overflow
+        // array (LaneStack) — any tree depth works within a fixed 24 KB of LDS per block.  (Measured: the cap does not
+        // change the trace time between 8 and 40 entries; the traversal needs >= 4 waves per SIMD and has them.)
+        ds.stack_entries = std::min(ds.stack_total, std::max(4u, env_u32("MSK_STACK_CAP", 24) & ~3u));
+        s->trace_lds_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4;
     }
     // LDS plan of k_shade_gen: the small lookup tables (tri_verts, mesh/bsdf/emitter records, cdf, d65, cie)
     const size_t table_bytes = ((size_t) ds.n_tris * 3 + ds.n_meshes + ds.n_bsdfs * MSK_BSDF_F4 + ds.n_emitters * 2 +
@@ -361,7 +368,7 @@ static std::vector<HostBlock> spiral_blocks(int w, int h, int bs, int *nbx, int 
 // wavefront driver
 // ------------------------------------------------------------------------------------------
 struct StateBufs {
-    DevBuf id, wl, thr, res, ray_o, ray_d, sh, contrib, hit, bs_pdf, aux, counts, ctrl;
+    DevBuf id, wl, thr, res, ray_o, ray_d, sh, contrib, hit, bs_pdf, aux, counts, ctrl, stack_ovf;
     PathState st;
     hipError_t alloc(size_t n, uint32_t n_regions) {
         hipError_t e;
@@ -419,15 +426,16 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
     const int refill_env = getenv("MSK_TRACE_REFILL") ? atoi(getenv("MSK_TRACE_REFILL")) : -1;
     const int max_inner = (int) env_u32("MSK_TRACE_QUANTUM", 4);
     const int refill = refill_env >= 0 ? refill_env : (sc->trace_mode == 0 ? 0 : 16);
+    const size_t lds = sc->trace_lds_bytes + (size_t) env_u32("MSK_TRACE_PAD_LDS_KB", 0) * 1024;      // occupancy experiments only
     if (refill > 0) {        // k_trace_r
-        if (sc->trace_mode == 0) hipLaunchKernelGGL(k_trace_r<0>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp, refill, max_inner);
-        else if (sc->trace_mode == 1) hipLaunchKernelGGL(k_trace_r<1>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp, refill, max_inner);
-        else hipLaunchKernelGGL(k_trace_r<2>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp, refill, max_inner);
+        if (sc->trace_mode == 0) hipLaunchKernelGGL(k_trace_r<0>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp, refill, max_inner);
+        else if (sc->trace_mode == 1) hipLaunchKernelGGL(k_trace_r<1>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp, refill, max_inner);
+        else hipLaunchKernelGGL(k_trace_r<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp, refill, max_inner);
         return;
     }
-    if (sc->trace_mode == 0) hipLaunchKernelGGL(k_trace<0>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp);
-    else if (sc->trace_mode == 1) hipLaunchKernelGGL(k_trace<1>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp);
-    else hipLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(MSK_BLOCK), sc->trace_lds_bytes, stream, sc->dev, st, pp);
+    if (sc->trace_mode == 0) hipLaunchKernelGGL(k_trace<0>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp);
+    else if (sc->trace_mode == 1) hipLaunchKernelGGL(k_trace<1>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp);
+    else hipLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp);
 }
 
 // Renders the samples of `pix` (pass pixel table, host) into records; leaves records on device.
@@ -460,6 +468,11 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     pp.aov_rgb = aov_rgb;
     const bool diffuse_only = sc->all_diffuse && !aov_rgb;      // the AOV RGB record lives in the general shading variant
     const uint32_t grid = (n_regions * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
+    pp.stack_ovf = nullptr;
+    if (sc->dev.stack_total > sc->dev.stack_entries) {          // LaneStack overflow: one word per lane per extra entry
+        HIP_TRY(ctx, sb.stack_ovf.reserve((size_t) (sc->dev.stack_total - sc->dev.stack_entries) * grid * MSK_BLOCK * 4));
+        pp.stack_ovf = sb.stack_ovf.as<uint32_t>();
+    }
     const uint32_t group = env_u32("MSK_SYNC_GROUP", 8);
     static const size_t shade_pad_lds = (size_t) env_u32("MSK_SHADE_PAD_LDS_KB", 0) * 1024;   // occupancy experiments only
     const bool timing = stats != nullptr;
@@ -817,15 +830,18 @@ static int trace_batch(msk_scene *scene, uint64_t n, const float *rays, float *o
     const uint32_t grid = (uint32_t) std::min<uint64_t>((n + MSK_BLOCK - 1) / MSK_BLOCK, 4096);
     float4 *oh = out_any ? nullptr : d_out.as<float4>();
     uint8_t *oa = out_any ? d_out.as<uint8_t>() : nullptr;
+    DevBuf d_ovf;
+    if (scene->dev.stack_total > scene->dev.stack_entries)
+        HIP_TRY(ctx, d_ovf.alloc((size_t) (scene->dev.stack_total - scene->dev.stack_entries) * grid * MSK_BLOCK * 4));
     if (scene->trace_mode == 0)
         hipLaunchKernelGGL(k_trace_batch<0>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
-                           d_rays.as<float4>(), n, oh, oa);
+                           d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
     else if (scene->trace_mode == 1)
         hipLaunchKernelGGL(k_trace_batch<1>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
-                           d_rays.as<float4>(), n, oh, oa);
+                           d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
     else
         hipLaunchKernelGGL(k_trace_batch<2>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
-                           d_rays.as<float4>(), n, oh, oa);
+                           d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out_any ? (void *) out_any : (void *) out_hit, d_out.p, out_any ? n : n * 16, hipMemcpyDeviceToHost));

@@ -48,7 +48,8 @@ struct DeviceScene {
     const float *cie;           // 285 floats
     uint32_t n_nodes, n_tris, n_emitters, n_meshes, n_bsdfs, cdf_len;
     uint32_t root_ref;          // packed child ref of the root
-    uint32_t stack_entries;     // per-lane traversal stack depth (BVH depth + 2)
+    uint32_t stack_entries;     // per-lane traversal stack entries kept in LDS
+    uint32_t stack_total;       // entries a traversal can need (BVH depth + 2, or 3 per level of the 4-wide tree); the rest overflows to HBM
     float s2c[16], to_world[16];
     float near_clip, far_clip;
     int32_t width, height;
@@ -96,6 +97,7 @@ struct PassParams {
     float *rec_b;                 // per sample pos.y           i.e. [block][sample][pixel], pixel fastest
     uint32_t region_size, n_regions;
     RegionCtl *regions;
+    uint32_t *stack_ovf;          // traversal-stack overflow (LaneStack), (stack_total - stack_entries) x lanes words, or nullptr
     float4 *aov_rgb;              // nullptr, or per sample {R,G,B,pos.x} of the nested path integrator (aov.cpp:124-141)
 };
 
@@ -155,41 +157,33 @@ MSK_DEV bool box_test(float lox, float loy, float loz, float hix, float hiy, flo
     return t0 <= t1 * 1.0000004f;
 }
 
-// The same test for two boxes at once; lo*/hi* hold child 0 in .x and child 1 in .y.  With MSK_PK_SLAB=1 the six
-// multiply-adds of each box pair up into v_pk_fma_f32 — measured SLOWER on gfx950 (cbox trace +6 %, 70 k-triangle scene
-// +6 %: the packed op saves no issue cycles and costs register shuffles), so the scalar form is the default.
-typedef float f2v __attribute__((ext_vector_type(2)));
-#ifndef MSK_PK_SLAB
-#define MSK_PK_SLAB 0
-#endif
-MSK_DEV void box_test2(f2v lox, f2v loy, f2v loz, f2v hix, f2v hiy, f2v hiz, f3 idir, f3 oi, float tmin, float tcur,
-                       float *tn0, float *tn1, bool *h0, bool *h1) {
-#if !MSK_PK_SLAB
-    *h0 = box_test(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, idir, oi, tmin, tcur, tn0);
-    *h1 = box_test(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, idir, oi, tmin, tcur, tn1);
-    return;
-#endif
-    const f2v ix = {idir.x, idir.x}, iy = {idir.y, idir.y}, iz = {idir.z, idir.z};
-    const f2v ox = {-oi.x, -oi.x}, oy = {-oi.y, -oi.y}, oz = {-oi.z, -oi.z};
-    const f2v ax = __builtin_elementwise_fma(lox, ix, ox), bx = __builtin_elementwise_fma(hix, ix, ox);
-    const f2v ay = __builtin_elementwise_fma(loy, iy, oy), by = __builtin_elementwise_fma(hiy, iy, oy);
-    const f2v az = __builtin_elementwise_fma(loz, iz, oz), bz = __builtin_elementwise_fma(hiz, iz, oz);
-    const float t00 = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fmaxf(fminf(az.x, bz.x), tmin));
-    const float t01 = fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fminf(fmaxf(az.x, bz.x), tcur));
-    const float t10 = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fmaxf(fminf(az.y, bz.y), tmin));
-    const float t11 = fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fminf(fmaxf(az.y, bz.y), tcur));
-    *tn0 = t00; *tn1 = t10;
-    *h0 = t00 <= t01 * 1.0000004f; *h1 = t10 <= t11 * 1.0000004f;
-}
+// Measured and rejected: the two children's slabs as v_pk_fma_f32 pairs (cbox trace +6 %, 70 k-triangle scene +6 %: the
+// packed op saves no issue cycles and costs register shuffles and 6 VGPRs = one wave of occupancy in k_trace<0>).
+
+// A lane's traversal stack: the first `cap` entries in LDS (stride MSK_BLOCK), deeper ones in an HBM overflow array
+// (stride = number of lanes of the launch).  Scenes staged in LDS (OVF = false) never overflow: their whole stack is LDS.
+// For trees in HBM this bounds the LDS a block needs whatever the tree depth; the overflow is touched by few rays.
+template <bool OVF>
+struct LaneStack {
+    uint32_t *lds; uint32_t *ovf; int cap; size_t stride;
+    MSK_DEV void push(int &sp, uint32_t v) const {
+        if (!OVF || sp < cap) lds[sp * MSK_BLOCK] = v; else ovf[(size_t) (sp - cap) * stride] = v;
+        sp += 1;
+    }
+    MSK_DEV uint32_t pop(int &sp) const {
+        sp -= 1;
+        return (!OVF || sp < cap) ? lds[sp * MSK_BLOCK] : ovf[(size_t) (sp - cap) * stride];
+    }
+};
 
 // ANY: returns true on the first accepted triangle.  Closest: keeps (t, prim)-minimal hit.
 // nodes/tris may point into LDS or HBM.  stack: this lane's LDS stack, stride MSK_BLOCK.
 // "while-while" form: the inner loop walks inner nodes until the lane holds a leaf (or runs out of
 // work), then the wave tests leaf triangles together — lanes at inner nodes do not sit through
 // other lanes' triangle tests one node at a time.
-template <bool ANY>
+template <bool ANY, bool OVF>
 MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict__ tris, uint32_t root_ref,
-                      uint32_t n_tris, f3 o, f3 d, float tmin, float tmax, uint32_t *stack, float *best_t, float *best_u,
+                      uint32_t n_tris, f3 o, f3 d, float tmin, float tmax, const LaneStack<OVF> &stack, float *best_t, float *best_u,
                       float *best_v, uint32_t *best_prim) {
     float bt = tmax, bu = 0.f, bv = 0.f;
     uint32_t bp = MSK_NO_PRIM;
@@ -205,17 +199,17 @@ MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict
         while (!(cur & MSK_LEAF_BIT)) {
             const float4 *n = nodes + (size_t) cur * 4;
             const float4 a = n[0], b = n[1], c = n[2], m = n[3];
-            float t0, t1; bool h0, h1;
-            box_test2(f2v{a.x, a.y}, f2v{a.z, a.w}, f2v{b.x, b.y}, f2v{b.z, b.w}, f2v{c.x, c.y}, f2v{c.z, c.w}, idir, oi, tmin, bt,
-                      &t0, &t1, &h0, &h1);
+            float t0, t1;
+            const bool h0 = box_test(a.x, a.z, b.x, b.z, c.x, c.z, idir, oi, tmin, bt, &t0);
+            const bool h1 = box_test(a.y, a.w, b.y, b.w, c.y, c.w, idir, oi, tmin, bt, &t1);
             const uint32_t c0 = __float_as_uint(m.x), c1 = __float_as_uint(m.y);
             if (h0 && h1) {
                 const bool swap = t1 < t0;            // nearer child first, the other one on the stack
                 cur = swap ? c1 : c0;
-                stack[sp * MSK_BLOCK] = swap ? c0 : c1; sp += 1;
+                stack.push(sp, swap ? c0 : c1);
             } else if (h0) { cur = c0; }
             else if (h1) { cur = c1; }
-            else if (sp > 0) { sp -= 1; cur = stack[sp * MSK_BLOCK]; }
+            else if (sp > 0) { cur = stack.pop(sp); }
             else { cur = DONE; break; }
         }
         if (cur == DONE) break;
@@ -231,7 +225,7 @@ MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict
                 if (t < bt || (t == bt && prim < bp)) { bt = t; bu = u; bv = v; bp = prim; }
             }
         }
-        if (sp > 0) { sp -= 1; cur = stack[sp * MSK_BLOCK]; } else cur = DONE;
+        if (sp > 0) { cur = stack.pop(sp); } else cur = DONE;
     }
     *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
     return false;
@@ -241,9 +235,9 @@ MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict
 // of the binary tree); used when the tree lives in HBM/L2.  Hit selection is by (t, prim), so the result is the binary
 // tree's, bit for bit.
 #define MSK_EMPTY4 0xfffffffeu
-template <bool ANY>
+template <bool ANY, bool OVF>
 MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restrict__ tris, uint32_t root_ref,
-                       uint32_t n_tris, f3 o, f3 d, float tmin, float tmax, uint32_t *stack, float *best_t, float *best_u,
+                       uint32_t n_tris, f3 o, f3 d, float tmin, float tmax, const LaneStack<OVF> &stack, float *best_t, float *best_u,
                        float *best_v, uint32_t *best_prim) {
     float bt = tmax, bu = 0.f, bv = 0.f;
     uint32_t bp = MSK_NO_PRIM;
@@ -258,11 +252,11 @@ MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restric
         while (!(cur & MSK_LEAF_BIT)) {
             const float4 *n = nodes + (size_t) cur * 8;
             const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], rf = n[6];
-            float t0, t1, t2, t3; bool h0, h1, h2, h3;
-            box_test2(f2v{lx.x, lx.y}, f2v{ly.x, ly.y}, f2v{lz.x, lz.y}, f2v{hx.x, hx.y}, f2v{hy.x, hy.y}, f2v{hz.x, hz.y}, idir, oi,
-                      tmin, bt, &t0, &t1, &h0, &h1);
-            box_test2(f2v{lx.z, lx.w}, f2v{ly.z, ly.w}, f2v{lz.z, lz.w}, f2v{hx.z, hx.w}, f2v{hy.z, hy.w}, f2v{hz.z, hz.w}, idir, oi,
-                      tmin, bt, &t2, &t3, &h2, &h3);
+            float t0, t1, t2, t3;
+            const bool h0 = box_test(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, idir, oi, tmin, bt, &t0);
+            const bool h1 = box_test(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, idir, oi, tmin, bt, &t1);
+            const bool h2 = box_test(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, idir, oi, tmin, bt, &t2);
+            const bool h3 = box_test(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, idir, oi, tmin, bt, &t3);
             uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
             // misses and empty slots sort to the end
             t0 = (h0 && r0 != MSK_EMPTY4) ? t0 : MSK_INF_F; t1 = (h1 && r1 != MSK_EMPTY4) ? t1 : MSK_INF_F;
@@ -273,11 +267,11 @@ MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restric
 #undef MSK_CSWAP
             if (t0 != MSK_INF_F) {
                 // nearest child next, the others on the stack, farthest first
-                if (t3 != MSK_INF_F) { stack[sp * MSK_BLOCK] = r3; sp += 1; }
-                if (t2 != MSK_INF_F) { stack[sp * MSK_BLOCK] = r2; sp += 1; }
-                if (t1 != MSK_INF_F) { stack[sp * MSK_BLOCK] = r1; sp += 1; }
+                if (t3 != MSK_INF_F) { stack.push(sp, r3); }
+                if (t2 != MSK_INF_F) { stack.push(sp, r2); }
+                if (t1 != MSK_INF_F) { stack.push(sp, r1); }
                 cur = r0;
-            } else if (sp > 0) { sp -= 1; cur = stack[sp * MSK_BLOCK]; }
+            } else if (sp > 0) { cur = stack.pop(sp); }
             else { cur = DONE; break; }
         }
         if (cur == DONE) break;
@@ -292,7 +286,7 @@ MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restric
                 if (t < bt || (t == bt && prim < bp)) { bt = t; bu = u; bv = v; bp = prim; }
             }
         }
-        if (sp > 0) { sp -= 1; cur = stack[sp * MSK_BLOCK]; } else cur = DONE;
+        if (sp > 0) { cur = stack.pop(sp); } else cur = DONE;
     }
     *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
     return false;
@@ -330,10 +324,10 @@ MSK_DEV TraceLds stage_scene(const DeviceScene &sc, float4 *lds, bool use_lds) {
 #define MSK_PRIM_MASK 0x7fffffffu
 // MODE 0: binary tree staged in LDS; 1: binary tree in HBM/L2; 2: 4-wide tree in HBM/L2
 template <int MODE, bool ANY>
-MSK_DEV bool traverse_scene(const DeviceScene &sc, const TraceLds &g, f3 o, f3 d, float tmin, float tmax, uint32_t *stack,
+MSK_DEV bool traverse_scene(const DeviceScene &sc, const TraceLds &g, f3 o, f3 d, float tmin, float tmax, const LaneStack<MODE != 0> &stack,
                             float *bt, float *bu, float *bv, uint32_t *bp) {
-    if (MODE == 2) return traverse4<ANY>(sc.nodes4, g.tris, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
-    return traverse<ANY>(g.nodes, g.tris, sc.root_ref, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+    if (MODE == 2) return traverse4<ANY, MODE != 0>(sc.nodes4, g.tris, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+    return traverse<ANY, MODE != 0>(g.nodes, g.tris, sc.root_ref, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
 }
 
 template <int MODE>
@@ -344,7 +338,8 @@ k_trace(DeviceScene sc, PathState st, PassParams pp) {
     uint32_t *stack_base = (uint32_t *) lds_dyn;                         // stack_entries * MSK_BLOCK words
     float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
     TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE);
-    uint32_t *stack = stack_base + threadIdx.x;
+    const LaneStack<MODE != 0> stack{stack_base + threadIdx.x, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
+                                     (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK};
     const uint32_t wave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
     if (wave >= pp.n_regions) return;
@@ -392,7 +387,7 @@ MSK_DEV void trav_begin(TravState &t, uint32_t root_ref, uint32_t n_tris, f3 o, 
 // `any` is a per-lane run-time flag on purpose: lanes in the shadow phase and lanes in the closest-hit phase share one
 // instruction stream instead of executing two instantiations one after the other.
 template <int MODE>
-MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t, uint32_t *stack, int max_inner, bool any) {
+MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t, const LaneStack<MODE != 0> &stack, int max_inner, bool any) {
     const uint32_t DONE = 0xffffffffu;
     int steps = 0;
     bool found = false;
@@ -401,11 +396,11 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
         if (MODE == 2) {
             const float4 *n = sc.nodes4 + (size_t) t.cur * 8;
             const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], rf = n[6];
-            float t0, t1, t2, t3; bool h0, h1, h2, h3;
-            box_test2(f2v{lx.x, lx.y}, f2v{ly.x, ly.y}, f2v{lz.x, lz.y}, f2v{hx.x, hx.y}, f2v{hy.x, hy.y}, f2v{hz.x, hz.y}, t.idir,
-                      t.oi, t.tmin, t.bt, &t0, &t1, &h0, &h1);
-            box_test2(f2v{lx.z, lx.w}, f2v{ly.z, ly.w}, f2v{lz.z, lz.w}, f2v{hx.z, hx.w}, f2v{hy.z, hy.w}, f2v{hz.z, hz.w}, t.idir,
-                      t.oi, t.tmin, t.bt, &t2, &t3, &h2, &h3);
+            float t0, t1, t2, t3;
+            const bool h0 = box_test(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t.idir, t.oi, t.tmin, t.bt, &t0);
+            const bool h1 = box_test(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t.idir, t.oi, t.tmin, t.bt, &t1);
+            const bool h2 = box_test(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t.idir, t.oi, t.tmin, t.bt, &t2);
+            const bool h3 = box_test(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t.idir, t.oi, t.tmin, t.bt, &t3);
             uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
             t0 = (h0 && r0 != MSK_EMPTY4) ? t0 : MSK_INF_F; t1 = (h1 && r1 != MSK_EMPTY4) ? t1 : MSK_INF_F;
             t2 = (h2 && r2 != MSK_EMPTY4) ? t2 : MSK_INF_F; t3 = (h3 && r3 != MSK_EMPTY4) ? t3 : MSK_INF_F;
@@ -414,26 +409,26 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
             MSK_CSWAP(t0, r0, t1, r1) MSK_CSWAP(t2, r2, t3, r3) MSK_CSWAP(t0, r0, t2, r2) MSK_CSWAP(t1, r1, t3, r3) MSK_CSWAP(t1, r1, t2, r2)
 #undef MSK_CSWAP
             if (t0 != MSK_INF_F) {
-                if (t3 != MSK_INF_F) { stack[t.sp * MSK_BLOCK] = r3; t.sp += 1; }
-                if (t2 != MSK_INF_F) { stack[t.sp * MSK_BLOCK] = r2; t.sp += 1; }
-                if (t1 != MSK_INF_F) { stack[t.sp * MSK_BLOCK] = r1; t.sp += 1; }
+                if (t3 != MSK_INF_F) { stack.push(t.sp, r3); }
+                if (t2 != MSK_INF_F) { stack.push(t.sp, r2); }
+                if (t1 != MSK_INF_F) { stack.push(t.sp, r1); }
                 t.cur = r0;
-            } else if (t.sp > 0) { t.sp -= 1; t.cur = stack[t.sp * MSK_BLOCK]; }
+            } else if (t.sp > 0) { t.cur = stack.pop(t.sp); }
             else { t.cur = DONE; }
         } else {
             const float4 *n = g.nodes + (size_t) t.cur * 4;
             const float4 a = n[0], b = n[1], c = n[2], m = n[3];
-            float t0, t1; bool h0, h1;
-            box_test2(f2v{a.x, a.y}, f2v{a.z, a.w}, f2v{b.x, b.y}, f2v{b.z, b.w}, f2v{c.x, c.y}, f2v{c.z, c.w}, t.idir, t.oi, t.tmin,
-                      t.bt, &t0, &t1, &h0, &h1);
+            float t0, t1;
+            const bool h0 = box_test(a.x, a.z, b.x, b.z, c.x, c.z, t.idir, t.oi, t.tmin, t.bt, &t0);
+            const bool h1 = box_test(a.y, a.w, b.y, b.w, c.y, c.w, t.idir, t.oi, t.tmin, t.bt, &t1);
             const uint32_t c0 = __float_as_uint(m.x), c1 = __float_as_uint(m.y);
             if (h0 && h1) {
                 const bool swap = t1 < t0;
                 t.cur = swap ? c1 : c0;
-                stack[t.sp * MSK_BLOCK] = swap ? c0 : c1; t.sp += 1;
+                stack.push(t.sp, swap ? c0 : c1);
             } else if (h0) { t.cur = c0; }
             else if (h1) { t.cur = c1; }
-            else if (t.sp > 0) { t.sp -= 1; t.cur = stack[t.sp * MSK_BLOCK]; }
+            else if (t.sp > 0) { t.cur = stack.pop(t.sp); }
             else { t.cur = DONE; }
         }
     }
@@ -449,7 +444,7 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
                 if (tt < t.bt || (tt == t.bt && prim < t.bp)) { t.bt = tt; t.bu = u; t.bv = v; t.bp = prim; }
             }
         }
-        if (t.sp > 0 && !found) { t.sp -= 1; t.cur = stack[t.sp * MSK_BLOCK]; } else t.cur = DONE;
+        if (t.sp > 0 && !found) { t.cur = stack.pop(t.sp); } else t.cur = DONE;
     }
     return found;
 }
@@ -462,7 +457,8 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
     uint32_t *stack_base = (uint32_t *) lds_dyn;
     float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
     TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE);
-    uint32_t *stack = stack_base + threadIdx.x;
+    const LaneStack<MODE != 0> stack{stack_base + threadIdx.x, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
+                                     (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK};
     const uint32_t wave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
     if (wave >= pp.n_regions) return;
@@ -517,13 +513,14 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
 // batch entry points for the sub-stage parity tests (msk_gpu_trace_closest / _any)
 template <int MODE>
 __global__ void __launch_bounds__(MSK_BLOCK)
-k_trace_batch(DeviceScene sc, const float4 *rays, uint64_t n, float4 *out_hit, uint8_t *out_any) {
+k_trace_batch(DeviceScene sc, const float4 *rays, uint64_t n, float4 *out_hit, uint8_t *out_any, uint32_t *stack_ovf) {
     constexpr bool LDS_SCENE = MODE == 0;
     extern __shared__ float4 lds_dyn[];
     uint32_t *stack_base = (uint32_t *) lds_dyn;
     float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
     TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE);
-    uint32_t *stack = stack_base + threadIdx.x;
+    const LaneStack<MODE != 0> stack{stack_base + threadIdx.x, stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
+                                     (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK};
     for (uint64_t i = (uint64_t) blockIdx.x * MSK_BLOCK + threadIdx.x; i < n; i += (uint64_t) gridDim.x * MSK_BLOCK) {
         const float4 ro = rays[2 * i], rd = rays[2 * i + 1];
         float bt, bu, bv; uint32_t bp;
