@@ -303,12 +303,22 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         mskbvh::collapse4(bvh);
         hipError_t e4 = s->nodes4.upload(bvh.nodes4);
         if (e4 != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(e4)); }
-        ds.nodes4 = s->nodes4.as<float4>(); ds.root_ref4 = bvh.root_ref4;
+        ds.nodes4 = s->nodes4.as<float4>(); ds.root_ref4 = bvh.root_ref4; ds.n_nodes4 = (uint32_t) (bvh.nodes4.size() / 32);
         ds.stack_entries = (uint32_t) ((3 * bvh.max_depth4 + 2 + 3) & ~3);     // up to three pushes per level
         s->trace_mode = 2;
+    } else if (s->lds_scene && env_u32("MSK_WIDE_LDS", 0) && !(bvh.root_ref & MSK_LEAF_BIT)) {
+        // experiment knob, off by default: the 4-wide tree staged in LDS (half the dependent LDS round trips per ray).
+        // Measured on cbox: trace 12.45 vs 12.34 ms for the binary tree — no gain.
+        mskbvh::collapse4(bvh);
+        hipError_t e4 = s->nodes4.upload(bvh.nodes4);
+        if (e4 != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(e4)); }
+        ds.nodes4 = s->nodes4.as<float4>(); ds.root_ref4 = bvh.root_ref4; ds.n_nodes4 = (uint32_t) (bvh.nodes4.size() / 32);
+        ds.stack_entries = (uint32_t) ((3 * bvh.max_depth4 + 2 + 3) & ~3);
+        s->trace_lds_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4 + ((size_t) ds.n_nodes4 * 128 + (size_t) ds.n_tris * 64);
+        s->trace_mode = 3;
     }
     ds.stack_total = ds.stack_entries;
-    if (s->trace_mode != 0) {
+    if (s->trace_mode == 1 || s->trace_mode == 2) {
         // trees in HBM: only the first MSK_STACK_CAP entries of a lane's stack live in LDS, the rest in an HBM overflow
         // array (LaneStack) — any tree depth works within a fixed 24 KB of LDS per block.  (Measured: the cap does not
         // change the trace time between 8 and 40 entries; the traversal needs >= 4 waves per SIMD and has them.)
@@ -425,7 +435,7 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
     // are short (LDS-resident cbox: +50 %): on by default for modes 1 and 2 only.  MSK_TRACE_REFILL=0 turns it off.
     const int refill_env = getenv("MSK_TRACE_REFILL") ? atoi(getenv("MSK_TRACE_REFILL")) : -1;
     const int max_inner = (int) env_u32("MSK_TRACE_QUANTUM", 4);
-    const int refill = refill_env >= 0 ? refill_env : (sc->trace_mode == 0 ? 0 : 16);
+    const int refill = (sc->trace_mode == 3) ? 0 : refill_env >= 0 ? refill_env : (sc->trace_mode == 0 ? 0 : 16);
     const size_t lds = sc->trace_lds_bytes + (size_t) env_u32("MSK_TRACE_PAD_LDS_KB", 0) * 1024;      // occupancy experiments only
     if (refill > 0) {        // k_trace_r
         if (sc->trace_mode == 0) hipLaunchKernelGGL(k_trace_r<0>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp, refill, max_inner);
@@ -435,7 +445,8 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
     }
     if (sc->trace_mode == 0) hipLaunchKernelGGL(k_trace<0>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp);
     else if (sc->trace_mode == 1) hipLaunchKernelGGL(k_trace<1>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp);
-    else hipLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp);
+    else if (sc->trace_mode == 2) hipLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp);
+    else hipLaunchKernelGGL(k_trace<3>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp);
 }
 
 // Renders the samples of `pix` (pass pixel table, host) into records; leaves records on device.
@@ -541,7 +552,7 @@ static uint32_t owned_spp(const msk_render_params *p) {
 // 8 M path slots either way.  Short rays (LDS-resident scene): many small regions, one chunk loop per wave.  Long rays
 // (k_trace_r): few large regions, so that lane replacement has a long list of rays to keep the lanes busy with.
 static void pool_shape(const msk_scene *sc, uint64_t total_samples, uint32_t *region_size, uint32_t *n_regions) {
-    const bool big = sc->trace_mode != 0;
+    const bool big = sc->trace_mode == 1 || sc->trace_mode == 2;
     uint32_t rs = env_u32("MSK_REGION_SIZE", big ? 2048 : 512), nr = env_u32("MSK_REGIONS", big ? 4096 : 16384);
     rs = std::max(64u, (rs + 63u) & ~63u);
     while (rs > 256 && total_samples / rs < nr) rs = std::max(256u, rs / 2);       // small jobs: keep the GPU full first
@@ -839,8 +850,11 @@ static int trace_batch(msk_scene *scene, uint64_t n, const float *rays, float *o
     else if (scene->trace_mode == 1)
         hipLaunchKernelGGL(k_trace_batch<1>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
                            d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
-    else
+    else if (scene->trace_mode == 2)
         hipLaunchKernelGGL(k_trace_batch<2>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
+                           d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_trace_batch<3>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
                            d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -35,7 +35,7 @@ namespace msk {
 struct DeviceScene {
     const float4 *nodes;        // 4 x float4 per node (msk_bvh.h)
     const float4 *nodes4;       // 8 x float4 per 4-wide node, or nullptr (scenes whose BVH is staged in LDS use `nodes`)
-    uint32_t root_ref4;
+    uint32_t root_ref4, n_nodes4;
     const float4 *tris;         // 4 x float4 per triangle, leaf order
     const float4 *tri_verts;    // 3 x float4 per triangle, scene-global order: p0|mesh p1|- p2|-
     const float4 *tri_normals;  // 3 x float4 per triangle (n0 n1 n2) or nullptr
@@ -297,11 +297,12 @@ struct TraceLds {
 };
 
 // stage nodes + triangles into dynamic LDS (all threads of the block)
-MSK_DEV TraceLds stage_scene(const DeviceScene &sc, float4 *lds, bool use_lds) {
+MSK_DEV TraceLds stage_scene(const DeviceScene &sc, float4 *lds, bool use_lds, bool wide = false) {
     TraceLds r;
     if (!use_lds) { r.nodes = sc.nodes; r.tris = sc.tris; return r; }
-    const uint32_t nn = sc.n_nodes * 4, nt = sc.n_tris * 4;
-    for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) lds[i] = sc.nodes[i];
+    const uint32_t nn = wide ? sc.n_nodes4 * 8 : sc.n_nodes * 4, nt = sc.n_tris * 4;
+    const float4 *src = wide ? sc.nodes4 : sc.nodes;
+    for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) lds[i] = src[i];
     for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[nn + i] = sc.tris[i];
     __syncthreads();
     r.nodes = lds; r.tris = lds + nn;
@@ -322,23 +323,24 @@ MSK_DEV TraceLds stage_scene(const DeviceScene &sc, float4 *lds, bool use_lds) {
 // between the phases — the compiler otherwise runs one side of a divergent region past the other's writes.
 #define MSK_HIT_UNOCCLUDED 0x80000000u
 #define MSK_PRIM_MASK 0x7fffffffu
-// MODE 0: binary tree staged in LDS; 1: binary tree in HBM/L2; 2: 4-wide tree in HBM/L2
+// MODE 0: binary tree staged in LDS; 1: binary tree in HBM/L2; 2: 4-wide tree in HBM/L2; 3: 4-wide tree staged in LDS
+#define MSK_OVF(MODE) ((MODE) == 1 || (MODE) == 2)      /* the stack can overflow to HBM only when the tree lives there */
 template <int MODE, bool ANY>
-MSK_DEV bool traverse_scene(const DeviceScene &sc, const TraceLds &g, f3 o, f3 d, float tmin, float tmax, const LaneStack<MODE != 0> &stack,
+MSK_DEV bool traverse_scene(const DeviceScene &sc, const TraceLds &g, f3 o, f3 d, float tmin, float tmax, const LaneStack<MSK_OVF(MODE)> &stack,
                             float *bt, float *bu, float *bv, uint32_t *bp) {
-    if (MODE == 2) return traverse4<ANY, MODE != 0>(sc.nodes4, g.tris, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
-    return traverse<ANY, MODE != 0>(g.nodes, g.tris, sc.root_ref, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+    if (MODE == 2 || MODE == 3) return traverse4<ANY, MSK_OVF(MODE)>(MODE == 3 ? g.nodes : sc.nodes4, g.tris, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+    return traverse<ANY, MSK_OVF(MODE)>(g.nodes, g.tris, sc.root_ref, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
 }
 
 template <int MODE>
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_trace(DeviceScene sc, PathState st, PassParams pp) {
-    constexpr bool LDS_SCENE = MODE == 0;
+    constexpr bool LDS_SCENE = MODE == 0 || MODE == 3;
     extern __shared__ float4 lds_dyn[];
     uint32_t *stack_base = (uint32_t *) lds_dyn;                         // stack_entries * MSK_BLOCK words
     float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
-    TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE);
-    const LaneStack<MODE != 0> stack{stack_base + threadIdx.x, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
+    TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE, MODE == 3);
+    const LaneStack<MSK_OVF(MODE)> stack{stack_base + threadIdx.x, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
                                      (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK};
     const uint32_t wave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
@@ -387,7 +389,7 @@ MSK_DEV void trav_begin(TravState &t, uint32_t root_ref, uint32_t n_tris, f3 o, 
 // `any` is a per-lane run-time flag on purpose: lanes in the shadow phase and lanes in the closest-hit phase share one
 // instruction stream instead of executing two instantiations one after the other.
 template <int MODE>
-MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t, const LaneStack<MODE != 0> &stack, int max_inner, bool any) {
+MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t, const LaneStack<MSK_OVF(MODE)> &stack, int max_inner, bool any) {
     const uint32_t DONE = 0xffffffffu;
     int steps = 0;
     bool found = false;
@@ -452,12 +454,12 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
 template <int MODE>
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner) {
-    constexpr bool LDS_SCENE = MODE == 0;
+    constexpr bool LDS_SCENE = MODE == 0 || MODE == 3;
     extern __shared__ float4 lds_dyn[];
     uint32_t *stack_base = (uint32_t *) lds_dyn;
     float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
-    TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE);
-    const LaneStack<MODE != 0> stack{stack_base + threadIdx.x, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
+    TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE, MODE == 3);
+    const LaneStack<MSK_OVF(MODE)> stack{stack_base + threadIdx.x, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
                                      (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK};
     const uint32_t wave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
@@ -514,12 +516,12 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
 template <int MODE>
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_trace_batch(DeviceScene sc, const float4 *rays, uint64_t n, float4 *out_hit, uint8_t *out_any, uint32_t *stack_ovf) {
-    constexpr bool LDS_SCENE = MODE == 0;
+    constexpr bool LDS_SCENE = MODE == 0 || MODE == 3;
     extern __shared__ float4 lds_dyn[];
     uint32_t *stack_base = (uint32_t *) lds_dyn;
     float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
-    TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE);
-    const LaneStack<MODE != 0> stack{stack_base + threadIdx.x, stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
+    TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE, MODE == 3);
+    const LaneStack<MSK_OVF(MODE)> stack{stack_base + threadIdx.x, stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
                                      (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK};
     for (uint64_t i = (uint64_t) blockIdx.x * MSK_BLOCK + threadIdx.x; i < n; i += (uint64_t) gridDim.x * MSK_BLOCK) {
         const float4 ro = rays[2 * i], rd = rays[2 * i + 1];

@@ -190,7 +190,8 @@ def test_large_mesh_uses_hbm_bvh(gpu_ctx, abi, hostmirror, oracle, golden_lookup
 
 @pytest.mark.parametrize("env", [dict(MSK_TRACE_REFILL="0"), dict(MSK_WIDE_BVH="0"), dict(MSK_WIDE_BVH="0", MSK_TRACE_REFILL="0"),
                                  dict(MSK_TRACE_REFILL="48", MSK_TRACE_QUANTUM="1"), dict(MSK_LDS_SCENE_KB="0", MSK_WIDE_BVH="0"),
-                                 dict(MSK_STACK_CAP="4"), dict(MSK_STACK_CAP="4", MSK_TRACE_REFILL="0", MSK_WIDE_BVH="0")])
+                                 dict(MSK_STACK_CAP="4"), dict(MSK_STACK_CAP="4", MSK_TRACE_REFILL="0", MSK_WIDE_BVH="0"),
+                                 dict(MSK_WIDE_LDS="1", MSK_TRACE_REFILL="0")])
 def test_every_traversal_kernel_gives_the_same_film(gpu_ctx, abi, hostmirror, oracle, golden_lookup, monkeypatch, env):
     """k_trace<0|1|2> (chunk loop) and k_trace_r<0|1|2> (lane replacement), binary and 4-wide trees: hit selection is by
     (t, prim), so every one of them must reproduce the oracle's film bit for bit."""
