@@ -329,7 +329,8 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     const size_t table_bytes = ((size_t) ds.n_tris * 3 + ds.n_meshes + ds.n_bsdfs * MSK_BSDF_F4 + ds.n_emitters * 2 +
                                 (ds.n_emitters * 95 + 3) / 4 + (ds.cdf_len + 3) / 4 + 72) * 16;
     s->lds_tables = table_bytes <= 40 * 1024;
-    s->shade_lds_bytes = s->lds_tables ? table_bytes : 0;
+    // + the waves' done-queues (k_shade_gen: 3 x MSK_DONE_Q float4 per wave)
+    s->shade_lds_bytes = (s->lds_tables ? table_bytes : 0) + (size_t) (MSK_BLOCK / MSK_WAVE) * 3 * MSK_DONE_Q * 16;
     if (s->trace_lds_bytes > ctx->prop.sharedMemPerBlock) {
         delete s;
         return fail(ctx, MSK_ERR_UNSUPPORTED, "BVH depth %d needs %zu B of traversal stack per block", bvh.max_depth, stack_bytes);
@@ -493,7 +494,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
         for (uint32_t g = 0; g < group; ++g, ++it) {
             hipEvent_t a = nullptr, b = nullptr, c = nullptr;
             if (timing) { a = ev.get(); b = ev.get(); c = ev.get(); (void) hipEventRecord(a, stream); }
-#define MSK_SHADE(L, D) hipLaunchKernelGGL((k_shade_gen<L, D>), dim3(grid), dim3(MSK_BLOCK), ((L) ? sc->shade_lds_bytes : 0) + shade_pad_lds, stream, sc->dev, sb.st, pp)
+#define MSK_SHADE(L, D) hipLaunchKernelGGL((k_shade_gen<L, D>), dim3(grid), dim3(MSK_BLOCK), sc->shade_lds_bytes + shade_pad_lds, stream, sc->dev, sb.st, pp)
             if (sc->lds_tables) { if (diffuse_only) MSK_SHADE(true, true); else MSK_SHADE(true, false); }
             else { if (diffuse_only) MSK_SHADE(false, true); else MSK_SHADE(false, false); }
 #undef MSK_SHADE

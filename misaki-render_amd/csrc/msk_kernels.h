@@ -774,6 +774,46 @@ MSK_DEV spec bsdf_sample(const BsdfRec &b, f3 wi, float sample1, f2 sample, spec
 // ------------------------------------------------------------------------------------------
 // k_shade_gen
 // ------------------------------------------------------------------------------------------
+// Lanes of one wave exchanging data through LDS: the compiler may otherwise run one side of a divergent region past the
+// other side's LDS accesses (measured, see the k_trace note).
+MSK_DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// render_sample's tail for one finished path (integrator.cpp:115-125): ray weight, XYZ, film position -> sample record
+template <bool DIFFUSE_ONLY>
+MSK_DEV void emit_record(const DeviceScene &sc, const SceneTables &tb, const PassParams &pp, spec wl, spec res, uint32_t j,
+                         uint32_t si, uint32_t pix) {
+    spec wgt;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wgt.v[k] = wavelength_weight(wl.v[k]);
+    const spec result = res * wgt;
+    float X, Y, Z;
+    spectrum_to_xyz(tb.cie, result, wl, &X, &Y, &Z);
+    const uint64_t key = counter_key(pp.seed, pix, pp.sample_first + si * pp.sample_stride);
+    const f2 jit = counter_pair(key, 0);
+    const float px = (float) (pix % (uint32_t) sc.width) + jit.x, py = (float) (pix / (uint32_t) sc.width) + jit.y;
+    const uint4 pt = pp.pix_table[j];
+    const size_t r = (((size_t) pt.z << 32) | pt.y) + (size_t) si * pt.w;
+    pp.rec_a[r] = make_float4(X, Y, Z, px);
+    pp.rec_b[r] = py;
+    if (!DIFFUSE_ONLY && pp.aov_rgb) {                             // aov.cpp:124-136: the sample before ray_weight
+        float x0, y0, z0;
+        spectrum_to_xyz(tb.cie, res, wl, &x0, &y0, &z0);
+        pp.aov_rgb[r] = make_float4(3.240479f * x0 + (-1.537150f * y0 + -0.498535f * z0),
+                                    -0.969256f * x0 + (1.875991f * y0 + 0.041556f * z0),
+                                    0.055648f * x0 + (-0.204043f * y0 + 1.057311f * z0), px);
+    }
+}
+
+// Finished paths are parked in a wave-local LDS queue and turned into records 64 at a time: the record arithmetic (four
+// fp64 cosh, twelve CIE lookups, one RNG draw — about a fifth of this kernel's instructions) then runs with all lanes
+// busy instead of once per chunk for the ~25 % of its lanes that happened to finish.
+#define MSK_DONE_Q 128                     /* entries per wave: up to 63 parked + 64 new */
+struct DoneQueue { float4 *wl, *res; uint4 *id; };
+
 template <bool LDS_TABLES, bool DIFFUSE_ONLY>
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
@@ -781,6 +821,13 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
     const SceneTables tb = stage_tables<LDS_TABLES>(sc, lds_dyn);
     const uint32_t wave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
+    // this wave's done-queue: after the staged tables, 3 x MSK_DONE_Q float4 per wave
+    DoneQueue dq;
+    {
+        float4 *qbase = lds_dyn + (LDS_TABLES ? tables_lds_float4s(sc) : 0u) + (threadIdx.x / MSK_WAVE) * (3 * MSK_DONE_Q);
+        dq.wl = qbase; dq.res = qbase + MSK_DONE_Q; dq.id = (uint4 *) (qbase + 2 * MSK_DONE_Q);
+    }
+    uint32_t n_queued = 0;
     if (wave >= pp.n_regions) return;
     RegionCtl rc = pp.regions[wave];
     const uint32_t n_in = rc.count;
@@ -966,26 +1013,30 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
                 }
             }
         }
-        // ---- finished paths: render_sample's tail (integrator.cpp:115-125) -> sample record
-        if (active && !alive) {
-            spec wgt;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) wgt.v[k] = wavelength_weight(wl.v[k]);
-            const spec result = res * wgt;
-            float X, Y, Z;
-            spectrum_to_xyz(tb.cie, result, wl, &X, &Y, &Z);
-            const f2 jit = counter_pair(key, 0);
-            const float px = (float) (pix % (uint32_t) sc.width) + jit.x, py = (float) (pix / (uint32_t) sc.width) + jit.y;
-            const uint4 pt = pp.pix_table[id.x];
-            const size_t r = (((size_t) pt.z << 32) | pt.y) + (size_t) id.y * pt.w;
-            pp.rec_a[r] = make_float4(X, Y, Z, px);
-            pp.rec_b[r] = py;
-            if (!DIFFUSE_ONLY && pp.aov_rgb) {                             // aov.cpp:124-136: the sample before ray_weight
-                float x0, y0, z0;
-                spectrum_to_xyz(tb.cie, res, wl, &x0, &y0, &z0);
-                pp.aov_rgb[r] = make_float4(3.240479f * x0 + (-1.537150f * y0 + -0.498535f * z0),
-                                            -0.969256f * x0 + (1.875991f * y0 + 0.041556f * z0),
-                                            0.055648f * x0 + (-0.204043f * y0 + 1.057311f * z0), px);
+        // ---- finished paths: park them; 64 parked paths become records together (emit_record)
+        {
+            const bool fin = active && !alive;
+            const unsigned long long fm = __ballot(fin);
+            if (fm != 0ull) {
+                if (fin) {
+                    const uint32_t q = n_queued + (uint32_t) __popcll(fm & ((1ull << lane) - 1ull));
+                    dq.wl[q] = to4(wl); dq.res[q] = to4(res); dq.id[q] = make_uint4(id.x, id.y, id.z, 0u);
+                }
+                n_queued += (uint32_t) __popcll(fm);
+                wave_sync();
+                if (n_queued >= MSK_WAVE) {
+                    const spec qwl = from4(dq.wl[lane]), qres = from4(dq.res[lane]);
+                    const uint4 qid = dq.id[lane];
+                    emit_record<DIFFUSE_ONLY>(sc, tb, pp, qwl, qres, qid.x, qid.y, qid.z);
+                    // move the rest (< 64 entries) to the front
+                    const uint32_t rem = n_queued - MSK_WAVE;
+                    float4 a = make_float4(0, 0, 0, 0), b = a; uint4 c4 = make_uint4(0, 0, 0, 0);
+                    if (lane < rem) { a = dq.wl[MSK_WAVE + lane]; b = dq.res[MSK_WAVE + lane]; c4 = dq.id[MSK_WAVE + lane]; }
+                    wave_sync();
+                    if (lane < rem) { dq.wl[lane] = a; dq.res[lane] = b; dq.id[lane] = c4; }
+                    wave_sync();
+                    n_queued = rem;
+                }
             }
         }
         // ---- in-place compaction of the survivors (wave ballot + prefix popcount)
@@ -1005,6 +1056,12 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
         cursor += __popcll(m);
     }
 
+    // ---- the paths still parked (< 64)
+    if (lane < n_queued) {
+        const spec qwl = from4(dq.wl[lane]), qres = from4(dq.res[lane]);
+        const uint4 qid = dq.id[lane];
+        emit_record<DIFFUSE_ONLY>(sc, tb, pp, qwl, qres, qid.x, qid.y, qid.z);
+    }
     // ---- regeneration: fill the free tail with new camera samples (integrator.cpp:103-116)
     const uint32_t n_free = pp.region_size - cursor;
     const unsigned long long first = rc.next_sample, left = rc.end_sample - rc.next_sample;
