@@ -398,6 +398,11 @@ struct StateBufs {
 
 struct Workspace {
     StateBufs sb;
+    // Single-pass renders repeated with the same shape (bench, animation frames) reuse the uploaded plan: the pass pixel
+    // table (4 MB at 512^2), block tables and the regions' initial share of the samples.
+    std::vector<uint64_t> plan_key;          // empty = nothing cached
+    uint64_t plan_n_pix = 0;
+    DevBuf counts_init; unsigned long long counts_total = 0; uint32_t counts_regions = 0;
     DevBuf block_buf, blocks, block_of, spiral, pix, rec_a, rec_b, film;
     DevBuf aov_rec[MSK_MAX_AOV_GROUPS + 1], aov_block_buf[MSK_MAX_AOV_GROUPS + 1];   // [n_groups] = the nested path's RGB
 };
@@ -459,18 +464,29 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
                          const AovParams *aov = nullptr, float4 *aov_rgb = nullptr) {
     msk_ctx *ctx = sc->ctx;
     const unsigned long long total = (unsigned long long) n_pix * spp_owned;
-    // static, interleaved partition of the pass's samples over the regions (see RegionCtl)
-    std::vector<RegionCtl> init(n_regions);
-    std::memset(init.data(), 0, init.size() * sizeof(RegionCtl));
-    const unsigned long long n_chunks = (total + 63) / 64;
-    for (uint32_t r = 0; r < n_regions; ++r) {
-        const unsigned long long mine = n_chunks > r ? (n_chunks - r + n_regions - 1) / n_regions : 0;
-        unsigned long long n = mine * 64;
-        if (mine && (mine - 1) * n_regions + r == n_chunks - 1) n -= n_chunks * 64 - total;   // partial last chunk
-        init[r].next_sample = 0; init[r].end_sample = n;
+    // static, interleaved partition of the pass's samples over the regions (see RegionCtl); the initial records are kept
+    // on the device and copied from there when the next render has the same shape
+    Workspace *wsp = sc->ws;
+    if (!(wsp && wsp->counts_total == total && wsp->counts_regions == n_regions && wsp->counts_init.p)) {
+        std::vector<RegionCtl> init(n_regions);
+        std::memset(init.data(), 0, init.size() * sizeof(RegionCtl));
+        const unsigned long long n_chunks = (total + 63) / 64;
+        for (uint32_t r = 0; r < n_regions; ++r) {
+            const unsigned long long mine = n_chunks > r ? (n_chunks - r + n_regions - 1) / n_regions : 0;
+            unsigned long long n = mine * 64;
+            if (mine && (mine - 1) * n_regions + r == n_chunks - 1) n -= n_chunks * 64 - total;   // partial last chunk
+            init[r].next_sample = 0; init[r].end_sample = n;
+        }
+        if (wsp) {
+            HIP_TRY(ctx, wsp->counts_init.reserve(init.size() * sizeof(RegionCtl)));
+            HIP_TRY(ctx, hipMemcpy(wsp->counts_init.p, init.data(), init.size() * sizeof(RegionCtl), hipMemcpyHostToDevice));
+            wsp->counts_total = total; wsp->counts_regions = n_regions;
+        } else {
+            HIP_TRY(ctx, hipMemcpyAsync(sb.counts.p, init.data(), init.size() * sizeof(RegionCtl), hipMemcpyHostToDevice, stream));
+            HIP_TRY(ctx, hipStreamSynchronize(stream));
+        }
     }
-    HIP_TRY(ctx, hipMemcpyAsync(sb.counts.p, init.data(), init.size() * sizeof(RegionCtl), hipMemcpyHostToDevice, stream));
-    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    if (wsp) HIP_TRY(ctx, hipMemcpyAsync(sb.counts.p, wsp->counts_init.p, (size_t) n_regions * sizeof(RegionCtl), hipMemcpyDeviceToDevice, stream));
     PassParams pp;
     pp.seed = prm->seed; pp.spp_owned = spp_owned; pp.sample_first = prm->sample_first;
     pp.sample_stride = prm->sample_stride ? prm->sample_stride : 1;
@@ -632,24 +648,35 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
         }
         passes.push_back({b0, b1}); b0 = b1;
     }
-    HIP_TRY(ctx, d_blocks.upload(owned)); HIP_TRY(ctx, d_block_of.upload(block_of)); HIP_TRY(ctx, d_spiral.upload(spiral_id));
+    const std::vector<uint64_t> plan_key = {(uint64_t) W, (uint64_t) H, (uint64_t) bs, (uint64_t) border, prm->block_first, bstride,
+                                            spp_owned, passes.size(), owned.size()};
+    const bool plan_cached = passes.size() == 1 && ws.plan_key == plan_key;
+    if (!plan_cached) {
+        ws.plan_key.clear();
+        HIP_TRY(ctx, d_blocks.upload(owned)); HIP_TRY(ctx, d_block_of.upload(block_of)); HIP_TRY(ctx, d_spiral.upload(spiral_id));
+    }
     StateBufs &sb = ws.sb;
     if (!owned.empty()) HIP_TRY(ctx, sb.alloc(n_slots, n_regions));
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_trace, ev_shade, ev_resolve;
     DevBuf &d_pix = ws.pix, &d_rec_a = ws.rec_a, &d_rec_b = ws.rec_b;
     for (auto &ps : passes) {
-        std::vector<uint4> pix;
-        for (size_t b = ps.first; b < ps.second; ++b) {
-            const uint32_t npix = (uint32_t) (owned[b].size_x * owned[b].size_y);
-            for (int y = 0; y < owned[b].size_y; ++y)
-                for (int x = 0; x < owned[b].size_x; ++x) {
-                    const uint64_t rec0 = (uint64_t) owned[b].pixel_base * spp_owned + (uint32_t) (y * owned[b].size_x + x);
-                    pix.push_back(make_uint4((uint32_t) ((owned[b].off_y + y) * W + owned[b].off_x + x), (uint32_t) rec0,
-                                             (uint32_t) (rec0 >> 32), npix));
-                }
+        uint64_t n_pix = ws.plan_n_pix;
+        if (!plan_cached) {
+            std::vector<uint4> pix;
+            for (size_t b = ps.first; b < ps.second; ++b) {
+                const uint32_t npix = (uint32_t) (owned[b].size_x * owned[b].size_y);
+                for (int y = 0; y < owned[b].size_y; ++y)
+                    for (int x = 0; x < owned[b].size_x; ++x) {
+                        const uint64_t rec0 = (uint64_t) owned[b].pixel_base * spp_owned + (uint32_t) (y * owned[b].size_x + x);
+                        pix.push_back(make_uint4((uint32_t) ((owned[b].off_y + y) * W + owned[b].off_x + x), (uint32_t) rec0,
+                                                 (uint32_t) (rec0 >> 32), npix));
+                    }
+            }
+            HIP_TRY(ctx, d_pix.upload(pix));
+            n_pix = pix.size();
+            if (passes.size() == 1) { ws.plan_key = plan_key; ws.plan_n_pix = n_pix; }
         }
-        const uint64_t n_rec = (uint64_t) pix.size() * spp_owned;
-        HIP_TRY(ctx, d_pix.upload(pix));
+        const uint64_t n_rec = n_pix * spp_owned;
         HIP_TRY(ctx, d_rec_a.reserve(n_rec * 16)); HIP_TRY(ctx, d_rec_b.reserve(n_rec * 4));
         AovParams ap;
         std::memset(&ap, 0, sizeof ap);
@@ -662,7 +689,7 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
             }
             if (aov->rgba) { HIP_TRY(ctx, ws.aov_rec[MSK_MAX_AOV_GROUPS].reserve(n_rec * 16)); aov_rgb = ws.aov_rec[MSK_MAX_AOV_GROUPS].as<float4>(); }
         }
-        rc = run_wavefront(sc, stream, prm, spp_owned, d_pix.as<uint4>(), pix.size(), d_rec_a.as<float4>(),
+        rc = run_wavefront(sc, stream, prm, spp_owned, d_pix.as<uint4>(), n_pix, d_rec_a.as<float4>(),
                            d_rec_b.as<float>(), sb, region_size, n_regions, stats, ev, ev_trace, ev_shade, aov ? &ap : nullptr, aov_rgb);
         if (rc) return rc;
         const uint32_t nb = (uint32_t) (ps.second - ps.first);
