@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=SPP_PER_GPU, help="spp per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", choices=("samples", "tiles"), default="samples",
+                    help="N > 1: which axis the ranks split (misaki-render_amd/multigpu.py); both end in one film reduce")
     args = ap.parse_args()
 
     import torch
@@ -81,7 +83,7 @@ def main():
     ctx = abi.Context(local_rank)
     scene = abi.Scene(ctx, flat)
     spp_total = mg.weak_scaling_spp(args.spp, world)
-    prm = mg.shard_params(abi, spp_total, rank, world, seed=0)
+    prm = mg.shard_params(abi, spp_total, rank, world, mode=args.shard, seed=0)
     film = torch.zeros((HEIGHT, WIDTH, 5), dtype=torch.float32, device="cuda")
 
     def step():
@@ -146,7 +148,7 @@ def main():
             "config": {"workload": f"cbox {WIDTH}x{HEIGHT} @ {args.spp} spp per GPU ({spp_total} spp total), diffuse BSDFs, "
                                    f"path integrator (NEE+MIS, RR from depth 4), counter RNG, Gaussian filter, "
                                    f"ordered film resolve included",
-                       "parallelism": f"tile-shard x{world}" if world > 1 else "single GPU",
+                       "parallelism": f"{args.shard[:-1]}-shard x{world} + RCCL film reduce" if world > 1 else "single GPU",
                        "samples_per_step": samples_step,
                        "segments_per_sample": round(seg / max(smp, 1), 3)},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,4 +1,4 @@
-"""Multi-GPU decomposition of the hot path: one process per GPU, pixel-tile shard, one film reduce.
+"""Multi-GPU decomposition of the hot path: one process per GPU, pixel-tile or sample shard, one film reduce.
 
 Samples are independent; the only coupling is the linear film sum (imageblock.cpp:100-110,
 157-173).  Rank r of G renders the spiral blocks (imageblock.cpp:187-247) whose id is r mod G —
@@ -7,12 +7,23 @@ H x W x 5 film of weighted sums; the films are then summed onto rank 0 with ONE 
 (RCCL `reduce` over xGMI on the GPU box, gloo in the CPU tests).  A pixel further than the filter
 border (2 px) from a tile edge receives a non-zero value from exactly one rank, so the reduced film
 equals the single-GPU film bit for bit there; border pixels differ by fp32 re-association of <= 4 terms.
+
+mode="samples" (SURVEY §8e's primary scheme, bench.py's default) shards the other axis: rank r renders EVERY tile for
+the sample indices s = r (mod G).  Every rank then runs the single-GPU workload shape (all 256 tiles of a 512^2 film,
+spp/G samples each), which matters for the ordered film replay: its parallelism is tiles x pixels and its critical path
+is one pixel's spp-long chain, so 1/G of the tiles at the full spp (tile shard) starves it on a small film.  The reduced
+film then differs from the single-GPU one by fp32 re-association of G partial sums per pixel (<< the 1e-4 tolerance).
 """
 
 
-def shard_params(abi, spp_total, rank, world, **kw):
-    """Render parameters of rank `rank`: blocks id % world == rank, every sample of those blocks."""
-    return abi.render_params(spp=spp_total, block_first=rank, block_stride=world, **kw)
+def shard_params(abi, spp_total, rank, world, mode="tiles", **kw):
+    """Render parameters of rank `rank`.  mode "tiles": blocks id % world == rank, every sample of those blocks;
+    mode "samples": every block, sample indices s % world == rank."""
+    if mode == "tiles":
+        return abi.render_params(spp=spp_total, block_first=rank, block_stride=world, **kw)
+    if mode == "samples":
+        return abi.render_params(spp=spp_total, sample_first=rank, sample_stride=world, **kw)
+    raise ValueError(mode)
 
 
 def reduce_film(film, dist=None, dst=0):

@@ -10,7 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, mode="tiles"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -26,8 +26,11 @@ def _worker(rank, world, port, out_path):
     flat = hm.cbox_scene(96, 64, coeff_lookup=lambda rgb: (0.0, 0.0, 1.0))
     sc = orc.scene(flat)
     spp_total = mg.weak_scaling_spp(2, world)
-    prm = mg.shard_params(abi, spp_total, rank, world, seed=5)
-    assert prm.block_first == rank and prm.block_stride == world and prm.spp == 2 * world
+    prm = mg.shard_params(abi, spp_total, rank, world, mode=mode, seed=5)
+    if mode == "tiles":
+        assert prm.block_first == rank and prm.block_stride == world and prm.spp == 2 * world
+    else:
+        assert prm.sample_first == rank and prm.sample_stride == world and prm.spp == 2 * world and prm.block_stride == 1
     film_np, st = sc.render(prm, threads=2)
     film = torch.from_numpy(film_np.copy())
     mg.reduce_film(film, dist)
@@ -56,3 +59,18 @@ def test_two_rank_tile_shard_and_film_reduce(tmp_path):
     assert np.array_equal(reduced[interior], full[interior])         # exactly one rank contributes
     assert np.allclose(reduced, full, rtol=3e-7, atol=1e-6)           # tile borders: <= 4 terms re-associated
     assert reduced[..., 4].min() > 0
+
+
+def test_two_rank_sample_shard_and_film_reduce(tmp_path):
+    """bench.py's default for N > 1: every rank renders all tiles for its sample indices; one reduce."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "film_s.npz")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out, "samples"), nprocs=2, join=True)
+    d = np.load(out)
+    reduced, full = d["reduced"], d["full"]
+    assert d["samples"][0] == d["full_samples"] == 96 * 64 * 4       # every sample rendered exactly once
+    assert np.allclose(reduced, full, rtol=3e-6, atol=1e-6)           # two partial sums per pixel re-associated
+    hm = importlib.import_module("misaki-render_amd.hostmirror")
+    err = np.linalg.norm(hm.develop(reduced)[..., :3] - hm.develop(full)[..., :3], axis=-1)
+    assert err.max() < 1e-4                                           # the north star's per-pixel L2 tolerance
