@@ -5,6 +5,7 @@ from the reference's own formulas / from the one leaf of the reference that buil
 (ext/rgb2spec -> oracle/_ref), plus hand-derived closed-form values.
 """
 import ctypes as C
+import json
 import os
 import struct
 
@@ -311,3 +312,33 @@ def test_pcg_block_and_counter_modes_estimate_the_same_image(oracle, hostmirror,
     d = tiles(d_film)
     assert np.all(np.abs(a - d) <= 2e-3 * (np.abs(a) + 0.3))      # last-ulp differences only flip rare decisions
     sc.close()
+
+
+# ----------------------------------------------------------------------------- regression anchor of the oracle itself
+def test_oracle_films_match_the_committed_anchor(oracle, hostmirror, abi):
+    """GPU parity is measured against the oracle, so a change that moved both together would go unnoticed: three small
+    films of the oracle (diffuse cbox; metal + glass; open box + environment with rr_depth 2) are pinned by SHA-256
+    (tests/golden/oracle_film.json, written by tests/golden/make_film_golden.py).  Update the anchor deliberately."""
+    import hashlib
+    import importlib.util
+    here = os.path.join(ROOT, "tests", "golden")
+    spec = importlib.util.spec_from_file_location("make_film_golden", os.path.join(here, "make_film_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    anchor = json.load(open(os.path.join(here, "oracle_film.json")))
+    trip = json.load(open(os.path.join(here, "rgb2spec_triplets.json")))
+    table = {tuple(round(c, 6) for c in v["rgb"]): tuple(struct.unpack(">f", bytes.fromhex(h))[0] for h in v["coeff_hex"])
+             for v in trip.values()}
+    seen = 0
+    for name, flat, kw in mod.scenes(hostmirror, lambda rgb: table[tuple(round(c, 6) for c in rgb)]):
+        sc = oracle.scene(flat)
+        film, st = sc.render(abi.render_params(**kw), threads=3)
+        sc.close()
+        a = anchor[name]
+        assert list(film.shape) == a["shape"] and int(st.samples) == a["samples"]
+        for key, hexval in a["pixels_hex"].items():
+            y, x = (int(v) for v in key.split(","))
+            assert film[y, x].tobytes().hex() == hexval, (name, key)
+        assert hashlib.sha256(film.tobytes()).hexdigest() == a["sha256"], name
+        seen += 1
+    assert seen == 3
