@@ -5,15 +5,16 @@
 //
 //   k_shade_gen  wave w sweeps its region 64 slots at a time: finishes the previous bounce of
 //                every path (emitter hit + MIS, Russian roulette), runs the next bounce's
-//                NEE + BSDF sampling (PathTracer::sample body, path.cpp:33-123), writes a sample
-//                record for every finished path, compacts the survivors to the front of the
-//                region IN PLACE with a wave ballot + prefix popcount (no LDS, no block
-//                barrier, no global queue atomic), then refills the free tail of the region
-//                with new camera samples (render_sample, integrator.cpp:103-116) taken from
-//                one global cursor (one atomic per wave per iteration).
+//                NEE + BSDF sampling (PathTracer::sample body, path.cpp:33-123), parks finished
+//                paths in a wave-local LDS queue and writes their sample records 64 at a time,
+//                compacts the survivors to the front of the region IN PLACE with a wave ballot +
+//                prefix popcount (no block barrier, no global queue, no atomic), then refills the
+//                free tail of the region with new camera samples (render_sample,
+//                integrator.cpp:103-116) from the region's own static share of the pass (RegionCtl).
 //   k_trace      per live slot: the pending shadow ray (Scene::ray_test, scene.cpp:255-273) and
 //                the extension ray (Scene::ray_intersect, scene.cpp:216-253) against the
-//                flattened BVH, nodes + triangles staged in LDS when the scene is small.
+//                flattened BVH: k_trace<0> with nodes + triangles staged in LDS when the scene is
+//                small, k_trace_r<2> (4-wide nodes in HBM/L2, lane replacement) when it is not.
 //
 // After the last iteration k_resolve_blocks / k_film_put rebuild the film from the per-sample
 // records in exactly the order ImageBlock::put / Film::put accumulate them
