@@ -153,3 +153,41 @@ def test_render_through_the_plugin_interface(hostlib, hostmirror, oracle, tmp_pa
     assert np.allclose(rgba, hostmirror.develop(ref), rtol=1e-6, atol=1e-7)
     assert os.path.getsize(tmp_path / "out.exr") > 96 * 64 * 16
     sc.close()
+
+
+def _cli():
+    import __graft_entry__ as ge
+    ge.build_gpu_library()
+    ge.build_host_library()
+    return os.path.join(ge.PKG, "lib", "misaki-cli")
+
+
+def test_cli_usage_and_errors(cbox_xml, tmp_path):
+    """misaki-cli (the reference's src/apps/main.cpp with arguments): usage, help, and the caught-exception path
+    (main.cpp:55-57) — none of which touches the GPU."""
+    import subprocess
+    cli = _cli()
+    r = subprocess.run([cli], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage: misaki-cli" in r.stderr
+    r = subprocess.run([cli, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "usage" in r.stdout
+    r = subprocess.run([cli, str(tmp_path / "missing.xml")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Caught a critical exception" in (r.stderr + r.stdout) and "file not exists" in (r.stderr + r.stdout)
+    bad = tmp_path / "bad.xml"
+    bad.write_text(open(cbox_xml).read().replace('<integrator type="path">', '<integrator type="path"><integer name="rr_depth" value="0"/>'))
+    r = subprocess.run([cli, str(bad), "-q"], capture_output=True, text=True)
+    assert r.returncode == 1 and "rr_depth" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_cli_renders_a_scene_file_to_exr(hostmirror, tmp_path):
+    import subprocess
+    xml = hostmirror.write_scene_xml(hostmirror.cbox_meshes(), str(tmp_path), 64, 48, 4)
+    out = tmp_path / "image.exr"
+    r = subprocess.run([_cli(), xml, "-o", str(out), "-D", "spp=2", "-q"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    raw = out.read_bytes()
+    assert struct.unpack("<I", raw[:4])[0] == 20000630 and len(raw) > 64 * 48 * 16
+    # the last scanline's R plane is finite and the image is not black
+    tail = np.frombuffer(raw[-64 * 4:], np.float32)
+    assert np.isfinite(tail).all() and np.frombuffer(raw[-64 * 48 * 16:], np.float32).max() > 0
