@@ -6,9 +6,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))));
 import numpy as np
 abi = importlib.import_module("misaki-render_amd.abi"); hm = importlib.import_module("misaki-render_amd.hostmirror")
 import oracle_binding
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-ctx = abi.Context(0); orc = oracle_binding.load()
 
 
 def random_scene(rng):
@@ -50,21 +47,32 @@ def random_scene(rng):
     return hm.flatten(meshes, 48, 40, env=env)
 
 
-bad = 0
-for s in range(seed0, seed0 + n):
-    rng = np.random.RandomState(s)
-    flat = random_scene(rng)
-    kw = dict(spp=4, seed=int(rng.randint(0, 1000)), rr_depth=int(rng.choice([1, 2, 5])), max_depth=int(rng.choice([-1, -1, 1, 3, 6])),
-              hide_emitters=int(rng.randint(0, 2)), block_size=int(rng.choice([8, 16, 32])))
-    g, o = abi.Scene(ctx, flat), orc.scene(flat)
-    film, st = g.render(abi.render_params(**kw))
-    ref, rst = o.render(abi.render_params(**kw), threads=8)
-    same = np.array_equal(film.view(np.uint32), ref.view(np.uint32))
-    nan_same = np.array_equal(np.isnan(film), np.isnan(ref))
-    if not same:
-        bad += 1
-        d = film.view(np.uint32) != ref.view(np.uint32)
-        print("seed %d: %d values differ (nan pattern equal: %s) params %s" % (s, int(d.sum()), nan_same, kw))
-    g.close(); o.close()
-print("fuzz: %d scenes, %d with a film different from the oracle's" % (n, bad))
-sys.exit(1 if bad else 0)
+def random_params(rng):
+    return dict(spp=4, seed=int(rng.randint(0, 1000)), rr_depth=int(rng.choice([1, 2, 5])), max_depth=int(rng.choice([-1, -1, 1, 3, 6])),
+                hide_emitters=int(rng.randint(0, 2)), block_size=int(rng.choice([8, 16, 32])))
+
+
+def sweep(ctx, orc, seeds, verbose=True):
+    bad = []
+    for s in seeds:
+        rng = np.random.RandomState(s)
+        flat = random_scene(rng)
+        kw = random_params(rng)
+        g, o = abi.Scene(ctx, flat), orc.scene(flat)
+        film, st = g.render(abi.render_params(**kw))
+        ref, rst = o.render(abi.render_params(**kw), threads=8)
+        if not np.array_equal(film.view(np.uint32), ref.view(np.uint32)):
+            bad.append(s)
+            if verbose:
+                d = film.view(np.uint32) != ref.view(np.uint32)
+                print("seed %d: %d values differ (nan pattern equal: %s) params %s" % (s, int(d.sum()), np.array_equal(np.isnan(film), np.isnan(ref)), kw))
+        g.close(); o.close()
+    return bad
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = sweep(abi.Context(0), oracle_binding.load(), range(seed0, seed0 + n))
+    print("fuzz: %d scenes, %d with a film different from the oracle's" % (n, len(bad)))
+    sys.exit(1 if bad else 0)
