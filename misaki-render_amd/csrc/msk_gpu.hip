@@ -280,6 +280,15 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     ds.filter_border = (int) std::ceil(d->film.filter_radius - .5f);                  // rfilter.cpp:22
     std::memcpy(ds.lut, d->film.filter_lut, sizeof ds.lut);
     // constant.cpp:21-28 set_scene: the sphere around Scene::bbox() (bbox.h:105-112), in fp32 exactly as the oracle does
+    {   // oracle D10: the triangle-bounds predicate's padding, computed exactly as the oracle does (0.5e-4 * |hi - lo|)
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t t = 0; t < d->n_faces; ++t)
+            for (int v = 0; v < 3; ++v)
+                for (int k = 0; k < 3; ++k) { const float q = pos[(size_t) t * 9 + v * 3 + k]; lo[k] = std::min(lo[k], q); hi[k] = std::max(hi[k], q); }
+        const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        const float diag = d->n_faces ? std::sqrt(ex * ex + (ey * ey + ez * ez)) : 1.f;
+        ds.tri_pad = 0.5e-4f * diag;
+    }
     ds.env_emitter = env_emitter; ds.env_radius = 0.f;
     if (env_emitter >= 0) {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};

@@ -59,6 +59,7 @@ struct DeviceScene {
     float lut[33];
     int32_t env_emitter;        // index of the constant environment emitter in `emitters`, or -1 (scene.cpp:35-41)
     float env_radius;           // ConstantBackgroundEmitter::m_bsphere.radius after set_scene (constant.cpp:21-28)
+    float tri_pad;              // oracle D10: padding of the per-triangle bounds predicate in tri_test (0.5e-4 scene diagonal)
 };
 
 struct PathState {
@@ -118,8 +119,11 @@ MSK_DEV float xor_sign(float a, uint32_t s) { return __uint_as_float(__float_as_
 
 // Embree 3 Moeller-Trumbore, restated (see oracle/oracle.cpp header for the derivation);
 // tmax is the ray's ORIGINAL far bound.
+// + oracle D10: when the ray is numerically parallel to the triangle's plane, the hit point of an accepted hit must lie
+// in the triangle's own bounding box grown by `pad` (same arithmetic as the oracle): acceptance is then a property of the
+// ray and the triangle, not of the tree.  Eight instructions per accepted hit, the box check itself almost never.
 MSK_DEV bool tri_test(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, float tmin, float tmax,
-                      float *t, float *u, float *v) {
+                      float *t, float *u, float *v, float pad) {
     const f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z),
              ng = mk3(q3.x, q3.y, q3.z);
     const f3 C = v0 - o;
@@ -136,7 +140,14 @@ MSK_DEV bool tri_test(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, fl
     *t = T * rcp;
     *u = fmin_std(U * rcp, 1.f);
     *v = fmin_std(V * rcp, 1.f);
-    return true;
+    // oracle D10, for rays within ~0.6 degrees of the triangle's plane only: the hit point o + t d lies in the bounding
+    // box of (v0, v0 - e1, v0 + e2) grown by `pad`
+    if (abs_den >= 1e-2f * (fabsf(ng.x * d.x) + (fabsf(ng.y * d.y) + fabsf(ng.z * d.z)))) return true;
+    const f3 w1 = v0 - e1, w2 = v0 + e2;
+    const float px = o.x + *t * d.x, py = o.y + *t * d.y, pz = o.z + *t * d.z;
+    return px >= fmin_std(v0.x, fmin_std(w1.x, w2.x)) - pad && px <= fmax_std(v0.x, fmax_std(w1.x, w2.x)) + pad &&
+           py >= fmin_std(v0.y, fmin_std(w1.y, w2.y)) - pad && py <= fmax_std(v0.y, fmax_std(w1.y, w2.y)) + pad &&
+           pz >= fmin_std(v0.z, fmin_std(w1.z, w2.z)) - pad && pz <= fmax_std(v0.z, fmax_std(w1.z, w2.z)) + pad;
 }
 
 // Reciprocal direction of the slab test: v_rcp_f32 (1 ulp) instead of an IEEE division (11 instructions each).  The slab
@@ -185,7 +196,7 @@ struct LaneStack {
 template <bool ANY, bool OVF>
 MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict__ tris, uint32_t root_ref,
                       uint32_t n_tris, f3 o, f3 d, float tmin, float tmax, const LaneStack<OVF> &stack, float *best_t, float *best_u,
-                      float *best_v, uint32_t *best_prim) {
+                      float *best_v, uint32_t *best_prim, float tri_pad) {
     float bt = tmax, bu = 0.f, bv = 0.f;
     uint32_t bp = MSK_NO_PRIM;
     *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
@@ -220,7 +231,7 @@ MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict
             const float4 *q = tris + (size_t) (first + i) * 4;
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             float t, u, v;
-            if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v)) {
+            if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v, tri_pad)) {
                 if (ANY) return true;
                 const uint32_t prim = __float_as_uint(q0.w);
                 if (t < bt || (t == bt && prim < bp)) { bt = t; bu = u; bv = v; bp = prim; }
@@ -239,7 +250,7 @@ MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict
 template <bool ANY, bool OVF>
 MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restrict__ tris, uint32_t root_ref,
                        uint32_t n_tris, f3 o, f3 d, float tmin, float tmax, const LaneStack<OVF> &stack, float *best_t, float *best_u,
-                       float *best_v, uint32_t *best_prim) {
+                       float *best_v, uint32_t *best_prim, float tri_pad) {
     float bt = tmax, bu = 0.f, bv = 0.f;
     uint32_t bp = MSK_NO_PRIM;
     *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
@@ -281,7 +292,7 @@ MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restric
             const float4 *q = tris + (size_t) (first + i) * 4;
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             float t, u, v;
-            if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v)) {
+            if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v, tri_pad)) {
                 if (ANY) return true;
                 const uint32_t prim = __float_as_uint(q0.w);
                 if (t < bt || (t == bt && prim < bp)) { bt = t; bu = u; bv = v; bp = prim; }
@@ -329,8 +340,8 @@ MSK_DEV TraceLds stage_scene(const DeviceScene &sc, float4 *lds, bool use_lds, b
 template <int MODE, bool ANY>
 MSK_DEV bool traverse_scene(const DeviceScene &sc, const TraceLds &g, f3 o, f3 d, float tmin, float tmax, const LaneStack<MSK_OVF(MODE)> &stack,
                             float *bt, float *bu, float *bv, uint32_t *bp) {
-    if (MODE == 2 || MODE == 3) return traverse4<ANY, MSK_OVF(MODE)>(MODE == 3 ? g.nodes : sc.nodes4, g.tris, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
-    return traverse<ANY, MSK_OVF(MODE)>(g.nodes, g.tris, sc.root_ref, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+    if (MODE == 2 || MODE == 3) return traverse4<ANY, MSK_OVF(MODE)>(MODE == 3 ? g.nodes : sc.nodes4, g.tris, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp, sc.tri_pad);
+    return traverse<ANY, MSK_OVF(MODE)>(g.nodes, g.tris, sc.root_ref, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp, sc.tri_pad);
 }
 
 template <int MODE>
@@ -441,7 +452,7 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
             const float4 *q = g.tris + (size_t) (first + i) * 4;
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             float tt, u, v;
-            if (tri_test(q0, q1, q2, q3, t.o, t.d, t.tmin, t.tmax, &tt, &u, &v)) {
+            if (tri_test(q0, q1, q2, q3, t.o, t.d, t.tmin, t.tmax, &tt, &u, &v, sc.tri_pad)) {
                 if (any) { found = true; break; }
                 const uint32_t prim = __float_as_uint(q0.w);
                 if (tt < t.bt || (tt == t.bt && prim < t.bp)) { t.bt = tt; t.bu = u; t.bv = v; t.bp = prim; }

@@ -64,6 +64,12 @@
  *            weight (path.cpp:90-95,103-108).  These paths are pinned by closed-form
  *            properties (tests/test_rough_*.py, tests/test_environment.py), not by
  *            reference outputs: "parity unpinned" applies to them.
+ *   D10      ray/triangle acceptance = the Moeller-Trumbore test above AND "the hit point
+ *            o + t d lies in the triangle's own bounding box (grown by 0.5e-4 of the scene
+ *            diagonal)": see intersect_triangle().  Found by the randomised parity sweep
+ *            (tools/fuzz_parity.py): a shadow ray lying in the plane of a sliver emitter
+ *            triangle produced a numerical "hit" 40 units outside the triangle that one
+ *            tree reported and another culled.
  */
 #include "oracle_math.h"
 #include "msk_gpu.h"
@@ -79,6 +85,7 @@
 namespace orc {
 
 int g_use_libm = 0;
+int g_trace_path = 0;     // debugging aid: print the per-bounce state of path_sample (msk_oracle_set_trace)
 
 // ===========================================================================
 // scene data derived from the flattened description
@@ -107,6 +114,7 @@ struct Scene {
     std::vector<float> mesh_area;          // Mesh::m_surface_area
     std::vector<std::vector<float>> mesh_cdf;  // Distribution1D::m_cdf per mesh
     std::vector<std::vector<float>> emitter_d65;  // RegularSpectrum::m_pdf per emitter
+    float tri_pad = 0.f;                   // D10: half the BVH padding, see intersect_triangle
     int env = -1;                          // Scene::m_environment as an index into emitters
     float env_radius = 0.f;                // ConstantBackgroundEmitter::m_bsphere.radius after set_scene
 
@@ -258,6 +266,7 @@ static Scene *scene_from_desc(const msk_scene_desc *d) {
         hi = mk3(std::max(hi.x, b.x), std::max(hi.y, b.y), std::max(hi.z, b.z));
     }
     float diag = d->n_faces ? norm(hi - lo) : 1.f;
+    sc->tri_pad = 0.5e-4f * diag;                       // the nodes' padding (1e-4 diag) strictly contains it
     if (d->n_faces) build_node(*sc, 0, (int) d->n_faces, 1e-4f * diag);
     return sc;
 }
@@ -274,7 +283,12 @@ static inline float xor_sign(float a, uint32_t sgn) {
 // Embree 3 MoellerTrumboreIntersector1 (see header).  tfar is the ray's
 // ORIGINAL maxt: the closest hit is chosen afterwards by (t, prim) so that the
 // result does not depend on the order triangles are visited in.
-static inline bool intersect_triangle(const Tri &tr, const Ray &ray, float *t, float *u, float *v) {
+// D10: for a near-parallel ray the hit point must also lie in the triangle's own bounding box grown by `pad`.  For a ray that is
+// numerically parallel to the triangle's plane the arithmetic above can accept "hits" far outside the triangle
+// (|den| ~ 1e-7 |Ng|: t = T/|den| is noise); whether such a hit is ever reported then depends on whether the ray happens
+// to enter a BVH node containing the triangle — in Embree as much as here.  The predicate makes the answer a property of
+// the ray and the triangle alone, so brute force and every conservative tree agree.
+static inline bool intersect_triangle(const Tri &tr, const Ray &ray, float *t, float *u, float *v, float pad) {
     const V3 e1 = tr.p0 - tr.p1;           // TriangleM: e1 = v0 - v1
     const V3 e2 = tr.p2 - tr.p0;           //            e2 = v2 - v0
     const V3 ng = cross(e2, e1);           // tri_Ng = cross(e2, e1)
@@ -292,7 +306,15 @@ static inline bool intersect_triangle(const Tri &tr, const Ray &ray, float *t, f
     *t = T * rcp;
     *u = std::min(U * rcp, 1.f);
     *v = std::min(V * rcp, 1.f);
-    return true;
+    // D10 bounds predicate, for rays within ~0.6 degrees of the triangle's plane (|Ng.d| < 1e-2 sum |Ng_k d_k|: the only
+    // ones whose t can be off by more than the padding): the reported hit point o + t d lies in the bounding box of the
+    // triangle as the intersector holds it (v0, v0 - e1, v0 + e2), grown by `pad`
+    if (abs_den >= 1e-2f * (std::fabs(ng.x * ray.d.x) + (std::fabs(ng.y * ray.d.y) + std::fabs(ng.z * ray.d.z)))) return true;
+    const V3 q1 = tr.p0 - e1, q2 = tr.p0 + e2;
+    const float px = ray.o.x + *t * ray.d.x, py = ray.o.y + *t * ray.d.y, pz = ray.o.z + *t * ray.d.z;
+    return px >= std::min(tr.p0.x, std::min(q1.x, q2.x)) - pad && px <= std::max(tr.p0.x, std::max(q1.x, q2.x)) + pad &&
+           py >= std::min(tr.p0.y, std::min(q1.y, q2.y)) - pad && py <= std::max(tr.p0.y, std::max(q1.y, q2.y)) + pad &&
+           pz >= std::min(tr.p0.z, std::min(q1.z, q2.z)) - pad && pz <= std::max(tr.p0.z, std::max(q1.z, q2.z)) + pad;
 }
 
 static inline bool box_hit(const BVHNode &n, const Ray &r, V3 inv, float tbest) {
@@ -311,7 +333,7 @@ static Hit closest_hit(const Scene &sc, const Ray &ray) {
     Hit best{kInf, 0, 0, 0xffffffffu, false};
     auto consider = [&](uint32_t prim) {
         float t, u, v;
-        if (intersect_triangle(sc.tris[prim], ray, &t, &u, &v)) {
+        if (intersect_triangle(sc.tris[prim], ray, &t, &u, &v, sc.tri_pad)) {
             if (!best.valid || t < best.t || (t == best.t && prim < best.prim))
                 best = Hit{t, u, v, prim, true};
         }
@@ -337,7 +359,7 @@ static bool any_hit(const Scene &sc, const Ray &ray) {   // scene.cpp:255-273
     float t, u, v;
     if (!sc.use_bvh || sc.nodes.empty()) {
         for (uint32_t p = 0; p < sc.tris.size(); ++p)
-            if (intersect_triangle(sc.tris[p], ray, &t, &u, &v)) return true;
+            if (intersect_triangle(sc.tris[p], ray, &t, &u, &v, sc.tri_pad)) return true;
         return false;
     }
     V3 inv = mk3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
@@ -347,7 +369,7 @@ static bool any_hit(const Scene &sc, const Ray &ray) {   // scene.cpp:255-273
         if (!box_hit(n, ray, inv, ray.maxt)) continue;
         if (n.left < 0) {
             for (int i = 0; i < n.count; ++i)
-                if (intersect_triangle(sc.tris[sc.tri_order[n.first + i]], ray, &t, &u, &v)) return true;
+                if (intersect_triangle(sc.tris[sc.tri_order[n.first + i]], ray, &t, &u, &v, sc.tri_pad)) return true;
         } else { stack[sp++] = n.left; stack[sp++] = n.right; }
     }
     return false;
@@ -572,7 +594,11 @@ static DirectSample sample_emitter_direct(const Scene &sc, const Interaction &re
     if (ds.pdf != 0.f) {                                           // scene.cpp:90-97
         Ray ray{ref.p, ds.d, kRayEpsilon * (1.f + max_abs(ref.p)), ds.dist * (1.f - kShadowEpsilon)};
         ++*shadow_rays;
-        if (any_hit(sc, ray)) *spec = s4(0.f);
+        const bool occluded = any_hit(sc, ray);
+        if (g_trace_path)
+            std::printf("  shadow ray o %.9g %.9g %.9g tmin %.9g d %.9g %.9g %.9g tmax %.9g occluded %d\n", ray.o.x, ray.o.y, ray.o.z, ray.mint,
+                        ray.d.x, ray.d.y, ray.d.z, ray.maxt, (int) occluded);
+        if (occluded) *spec = s4(0.f);
     }
     return ds;
 }
@@ -851,6 +877,9 @@ static S4 path_sample(const Scene &sc, Sampler &sampler, Ray ray, S4 wl, const m
                 S4 bsdf_val; float bsdf_pdf;
                 bsdf_eval_pdf(*bb, wi_s, wo, wl, &bsdf_val, &bsdf_pdf);
                 float weight = mis_weight(ds.pdf, bsdf_pdf);
+                if (g_trace_path)
+                    std::printf("  d%d NEE: ds.pdf %.9g bsdf_pdf %.9g w %.9g emitter_val %.9g bsdf_val %.9g %.9g %.9g %.9g thr %.9g wo_local %.9g %.9g %.9g wi %.9g %.9g %.9g\n", depth, ds.pdf,
+                                bsdf_pdf, weight, emitter_val.v[0], bsdf_val.v[0], bsdf_val.v[1], bsdf_val.v[2], bsdf_val.v[3], throughput.v[0], wo.x, wo.y, wo.z, wi_s.x, wi_s.y, wi_s.z);
                 result = result + throughput * emitter_val * bsdf_val * weight;
             }
         }
@@ -890,6 +919,10 @@ static S4 path_sample(const Scene &sc, Sampler &sampler, Ray ray, S4 wl, const m
             break;                                                 // path.cpp:96-97
         }
         throughput = throughput * bsdf_val;
+        if (g_trace_path)
+            std::printf("  d%d sample: bsdf %d type %u wo %.9g %.9g %.9g pdf %.9g weight %.9g %.9g %.9g %.9g -> thr %.9g %.9g %.9g %.9g hit %d t %.9g emitter %d\n", depth,
+                        (int) sc.meshes[si.mesh].bsdf_id, sampled_type, bs_wo.x, bs_wo.y, bs_wo.z, bs_pdf, bsdf_val.v[0], bsdf_val.v[1], bsdf_val.v[2], bsdf_val.v[3],
+                        throughput.v[0], throughput.v[1], throughput.v[2], throughput.v[3], (int) si_bsdf.valid(), si_bsdf.t, (int) hit_emitter);
         eta *= bs_eta;
         if (hit_emitter) {
             float emitter_pdf = pdf_emitter_direct(sc, ds);        // diffuse lobe is not Delta
@@ -1100,6 +1133,7 @@ void *msk_oracle_scene_create(const msk_scene_desc *d) { return scene_from_desc(
 void msk_oracle_scene_destroy(void *s) { delete (Scene *) s; }
 void msk_oracle_set_bvh(void *s, int on) { ((Scene *) s)->use_bvh = on; }
 void msk_oracle_set_libm(int on) { g_use_libm = on; }
+void msk_oracle_set_trace(int on) { g_trace_path = on; }
 
 int msk_oracle_render(void *s, const msk_render_params *prm, float *film, msk_stats *stats, int n_threads) {
     Counters c;
