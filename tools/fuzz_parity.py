@@ -17,8 +17,13 @@ def random_scene(rng):
         for _ in range(rng.randint(1, 12)):
             c = rng.uniform(-1, 1, 3) * 200 + np.array([278, 273, 280])
             size = 10 ** rng.uniform(0.3, 2.5)
-            kind = rng.randint(0, 10)
-            if kind == 0:      # sliver
+            kind = rng.randint(0, 12)
+            if kind >= 10:     # axis-aligned quad on a lattice (exact zeros in normals and ray/plane arithmetic)
+                c = np.round(c / 50) * 50
+                ax = rng.randint(0, 3); ext = np.round(rng.uniform(20, 300, 2) / 10) * 10
+                e0 = np.zeros(3); e1_ = np.zeros(3); e0[(ax + 1) % 3] = ext[0]; e1_[(ax + 2) % 3] = ext[1]
+                pts = [c, c + e0, c + e0 + e1_, c + e1_]
+            elif kind == 0:      # sliver
                 a, b = rng.normal(size=3) * size, rng.normal(size=3) * size
                 pts = [c, c + a, c + a * (1 + 1e-4) + b * 1e-4]
             elif kind == 1:    # quad
@@ -34,8 +39,8 @@ def random_scene(rng):
             bsdf = {"type": "roughconductor", "alpha": float(10 ** rng.uniform(-2.5, -0.3)), "eta": tuple(rng.uniform(0.1, 3, 3)),
                     "k": tuple(rng.uniform(0.5, 4, 3)), "twosided": bool(rng.randint(0, 2)), "sample_visible": bool(rng.randint(0, 2))}
         elif t == 2:
-            bsdf = {"type": "roughdielectric", "alpha": float(10 ** rng.uniform(-2.5, -0.3)), "int_ior": float(rng.uniform(1.1, 2.2)),
-                    "ext_ior": 1.0, "sample_visible": bool(rng.randint(0, 2))}
+            bsdf = {"type": "roughdielectric", "alpha": float(rng.choice([0.0, 10 ** rng.uniform(-2.5, -0.3)])), "int_ior": float(rng.uniform(1.05, 2.6)),
+                    "ext_ior": float(rng.choice([1.0, 1.33])), "sample_visible": bool(rng.randint(0, 2))}
         elif t == 3:
             bsdf = {"type": "roughconductor", "alpha": (float(rng.uniform(0.02, 0.5)), float(rng.uniform(0.02, 0.5))),
                     "eta": (1.5, 1.5, 1.5), "k": (3.0, 3.0, 3.0), "twosided": True}
@@ -51,12 +56,39 @@ def random_scene(rng):
     env = None
     if rng.randint(0, 3) == 0:
         env = {"radiance": tuple(float(x) for x in rng.uniform(0.1, 1.0, 3)) if rng.randint(0, 2) else None, "first": bool(rng.randint(0, 2))}
-    return hm.flatten(meshes, 48, 40, env=env)
+    flat = hm.flatten(meshes, 48, 40, env=env)
+    # vertex normals (perturbed face normals) and texture coordinates on some meshes: mesh.cpp:68-96
+    verts, faces = flat.vertices, flat.faces
+    for i in range(flat.desc.n_meshes):
+        md = flat.desc.meshes[i]
+        mode = rng.randint(0, 4)
+        if mode == 0 or md.face_count == 0:
+            continue
+        for f in range(md.first_face, md.first_face + md.face_count):
+            idx = md.first_vertex + faces[f]
+            p = verts[idx, :3].astype(np.float64)
+            n = np.cross(p[1] - p[0], p[2] - p[0])
+            ln = np.linalg.norm(n)
+            n = n / ln if ln > 0 else np.array([0.0, 0.0, 1.0])
+            for k in idx:
+                q = n + rng.normal(size=3) * 0.3
+                verts[k, 3:6] = (q / np.linalg.norm(q)).astype(np.float32)
+                verts[k, 6:8] = rng.uniform(0, 1, 2).astype(np.float32)
+        md.has_normals = 1 if mode in (1, 3) else 0
+        md.has_texcoords = 1 if mode in (2, 3) else 0
+    return flat
 
 
 def random_params(rng):
-    return dict(spp=4, seed=int(rng.randint(0, 1000)), rr_depth=int(rng.choice([1, 2, 5])), max_depth=int(rng.choice([-1, -1, 1, 3, 6])),
-                hide_emitters=int(rng.randint(0, 2)), block_size=int(rng.choice([8, 16, 32])))
+    kw = dict(spp=int(rng.choice([1, 4, 4, 7])), seed=int(rng.randint(0, 1000)), rr_depth=int(rng.choice([1, 2, 5])),
+              max_depth=int(rng.choice([-1, -1, 1, 3, 6])), hide_emitters=int(rng.randint(0, 2)), block_size=int(rng.choice([8, 16, 32])))
+    if rng.randint(0, 4) == 0:       # a multi-GPU shard of the job (tiles or sample indices)
+        world = int(rng.randint(2, 5))
+        if rng.randint(0, 2):
+            kw.update(block_first=int(rng.randint(0, world)), block_stride=world)
+        else:
+            kw.update(sample_first=int(rng.randint(0, world)), sample_stride=world)
+    return kw
 
 
 def sweep(ctx, orc, seeds, verbose=True):
