@@ -1,6 +1,6 @@
 """Randomised parity sweep: random triangle soups (including slivers and near-degenerate triangles), random BSDFs of
 every type, one to three area emitters, optional environment, random integrator properties — the GPU film must equal
-the oracle's bit for bit on every one.  usage: fuzz_parity.py n_scenes [first_seed]"""
+the oracle's bit for bit on every one.  usage: fuzz_parity.py n_scenes [first_seed [spp]]"""
 import importlib, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
@@ -91,12 +91,14 @@ def random_params(rng):
     return kw
 
 
-def sweep(ctx, orc, seeds, verbose=True):
+def sweep(ctx, orc, seeds, verbose=True, spp=None):
     bad = []
     for s in seeds:
         rng = np.random.RandomState(s)
         flat = random_scene(rng)
         kw = random_params(rng)
+        if spp:
+            kw["spp"] = spp
         g, o = abi.Scene(ctx, flat), orc.scene(flat)
         film, st = g.render(abi.render_params(**kw))
         ref, rst = o.render(abi.render_params(**kw), threads=8)
@@ -119,6 +121,7 @@ def sweep(ctx, orc, seeds, verbose=True):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    bad = sweep(abi.Context(0), oracle_binding.load(), range(seed0, seed0 + n))
+    spp = int(sys.argv[3]) if len(sys.argv) > 3 else None        # optional: samples per pixel for every scene
+    bad = sweep(abi.Context(0), oracle_binding.load(), range(seed0, seed0 + n), spp=spp)
     print("fuzz: %d scenes, %d with a film different from the oracle's" % (n, len(bad)))
     sys.exit(1 if bad else 0)
