@@ -128,7 +128,9 @@ MSK_DEV bool tri_test(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, fl
              ng = mk3(q3.x, q3.y, q3.z);
     const f3 C = v0 - o;
     const f3 R = cross(C, d);
-    const float den = dot(ng, d);
+    const float dx_ = ng.x * d.x, dy_ = ng.y * d.y, dz_ = ng.z * d.z;
+    const float den = dx_ + (dy_ + dz_);                                   // = dot(ng, d)
+    const float den_scale = fabsf(dx_) + (fabsf(dy_) + fabsf(dz_));         // D10 pre-filter, from the same products
     const float abs_den = fabsf(den);
     const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
     const float U = xor_sign(dot(R, e2), sgn);
@@ -142,7 +144,7 @@ MSK_DEV bool tri_test(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, fl
     *v = fmin_std(V * rcp, 1.f);
     // oracle D10, for rays within ~0.6 degrees of the triangle's plane only: the hit point o + t d lies in the bounding
     // box of (v0, v0 - e1, v0 + e2) grown by `pad`
-    if (abs_den >= 1e-2f * (fabsf(ng.x * d.x) + (fabsf(ng.y * d.y) + fabsf(ng.z * d.z)))) return true;
+    if (abs_den >= 1e-2f * den_scale) return true;
     const f3 w1 = v0 - e1, w2 = v0 + e2;
     const float px = o.x + *t * d.x, py = o.y + *t * d.y, pz = o.z + *t * d.z;
     return px >= fmin_std(v0.x, fmin_std(w1.x, w2.x)) - pad && px <= fmax_std(v0.x, fmax_std(w1.x, w2.x)) + pad &&
