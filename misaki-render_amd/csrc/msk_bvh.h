@@ -9,6 +9,9 @@
 //   tri   t : [v0.xyz, prim (uint bits)] [e1.xyz, 0] [e2.xyz, 0] [Ng.xyz, 0]
 //             in LEAF order; e1 = v0 - v1, e2 = v2 - v0, Ng = e2 x e1 — the precomputed form of
 //             Embree 3's TriangleM / Moeller-Trumbore test; prim = scene-global triangle index.
+//   bounds t: [lo.xyz, 0] [hi.xyz, 0], same order, a separate array (the 64-byte triangle records keep their cache-line
+//             alignment): bounding box of (v0, v0 - e1, v0 + e2) grown by tri_pad — the bounds predicate of oracle
+//             deviation D10 (an accepted hit point must lie inside), read only for accepted hits.
 // Child boxes are padded by 1e-4 of the scene diagonal so the slab test can never cull a
 // triangle the (differently rounded) triangle test accepts: hit selection is by (t, prim) and
 // therefore independent of the tree.
@@ -39,6 +42,7 @@ static inline float axis_of(V3 v, int a) { return a == 0 ? v.x : a == 1 ? v.y : 
 struct Built {
     std::vector<float> nodes;   // 16 floats per node
     std::vector<float> tris;    // 16 floats per triangle, leaf order
+    std::vector<float> bounds;  // 8 floats per triangle, leaf order
     uint32_t root_ref = 0;      // packed child ref of the root
     int max_depth = 0;
     // 4-wide form of the same tree for scenes that do not fit LDS (collapse4): 32 floats (128 B = one L2 line) per node,
@@ -138,7 +142,7 @@ struct Builder {
 // pos: 9 floats per triangle.  fp32 edge/normal precomputation uses one rounded operation per
 // arithmetic op (this TU is compiled with -ffp-contract=off), the same values a per-ray
 // evaluation of e1, e2, Ng would produce.
-static inline Built build(const float *pos, uint32_t n) {
+static inline Built build(const float *pos, uint32_t n, float tri_pad) {
     Built out;
     Builder b; b.pos = pos; b.n = n;
     if (const char *e = getenv("MSK_BVH_LEAF")) b.kLeaf = std::max(1, std::min(8, atoi(e)));
@@ -157,11 +161,12 @@ static inline Built build(const float *pos, uint32_t n) {
     out.root_ref = Builder::pack(root);
     out.nodes = std::move(b.nodes);
     out.max_depth = b.max_depth;
-    out.tris.resize((size_t) n * 16);
+    out.tris.resize((size_t) n * 16); out.bounds.resize((size_t) n * 8);
     for (uint32_t k = 0; k < n; ++k) {
         uint32_t prim = b.leaf_order[k];
         const float *p = pos + (size_t) prim * 9;
         float *t = &out.tris[(size_t) k * 16];
+        float *bb = &out.bounds[(size_t) k * 8];
         float e1[3] = {p[0] - p[3], p[1] - p[4], p[2] - p[5]};        // v0 - v1
         float e2[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};        // v2 - v0
         float ng[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0]};
@@ -169,6 +174,12 @@ static inline Built build(const float *pos, uint32_t n) {
         t[4] = e1[0]; t[5] = e1[1]; t[6] = e1[2]; t[7] = 0;
         t[8] = e2[0]; t[9] = e2[1]; t[10] = e2[2]; t[11] = 0;
         t[12] = ng[0]; t[13] = ng[1]; t[14] = ng[2]; t[15] = 0;
+        for (int a = 0; a < 3; ++a) {                     // oracle D10, same fp32 operations as oracle.cpp's intersect_triangle
+            const float w0 = p[a], w1 = p[a] - e1[a], w2 = p[a] + e2[a];
+            bb[a] = std::min(w0, std::min(w1, w2)) - tri_pad;
+            bb[4 + a] = std::max(w0, std::max(w1, w2)) + tri_pad;
+        }
+        bb[3] = 0; bb[7] = 0;
     }
     return out;
 }

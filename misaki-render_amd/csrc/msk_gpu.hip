@@ -61,7 +61,7 @@ struct msk_scene {
     msk_ctx *ctx = nullptr;
     Workspace *ws = nullptr;           // render buffers, kept between calls (hipMalloc/hipFree of GBs costs milliseconds)
     DeviceScene dev;
-    DevBuf nodes, nodes4, tris, tri_verts, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
+    DevBuf nodes, nodes4, tris, tri_bounds, tri_verts, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
     bool lds_scene = false, lds_tables = false, all_diffuse = true;
     int trace_mode = 0;                // 0 binary tree in LDS, 1 binary tree in HBM/L2, 2 4-wide tree in HBM/L2
     size_t trace_lds_bytes = 0, shade_lds_bytes = 0;
@@ -249,21 +249,32 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     }
     if (cdf_all.empty()) cdf_all.push_back(0.f);
 
-    mskbvh::Built bvh = mskbvh::build(pos.data(), d->n_faces);
+    // oracle D10: the triangle-bounds predicate's padding, computed exactly as the oracle does (0.5e-4 * |hi - lo|)
+    float tri_pad;
+    {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t t = 0; t < d->n_faces; ++t)
+            for (int v = 0; v < 3; ++v)
+                for (int k = 0; k < 3; ++k) { const float q = pos[(size_t) t * 9 + v * 3 + k]; lo[k] = std::min(lo[k], q); hi[k] = std::max(hi[k], q); }
+        const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        const float diag = d->n_faces ? std::sqrt(ex * ex + (ey * ey + ez * ez)) : 1.f;
+        tri_pad = 0.5e-4f * diag;
+    }
+    mskbvh::Built bvh = mskbvh::build(pos.data(), d->n_faces, tri_pad);
 
     msk_scene *s = new msk_scene();
     s->ctx = ctx; s->n_tris = d->n_faces; s->bvh_depth = bvh.max_depth; s->all_diffuse = all_diffuse;
     std::vector<float> cie(d->cie1931_xyz, d->cie1931_xyz + 3 * MSK_CIE_SAMPLES);
     hipError_t e = hipSuccess;
     auto up = [&](DevBuf &b, const std::vector<float> &v) { if (e == hipSuccess) e = b.upload(v); };
-    up(s->nodes, bvh.nodes); up(s->tris, bvh.tris); up(s->tri_verts, tv); up(s->tri_normals, tn); up(s->tri_uvs, tuv);
+    up(s->nodes, bvh.nodes); up(s->tris, bvh.tris); up(s->tri_bounds, bvh.bounds); up(s->tri_verts, tv); up(s->tri_normals, tn); up(s->tri_uvs, tuv);
     up(s->bsdfs, bsdfs); up(s->emitters, emitters); up(s->emitter_d65, d65); up(s->cdf, cdf_all); up(s->cie, cie);
     if (e == hipSuccess) e = s->mesh_info.upload(mesh_info);
     if (e != hipSuccess) { delete s; return fail(ctx, e == hipErrorOutOfMemory ? MSK_ERR_OOM : MSK_ERR_HIP, "scene upload: %s", hipGetErrorString(e)); }
 
     DeviceScene &ds = s->dev;
     std::memset(&ds, 0, sizeof ds);
-    ds.nodes = s->nodes.as<float4>(); ds.tris = s->tris.as<float4>(); ds.tri_verts = s->tri_verts.as<float4>();
+    ds.nodes = s->nodes.as<float4>(); ds.tris = s->tris.as<float4>(); ds.tri_bounds = s->tri_bounds.as<float4>(); ds.tri_pad = tri_pad; ds.tri_verts = s->tri_verts.as<float4>();
     ds.tri_normals = any_normals ? s->tri_normals.as<float4>() : nullptr;
     ds.tri_uvs = any_uvs ? s->tri_uvs.as<float4>() : nullptr;
     ds.mesh_info = s->mesh_info.as<int4>(); ds.bsdfs = s->bsdfs.as<float4>(); ds.emitters = s->emitters.as<float4>();
@@ -280,15 +291,6 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     ds.filter_border = (int) std::ceil(d->film.filter_radius - .5f);                  // rfilter.cpp:22
     std::memcpy(ds.lut, d->film.filter_lut, sizeof ds.lut);
     // constant.cpp:21-28 set_scene: the sphere around Scene::bbox() (bbox.h:105-112), in fp32 exactly as the oracle does
-    {   // oracle D10: the triangle-bounds predicate's padding, computed exactly as the oracle does (0.5e-4 * |hi - lo|)
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (uint32_t t = 0; t < d->n_faces; ++t)
-            for (int v = 0; v < 3; ++v)
-                for (int k = 0; k < 3; ++k) { const float q = pos[(size_t) t * 9 + v * 3 + k]; lo[k] = std::min(lo[k], q); hi[k] = std::max(hi[k], q); }
-        const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
-        const float diag = d->n_faces ? std::sqrt(ex * ex + (ey * ey + ez * ez)) : 1.f;
-        ds.tri_pad = 0.5e-4f * diag;
-    }
     ds.env_emitter = env_emitter; ds.env_radius = 0.f;
     if (env_emitter >= 0) {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -302,7 +304,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     }
     // LDS plan of k_trace: per-lane stack + (when it fits) the whole BVH
     const size_t stack_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4;
-    const size_t scene_bytes = ((size_t) ds.n_nodes + ds.n_tris) * 64;
+    const size_t scene_bytes = (size_t) ds.n_nodes * 64 + (size_t) ds.n_tris * 96;
     const size_t lds_cap = getenv("MSK_LDS_SCENE_KB") ? (size_t) atoi(getenv("MSK_LDS_SCENE_KB")) * 1024 : 48 * 1024;
     s->lds_scene = scene_bytes <= lds_cap && stack_bytes + scene_bytes <= 64 * 1024;
     s->trace_lds_bytes = stack_bytes + (s->lds_scene ? scene_bytes : 0);
@@ -323,7 +325,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         if (e4 != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(e4)); }
         ds.nodes4 = s->nodes4.as<float4>(); ds.root_ref4 = bvh.root_ref4; ds.n_nodes4 = (uint32_t) (bvh.nodes4.size() / 32);
         ds.stack_entries = (uint32_t) ((3 * bvh.max_depth4 + 2 + 3) & ~3);
-        s->trace_lds_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4 + ((size_t) ds.n_nodes4 * 128 + (size_t) ds.n_tris * 64);
+        s->trace_lds_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4 + ((size_t) ds.n_nodes4 * 128 + (size_t) ds.n_tris * 96);
         s->trace_mode = 3;
     }
     ds.stack_total = ds.stack_entries;

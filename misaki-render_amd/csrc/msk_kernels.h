@@ -37,7 +37,10 @@ struct DeviceScene {
     const float4 *nodes;        // 4 x float4 per node (msk_bvh.h)
     const float4 *nodes4;       // 8 x float4 per 4-wide node, or nullptr (scenes whose BVH is staged in LDS use `nodes`)
     uint32_t root_ref4, n_nodes4;
-    const float4 *tris;         // 4 x float4 per triangle, leaf order
+    const float4 *tris;         // 4 x float4 per triangle, leaf order (msk_bvh.h)
+    const float4 *tri_bounds;   // 2 x float4 per triangle, leaf order: padded bounds of the D10 predicate (staged next to the
+                                // triangles for LDS-resident scenes; trees in HBM recompute them from the record instead)
+    float tri_pad;
     const float4 *tri_verts;    // 3 x float4 per triangle, scene-global order: p0|mesh p1|- p2|-
     const float4 *tri_normals;  // 3 x float4 per triangle (n0 n1 n2) or nullptr
     const float4 *tri_uvs;      // 2 x float4 per triangle (uv0 uv1 | uv2 -) or nullptr
@@ -59,7 +62,6 @@ struct DeviceScene {
     float lut[33];
     int32_t env_emitter;        // index of the constant environment emitter in `emitters`, or -1 (scene.cpp:35-41)
     float env_radius;           // ConstantBackgroundEmitter::m_bsphere.radius after set_scene (constant.cpp:21-28)
-    float tri_pad;              // oracle D10: padding of the per-triangle bounds predicate in tri_test (0.5e-4 scene diagonal)
 };
 
 struct PathState {
@@ -119,18 +121,17 @@ MSK_DEV float xor_sign(float a, uint32_t s) { return __uint_as_float(__float_as_
 
 // Embree 3 Moeller-Trumbore, restated (see oracle/oracle.cpp header for the derivation);
 // tmax is the ray's ORIGINAL far bound.
-// + oracle D10: when the ray is numerically parallel to the triangle's plane, the hit point of an accepted hit must lie
-// in the triangle's own bounding box grown by `pad` (same arithmetic as the oracle): acceptance is then a property of the
-// ray and the triangle, not of the tree.  Eight instructions per accepted hit, the box check itself almost never.
+// + oracle D10: the hit point o + t d of an accepted hit must lie in the triangle's own padded bounding box (bounds[0..1],
+// precomputed with the oracle's arithmetic): acceptance is then a property of the ray and the triangle, not of the tree —
+// Moeller-Trumbore alone accepts points well outside sliver triangles and, for near-parallel rays, at meaningless t.
+// The bounds are read only for hits the test above accepted.
 MSK_DEV bool tri_test(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, float tmin, float tmax,
-                      float *t, float *u, float *v, float pad) {
+                      float *t, float *u, float *v, const float4 *bounds, float pad) {
     const f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z),
              ng = mk3(q3.x, q3.y, q3.z);
     const f3 C = v0 - o;
     const f3 R = cross(C, d);
-    const float dx_ = ng.x * d.x, dy_ = ng.y * d.y, dz_ = ng.z * d.z;
-    const float den = dx_ + (dy_ + dz_);                                   // = dot(ng, d)
-    const float den_scale = fabsf(dx_) + (fabsf(dy_) + fabsf(dz_));         // D10 pre-filter, from the same products
+    const float den = dot(ng, d);
     const float abs_den = fabsf(den);
     const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
     const float U = xor_sign(dot(R, e2), sgn);
@@ -142,11 +143,13 @@ MSK_DEV bool tri_test(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, fl
     *t = T * rcp;
     *u = fmin_std(U * rcp, 1.f);
     *v = fmin_std(V * rcp, 1.f);
-    // oracle D10, for rays within ~0.6 degrees of the triangle's plane only: the hit point o + t d lies in the bounding
-    // box of (v0, v0 - e1, v0 + e2) grown by `pad`
-    if (abs_den >= 1e-2f * den_scale) return true;
-    const f3 w1 = v0 - e1, w2 = v0 + e2;
     const float px = o.x + *t * d.x, py = o.y + *t * d.y, pz = o.z + *t * d.z;
+    if (bounds) {                           // LDS-resident scene: precomputed, two LDS reads
+        const float4 lo = bounds[0], hi = bounds[1];
+        return px >= lo.x && px <= hi.x && py >= lo.y && py <= hi.y && pz >= lo.z && pz <= hi.z;
+    }
+    // tree in HBM/L2 (memory-latency-bound, VALU to spare): the same bounds from the record, no extra fetch
+    const f3 w1 = v0 - e1, w2 = v0 + e2;
     return px >= fmin_std(v0.x, fmin_std(w1.x, w2.x)) - pad && px <= fmax_std(v0.x, fmax_std(w1.x, w2.x)) + pad &&
            py >= fmin_std(v0.y, fmin_std(w1.y, w2.y)) - pad && py <= fmax_std(v0.y, fmax_std(w1.y, w2.y)) + pad &&
            pz >= fmin_std(v0.z, fmin_std(w1.z, w2.z)) - pad && pz <= fmax_std(v0.z, fmax_std(w1.z, w2.z)) + pad;
@@ -190,15 +193,17 @@ struct LaneStack {
     }
 };
 
-// ANY: returns true on the first accepted triangle.  Closest: keeps (t, prim)-minimal hit.
+// ANY: returns true on the first accepted triangle.  Closest: keeps (t, prim)-minimal hit; the first accepted hit is kept
+// whatever its t (it can exceed tmax by an ulp: the test is T <= |den| tmax, then t = T / |den| — as in Embree, and
+// scene.cpp:234 only asks tfar != maxt).
 // nodes/tris may point into LDS or HBM.  stack: this lane's LDS stack, stride MSK_BLOCK.
 // "while-while" form: the inner loop walks inner nodes until the lane holds a leaf (or runs out of
 // work), then the wave tests leaf triangles together — lanes at inner nodes do not sit through
 // other lanes' triangle tests one node at a time.
 template <bool ANY, bool OVF>
-MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict__ tris, uint32_t root_ref,
+MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict__ tris, float tri_pad, uint32_t root_ref,
                       uint32_t n_tris, f3 o, f3 d, float tmin, float tmax, const LaneStack<OVF> &stack, float *best_t, float *best_u,
-                      float *best_v, uint32_t *best_prim, float tri_pad) {
+                      float *best_v, uint32_t *best_prim) {
     float bt = tmax, bu = 0.f, bv = 0.f;
     uint32_t bp = MSK_NO_PRIM;
     *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
@@ -230,13 +235,13 @@ MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict
         // ---- leaf
         const uint32_t first = (cur & 0x7fffffffu) >> 5, cnt = cur & 31u;
         for (uint32_t i = 0; i < cnt; ++i) {
-            const float4 *q = tris + (size_t) (first + i) * 4;
+            const float4 *q = tris + (size_t) (first + i) * (OVF ? 4 : 6);      // LDS copies carry their bounds: 6 float4
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             float t, u, v;
-            if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v, tri_pad)) {
+            if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v, OVF ? nullptr : q + 4, tri_pad)) {
                 if (ANY) return true;
                 const uint32_t prim = __float_as_uint(q0.w);
-                if (t < bt || (t == bt && prim < bp)) { bt = t; bu = u; bv = v; bp = prim; }
+                if (bp == MSK_NO_PRIM || t < bt || (t == bt && prim < bp)) { bt = t; bu = u; bv = v; bp = prim; }
             }
         }
         if (sp > 0) { cur = stack.pop(sp); } else cur = DONE;
@@ -250,9 +255,9 @@ MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict
 // tree's, bit for bit.
 #define MSK_EMPTY4 0xfffffffeu
 template <bool ANY, bool OVF>
-MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restrict__ tris, uint32_t root_ref,
+MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restrict__ tris, float tri_pad, uint32_t root_ref,
                        uint32_t n_tris, f3 o, f3 d, float tmin, float tmax, const LaneStack<OVF> &stack, float *best_t, float *best_u,
-                       float *best_v, uint32_t *best_prim, float tri_pad) {
+                       float *best_v, uint32_t *best_prim) {
     float bt = tmax, bu = 0.f, bv = 0.f;
     uint32_t bp = MSK_NO_PRIM;
     *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
@@ -291,13 +296,13 @@ MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restric
         if (cur == DONE) break;
         const uint32_t first = (cur & 0x7fffffffu) >> 5, cnt = cur & 31u;
         for (uint32_t i = 0; i < cnt; ++i) {
-            const float4 *q = tris + (size_t) (first + i) * 4;
+            const float4 *q = tris + (size_t) (first + i) * (OVF ? 4 : 6);      // LDS copies carry their bounds: 6 float4
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             float t, u, v;
-            if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v, tri_pad)) {
+            if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v, OVF ? nullptr : q + 4, tri_pad)) {
                 if (ANY) return true;
                 const uint32_t prim = __float_as_uint(q0.w);
-                if (t < bt || (t == bt && prim < bp)) { bt = t; bu = u; bv = v; bp = prim; }
+                if (bp == MSK_NO_PRIM || t < bt || (t == bt && prim < bp)) { bt = t; bu = u; bv = v; bp = prim; }
             }
         }
         if (sp > 0) { cur = stack.pop(sp); } else cur = DONE;
@@ -307,17 +312,18 @@ MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restric
 }
 
 struct TraceLds {
-    const float4 *nodes, *tris;
+    const float4 *nodes, *tris;        // staged triangles are 6 float4 each (record + bounds), global ones 4
 };
 
 // stage nodes + triangles into dynamic LDS (all threads of the block)
 MSK_DEV TraceLds stage_scene(const DeviceScene &sc, float4 *lds, bool use_lds, bool wide = false) {
     TraceLds r;
     if (!use_lds) { r.nodes = sc.nodes; r.tris = sc.tris; return r; }
-    const uint32_t nn = wide ? sc.n_nodes4 * 8 : sc.n_nodes * 4, nt = sc.n_tris * 4;
+    const uint32_t nn = wide ? sc.n_nodes4 * 8 : sc.n_nodes * 4, nt = sc.n_tris * 4, nb = sc.n_tris * 2;
     const float4 *src = wide ? sc.nodes4 : sc.nodes;
     for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) lds[i] = src[i];
-    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[nn + i] = sc.tris[i];
+    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[nn + (i >> 2) * 6 + (i & 3)] = sc.tris[i];
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) lds[nn + (i >> 1) * 6 + 4 + (i & 1)] = sc.tri_bounds[i];
     __syncthreads();
     r.nodes = lds; r.tris = lds + nn;
     return r;
@@ -342,8 +348,8 @@ MSK_DEV TraceLds stage_scene(const DeviceScene &sc, float4 *lds, bool use_lds, b
 template <int MODE, bool ANY>
 MSK_DEV bool traverse_scene(const DeviceScene &sc, const TraceLds &g, f3 o, f3 d, float tmin, float tmax, const LaneStack<MSK_OVF(MODE)> &stack,
                             float *bt, float *bu, float *bv, uint32_t *bp) {
-    if (MODE == 2 || MODE == 3) return traverse4<ANY, MSK_OVF(MODE)>(MODE == 3 ? g.nodes : sc.nodes4, g.tris, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp, sc.tri_pad);
-    return traverse<ANY, MSK_OVF(MODE)>(g.nodes, g.tris, sc.root_ref, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp, sc.tri_pad);
+    if (MODE == 2 || MODE == 3) return traverse4<ANY, MSK_OVF(MODE)>(MODE == 3 ? g.nodes : sc.nodes4, g.tris, sc.tri_pad, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+    return traverse<ANY, MSK_OVF(MODE)>(g.nodes, g.tris, sc.tri_pad, sc.root_ref, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
 }
 
 template <int MODE>
@@ -451,13 +457,13 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
     if (t.cur != DONE && (t.cur & MSK_LEAF_BIT)) {
         const uint32_t first = (t.cur & 0x7fffffffu) >> 5, cnt = t.cur & 31u;
         for (uint32_t i = 0; i < cnt; ++i) {
-            const float4 *q = g.tris + (size_t) (first + i) * 4;
+            const float4 *q = g.tris + (size_t) (first + i) * (MSK_OVF(MODE) ? 4 : 6);
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             float tt, u, v;
-            if (tri_test(q0, q1, q2, q3, t.o, t.d, t.tmin, t.tmax, &tt, &u, &v, sc.tri_pad)) {
+            if (tri_test(q0, q1, q2, q3, t.o, t.d, t.tmin, t.tmax, &tt, &u, &v, MSK_OVF(MODE) ? nullptr : q + 4, sc.tri_pad)) {
                 if (any) { found = true; break; }
                 const uint32_t prim = __float_as_uint(q0.w);
-                if (tt < t.bt || (tt == t.bt && prim < t.bp)) { t.bt = tt; t.bu = u; t.bv = v; t.bp = prim; }
+                if (t.bp == MSK_NO_PRIM || tt < t.bt || (tt == t.bt && prim < t.bp)) { t.bt = tt; t.bu = u; t.bv = v; t.bp = prim; }
             }
         }
         if (t.sp > 0 && !found) { t.cur = stack.pop(t.sp); } else t.cur = DONE;

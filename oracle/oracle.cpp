@@ -283,7 +283,8 @@ static inline float xor_sign(float a, uint32_t sgn) {
 // Embree 3 MoellerTrumboreIntersector1 (see header).  tfar is the ray's
 // ORIGINAL maxt: the closest hit is chosen afterwards by (t, prim) so that the
 // result does not depend on the order triangles are visited in.
-// D10: for a near-parallel ray the hit point must also lie in the triangle's own bounding box grown by `pad`.  For a ray that is
+// D10: the hit point must also lie in the triangle's own bounding box grown by `pad`.  Moeller-Trumbore alone accepts
+// points up to a few tenths of a unit outside sliver triangles (ill-conditioned barycentrics), and for a ray that is
 // numerically parallel to the triangle's plane the arithmetic above can accept "hits" far outside the triangle
 // (|den| ~ 1e-7 |Ng|: t = T/|den| is noise); whether such a hit is ever reported then depends on whether the ray happens
 // to enter a BVH node containing the triangle — in Embree as much as here.  The predicate makes the answer a property of
@@ -306,10 +307,8 @@ static inline bool intersect_triangle(const Tri &tr, const Ray &ray, float *t, f
     *t = T * rcp;
     *u = std::min(U * rcp, 1.f);
     *v = std::min(V * rcp, 1.f);
-    // D10 bounds predicate, for rays within ~0.6 degrees of the triangle's plane (|Ng.d| < 1e-2 sum |Ng_k d_k|: the only
-    // ones whose t can be off by more than the padding): the reported hit point o + t d lies in the bounding box of the
-    // triangle as the intersector holds it (v0, v0 - e1, v0 + e2), grown by `pad`
-    if (abs_den >= 1e-2f * (std::fabs(ng.x * ray.d.x) + (std::fabs(ng.y * ray.d.y) + std::fabs(ng.z * ray.d.z)))) return true;
+    // D10 bounds predicate: the reported hit point o + t d must lie in the bounding box of the triangle as the intersector
+    // holds it (v0, v0 - e1, v0 + e2), grown by `pad`
     const V3 q1 = tr.p0 - e1, q2 = tr.p0 + e2;
     const float px = ray.o.x + *t * ray.d.x, py = ray.o.y + *t * ray.d.y, pz = ray.o.z + *t * ray.d.z;
     return px >= std::min(tr.p0.x, std::min(q1.x, q2.x)) - pad && px <= std::max(tr.p0.x, std::max(q1.x, q2.x)) + pad &&

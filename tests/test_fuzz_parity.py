@@ -64,3 +64,31 @@ def test_hit_acceptance_does_not_depend_on_the_tree(oracle):
 @pytest.mark.gpu
 def test_gpu_equals_oracle_on_random_scenes(gpu_ctx, oracle):
     assert _fuzz().sweep(gpu_ctx, oracle, list(range(5000, 5060)) + [20657]) == []
+
+
+def _fuzz_rays():
+    spec = importlib.util.spec_from_file_location("fuzz_rays", os.path.join(ROOT, "tools", "fuzz_rays.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.gpu
+def test_adversarial_rays_gpu_equals_oracle_brute_force(gpu_ctx, oracle, abi):
+    """Rays from vertices / edges / planes of the triangles towards other vertices, along edges, axis-aligned, with tmax
+    exactly at the target (tools/fuzz_rays.py; 5 M such rays identical in development, after it had found that the GPU
+    dropped first hits whose t exceeds tmax by an ulp): whatever tree the GPU uses vs the oracle's brute force."""
+    fr = _fuzz_rays()
+    for s in (3, 4, 5, 143):
+        rng = np.random.RandomState(s)
+        flat = fr.fz.random_scene(rng)
+        d = flat.desc
+        tris = np.array([[flat.vertices[d.meshes[m].first_vertex + i, :3] for i in flat.faces[f]] for m in range(d.n_meshes)
+                         for f in range(d.meshes[m].first_face, d.meshes[m].first_face + d.meshes[m].face_count)], np.float32)
+        rays = fr.adversarial_rays(rng, tris, 20000)
+        g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+        o.set_bvh(0)
+        assert np.array_equal(g.trace_closest(rays).view(np.uint32), o.trace_closest(rays).view(np.uint32)), s
+        assert np.array_equal(g.trace_any(rays), o.trace_any(rays)), s
+        g.close()
+        o.close()
