@@ -56,7 +56,15 @@ def random_scene(rng):
     env = None
     if rng.randint(0, 3) == 0:
         env = {"radiance": tuple(float(x) for x in rng.uniform(0.1, 1.0, 3)) if rng.randint(0, 2) else None, "first": bool(rng.randint(0, 2))}
-    flat = hm.flatten(meshes, 48, 40, env=env)
+    camera = None
+    if rng.randint(0, 5) == 0:       # the whole scene (and the camera) at another scale: epsilons, clip planes, pdf magnitudes
+        sc = float(rng.choice([1e-3, 1e-2, 30.0, 1e3]))
+        for m in meshes:
+            m.faces = [tuple(tuple(float(np.float32(v * sc)) for v in p) for p in f) for f in m.faces]
+        c = hm.CBOX_CAMERA
+        camera = dict(fov=float(rng.uniform(20, 90)), near=c["near"] * sc, far=c["far"] * sc, origin=tuple(v * sc for v in c["origin"]),
+                      target=tuple(v * sc for v in c["target"]), up=c["up"])
+    flat = hm.flatten(meshes, 48, 40, env=env, camera=camera)
     # vertex normals (perturbed face normals) and texture coordinates on some meshes: mesh.cpp:68-96
     verts, faces = flat.vertices, flat.faces
     for i in range(flat.desc.n_meshes):
