@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MSK_ABI_VERSION 3
+#define MSK_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------- */
 #define MSK_OK                 0
@@ -50,6 +50,8 @@ extern "C" {
 #define MSK_BSDF_ROUGHCONDUCTOR 1  /* "roughconductor" bsdfs/roughconductor.cpp:139 (GGX only) */
 #define MSK_BSDF_ROUGHDIELECTRIC 2 /* "roughdielectric" bsdfs/roughdielectric.cpp:209 (GGX only) */
 #define MSK_EMITTER_AREA       0   /* "area"     emitters/area.cpp:61          */
+#define MSK_TEXTURE_CHECKERBOARD 1 /* "checkerboard" textures/checkerboard.cpp:52 */
+
 #define MSK_EMITTER_CONSTANT   1   /* "constant" emitters/constant.cpp:95 (environment; mesh_id = -1, at most one) */
 
 /* AOV channel groups of the "aov" integrator (integrators/aov.cpp:21-28,87-144); channels per type: 1 3 2 3 3 4 */
@@ -105,6 +107,8 @@ typedef struct msk_spectrum_desc {
  * specular_reflectance / specular_transmittance.
  * back_bsdf implements the "twosided" adapter (bsdfs/twosided.cpp:38-101): the BSDF evaluated with
  * flipped wi/wo when cos(theta_i) < 0; the entry's own index for twosided(A), -1 for a one-sided BSDF.
+ * reflectance_texture: 0 = the diffuse reflectance is the constant `reflectance`; k > 0 = it is
+ * textures[k-1] evaluated at the hit's uv (SmoothDiffuse::m_reflectance->eval(si), diffuse.cpp:31,44).
  */
 typedef struct msk_bsdf_desc {
     int32_t type;
@@ -114,8 +118,26 @@ typedef struct msk_bsdf_desc {
     int32_t sample_visible;
     msk_spectrum_desc eta, k, specular_reflectance, specular_transmittance;
     float   ior_eta, ior_inv_eta;
-    float   reserved[2];
+    uint32_t reflectance_texture;
+    float   reserved;
 } msk_bsdf_desc;
+
+/*
+ * A texture that varies over the surface.  MSK_TEXTURE_CHECKERBOARD (textures/checkerboard.cpp:10-33):
+ * uv' = m_transform.transform_affine_point(si.uv) with m_transform = the top-left 3x3 of the `to_uv`
+ * 4x4 (Transform4f::extract, core/transform.h:142-148; `to_uv` holds its rows 0 and 1, so the uv offset
+ * is the 4x4's z column), u = uv'.x - floor(uv'.x), v likewise; color0 where (u > .5) == (v > .5), else
+ * color1.  color0 / color1 are sigmoid-polynomial coefficients of two constant `srgb` spectra (nested
+ * textures other than that are not flattened).  si.uv = the interpolated vertex texcoords, or the
+ * hit's barycentrics for a mesh without them (mesh.cpp:66,68-72).
+ */
+typedef struct msk_texture_desc {
+    int32_t type;
+    float   color0[3];
+    float   color1[3];
+    float   to_uv[6];        /* m00 m01 m02 / m10 m11 m12 */
+    float   reserved[3];
+} msk_texture_desc;
 
 /*
  * Area emitter (emitters/area.cpp) with an `srgb_d65` radiance
@@ -161,6 +183,8 @@ typedef struct msk_scene_desc {
        (spectrum.cpp:8-111: x,y,z each 95 samples 360..830 nm; d65.cpp:12-27) */
     const float *cie1931_xyz;   /* 3 * MSK_CIE_SAMPLES                         */
     const float *d65;           /* MSK_CIE_SAMPLES                             */
+    uint32_t n_textures;        /* may be 0 (textures then unused)             */
+    const msk_texture_desc *textures;
 } msk_scene_desc;
 
 /*

@@ -10,11 +10,12 @@ import os
 
 import numpy as np
 
-MSK_ABI_VERSION = 3
+MSK_ABI_VERSION = 4
 MSK_OK = 0
 MSK_ERR_INVALID_ARG, MSK_ERR_NO_DEVICE, MSK_ERR_HIP, MSK_ERR_OOM, MSK_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 MSK_BSDF_DIFFUSE, MSK_BSDF_ROUGHCONDUCTOR, MSK_BSDF_ROUGHDIELECTRIC = 0, 1, 2
 MSK_EMITTER_AREA, MSK_EMITTER_CONSTANT = 0, 1
+MSK_TEXTURE_CHECKERBOARD = 1
 MSK_EMITTER_AREA = 0
 MSK_RNG_PCG_BLOCK, MSK_RNG_COUNTER = 0, 1
 MSK_CIE_SAMPLES = 95
@@ -37,7 +38,12 @@ class BsdfDesc(C.Structure):
                 ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("sample_visible", C.c_int32),
                 ("eta", SpectrumDesc), ("k", SpectrumDesc), ("specular_reflectance", SpectrumDesc),
                 ("specular_transmittance", SpectrumDesc), ("ior_eta", C.c_float), ("ior_inv_eta", C.c_float),
-                ("reserved", C.c_float * 2)]
+                ("reflectance_texture", C.c_uint32), ("reserved", C.c_float)]
+
+
+class TextureDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("color0", C.c_float * 3), ("color1", C.c_float * 3), ("to_uv", C.c_float * 6),
+                ("reserved", C.c_float * 3)]
 
 
 class EmitterDesc(C.Structure):
@@ -63,7 +69,8 @@ class SceneDesc(C.Structure):
                 ("vertices", C.POINTER(C.c_float)), ("faces", C.POINTER(C.c_uint32)),
                 ("n_vertices", C.c_uint32), ("n_faces", C.c_uint32),
                 ("camera", CameraDesc), ("film", FilmDesc),
-                ("cie1931_xyz", C.POINTER(C.c_float)), ("d65", C.POINTER(C.c_float))]
+                ("cie1931_xyz", C.POINTER(C.c_float)), ("d65", C.POINTER(C.c_float)),
+                ("n_textures", C.c_uint32), ("textures", C.POINTER(TextureDesc))]
 
 
 class RenderParams(C.Structure):

@@ -204,7 +204,18 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         if (!covered[g]) return fail(ctx, MSK_ERR_INVALID_ARG, "face %u belongs to no mesh", g);
 
     static_assert(sizeof(msk_bsdf_desc) == 16 * MSK_BSDF_F4, "msk_bsdf_desc is uploaded verbatim as MSK_BSDF_F4 float4");
-    std::vector<float> bsdfs((size_t) std::max(1u, d->n_bsdfs) * 4 * MSK_BSDF_F4, 0.f);
+    if (d->n_textures && !d->textures) return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: texture array missing");
+    const uint32_t n_bsdf_f4 = std::max(1u, d->n_bsdfs) * MSK_BSDF_F4 + d->n_textures * 3;
+    std::vector<float> bsdfs((size_t) n_bsdf_f4 * 4, 0.f);
+    for (uint32_t t = 0; t < d->n_textures; ++t) {
+        const msk_texture_desc &td = d->textures[t];
+        if (td.type != MSK_TEXTURE_CHECKERBOARD)
+            return fail(ctx, MSK_ERR_UNSUPPORTED, "texture %u: type %d is not supported by this back end (checkerboard)", t, td.type);
+        float *o = &bsdfs[((size_t) std::max(1u, d->n_bsdfs) * MSK_BSDF_F4 + (size_t) t * 3) * 4];
+        o[0] = td.color0[0]; o[1] = td.color0[1]; o[2] = td.color0[2]; o[3] = td.to_uv[2];
+        o[4] = td.color1[0]; o[5] = td.color1[1]; o[6] = td.color1[2]; o[7] = td.to_uv[5];
+        o[8] = td.to_uv[0]; o[9] = td.to_uv[1]; o[10] = td.to_uv[3]; o[11] = td.to_uv[4];
+    }
     bool all_diffuse = true;
     for (uint32_t b = 0; b < d->n_bsdfs; ++b) {
         const msk_bsdf_desc &bd = d->bsdfs[b];
@@ -217,8 +228,14 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
             return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: negative roughness", b);
         if (bd.type == MSK_BSDF_ROUGHDIELECTRIC && !(bd.ior_eta > 0.f && bd.ior_inv_eta > 0.f))
             return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: the relative index of refraction must be positive", b);
-        if (bd.type != MSK_BSDF_DIFFUSE || bd.back_bsdf >= 0) all_diffuse = false;
-        std::memcpy(&bsdfs[(size_t) b * 4 * MSK_BSDF_F4], &bd, sizeof bd);
+        if (bd.reflectance_texture > d->n_textures)
+            return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: reflectance_texture %u out of range", b, bd.reflectance_texture);
+        if (bd.reflectance_texture && bd.type != MSK_BSDF_DIFFUSE)
+            return fail(ctx, MSK_ERR_UNSUPPORTED, "bsdf %u: only the diffuse reflectance can be textured", b);
+        if (bd.type != MSK_BSDF_DIFFUSE || bd.back_bsdf >= 0 || bd.reflectance_texture) all_diffuse = false;
+        msk_bsdf_desc rec = bd;                                    // device form: the texture's float4 offset in the table
+        if (bd.reflectance_texture) rec.reflectance_texture = std::max(1u, d->n_bsdfs) * MSK_BSDF_F4 + (bd.reflectance_texture - 1) * 3;
+        std::memcpy(&bsdfs[(size_t) b * 4 * MSK_BSDF_F4], &rec, sizeof rec);
     }
     std::vector<float> emitters((size_t) std::max(1u, d->n_emitters) * 8, 0.f), d65((size_t) std::max(1u, d->n_emitters) * 95, 0.f), cdf_all;
     int env_emitter = -1;
@@ -280,7 +297,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     ds.mesh_info = s->mesh_info.as<int4>(); ds.bsdfs = s->bsdfs.as<float4>(); ds.emitters = s->emitters.as<float4>();
     ds.emitter_d65 = s->emitter_d65.as<float>(); ds.cdf = s->cdf.as<float>(); ds.cie = s->cie.as<float>();
     ds.n_nodes = (uint32_t) (bvh.nodes.size() / 16); ds.n_tris = d->n_faces; ds.n_emitters = d->n_emitters;
-    ds.n_meshes = d->n_meshes; ds.n_bsdfs = d->n_bsdfs; ds.cdf_len = (uint32_t) cdf_all.size();
+    ds.n_meshes = d->n_meshes; ds.n_bsdfs = d->n_bsdfs; ds.n_bsdf_f4 = n_bsdf_f4; ds.cdf_len = (uint32_t) cdf_all.size();
     ds.root_ref = bvh.root_ref;
     ds.stack_entries = (uint32_t) ((bvh.max_depth + 2 + 3) & ~3);
     std::memcpy(ds.s2c, d->camera.sample_to_camera, 64); std::memcpy(ds.to_world, d->camera.to_world, 64);
@@ -337,7 +354,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         s->trace_lds_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4;
     }
     // LDS plan of k_shade_gen: the small lookup tables (tri_verts, mesh/bsdf/emitter records, cdf, d65, cie)
-    const size_t table_bytes = ((size_t) ds.n_tris * 3 + ds.n_meshes + ds.n_bsdfs * MSK_BSDF_F4 + ds.n_emitters * 2 +
+    const size_t table_bytes = ((size_t) ds.n_tris * 3 + ds.n_meshes + ds.n_bsdf_f4 + ds.n_emitters * 2 +
                                 (ds.n_emitters * 95 + 3) / 4 + (ds.cdf_len + 3) / 4 + 72) * 16;
     s->lds_tables = table_bytes <= 40 * 1024;
     // + the waves' done-queues (k_shade_gen: 3 x MSK_DONE_Q float4 per wave)

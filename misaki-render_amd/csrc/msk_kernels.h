@@ -45,7 +45,10 @@ struct DeviceScene {
     const float4 *tri_normals;  // 3 x float4 per triangle (n0 n1 n2) or nullptr
     const float4 *tri_uvs;      // 2 x float4 per triangle (uv0 uv1 | uv2 -) or nullptr
     const int4 *mesh_info;      // {bsdf_id, emitter_id, flags(1=normals,2=texcoords), first_face}
-    const float4 *bsdfs;        // MSK_BSDF_F4 x float4 per bsdf = msk_bsdf_desc verbatim
+    const float4 *bsdfs;        // MSK_BSDF_F4 x float4 per bsdf = msk_bsdf_desc verbatim (reflectance_texture rewritten as the
+                                // float4 offset of the texture record), then 3 x float4 per texture: {color0, m02} {color1, m12}
+                                // {m00 m01 m10 m11}
+    uint32_t n_bsdf_f4;         // float4 count of `bsdfs` (records + textures)
     const float4 *emitters;     // 2 x float4 per emitter: {c0,c1,c2,inv_area} {mesh,first_face,face_count,cdf_off (uint bits)}
     const float *emitter_d65;   // 95 floats per emitter (d65 * d65_scale)
     const float *cdf;           // concatenated area CDFs (face_count+1 each)
@@ -577,7 +580,7 @@ struct SceneTables {
     const float *emitter_d65, *cdf, *cie;
 };
 MSK_DEV uint32_t tables_lds_float4s(const DeviceScene &sc) {
-    return sc.n_tris * 3 + sc.n_meshes + sc.n_bsdfs * MSK_BSDF_F4 + sc.n_emitters * 2 + (sc.n_emitters * 95 + 3) / 4 + (sc.cdf_len + 3) / 4 + 72;
+    return sc.n_tris * 3 + sc.n_meshes + sc.n_bsdf_f4 + sc.n_emitters * 2 + (sc.n_emitters * 95 + 3) / 4 + (sc.cdf_len + 3) / 4 + 72;
 }
 template <bool LDS_TABLES>
 MSK_DEV SceneTables stage_tables(const DeviceScene &sc, float4 *lds) {
@@ -593,7 +596,7 @@ MSK_DEV SceneTables stage_tables(const DeviceScene &sc, float4 *lds) {
     auto copy1 = [&](const float *src, uint32_t n) { float *d = (float *) p; for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = src[i]; p += (n + 3) / 4; return d; };
     t.tri_verts = copy4(sc.tri_verts, sc.n_tris * 3);
     t.mesh_info = (const int4 *) copy4((const float4 *) sc.mesh_info, sc.n_meshes);
-    t.bsdfs = copy4(sc.bsdfs, sc.n_bsdfs * MSK_BSDF_F4);
+    t.bsdfs = copy4(sc.bsdfs, sc.n_bsdf_f4);
     t.emitters = copy4(sc.emitters, sc.n_emitters * 2);
     t.emitter_d65 = copy1(sc.emitter_d65, sc.n_emitters * 95);
     t.cdf = copy1(sc.cdf, sc.cdf_len);
@@ -657,6 +660,24 @@ MSK_DEV BsdfRec load_bsdf(const SceneTables &tb, int id) {
     BsdfRec r; const float4 *p = tb.bsdfs + (size_t) id * MSK_BSDF_F4;
     r.a = p[0]; r.b = p[1]; r.eta = p[2]; r.k = p[3]; r.spec = p[4]; r.trans = p[5]; r.ior = p[6];
     return r;
+}
+// textures/checkerboard.cpp:24-33 at the hit's uv (mesh.cpp:66,68-72): the coefficients SmoothDiffuse::m_reflectance->eval(si)
+// evaluates.  `rec` = float4 offset of the texture record in tb.bsdfs.
+MSK_DEV f3 checkerboard_coeffs(const SceneTables &tb, uint32_t rec, float4 hit) {
+    const uint32_t prim = __float_as_uint(hit.w);
+    const int4 mi = tb.mesh_info[__float_as_uint(tb.tri_verts[(size_t) prim * 3].w)];
+    float u = hit.y, v = hit.z;
+    if (mi.z & 2) {
+        const float4 ua = tb.tri_uvs[(size_t) prim * 2], ub = tb.tri_uvs[(size_t) prim * 2 + 1];
+        const float b1 = hit.y, b2 = hit.z, b0 = 1.f - b1 - b2;
+        u = ua.x * b0 + ua.z * b1 + ub.x * b2;
+        v = ua.y * b0 + ua.w * b1 + ub.y * b2;
+    }
+    const float4 t0 = tb.bsdfs[rec], t1 = tb.bsdfs[rec + 1], m = tb.bsdfs[rec + 2];
+    const float x = m.x * u + (m.y * v + t0.w * 1.f), y = m.z * u + (m.w * v + t1.w * 1.f);
+    const float fu = x - floorf(x), fv = y - floorf(y);
+    const bool first = (fu > .5f) == (fv > .5f);
+    return first ? mk3(t0.x, t0.y, t0.z) : mk3(t1.x, t1.y, t1.z);
 }
 MSK_DEV spec spectrum_eval(float4 s, spec wl) { return srgb_model_eval(s.x, s.y, s.z, wl) * s.w; }
 MSK_DEV float clamp_alpha(float a) { return fmax_std(a, 1e-4f); }
@@ -935,7 +956,13 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
             if (alive) {
                 const uint32_t pb = 3 + 3 * (depth - 1);
                 spec refl = splat(0.f);                  // SmoothDiffuse::m_reflectance->eval(si) (diffuse.cpp:31,44): once per bounce
-                if (DIFFUSE_ONLY || __float_as_int(bs.a.x) == 0) refl = srgb_model_eval(bs.a.z, bs.a.w, bs.b.x, wl);
+                if (DIFFUSE_ONLY) refl = srgb_model_eval(bs.a.z, bs.a.w, bs.b.x, wl);
+                else if (__float_as_int(bs.a.x) == 0) {
+                    f3 c = mk3(bs.a.z, bs.a.w, bs.b.x);
+                    const uint32_t tex = __float_as_uint(bs.ior.z);
+                    if (tex) c = checkerboard_coeffs(tb, tex, hit);
+                    refl = srgb_model_eval(c.x, c.y, c.z, wl);
+                }
                 // ---- next-event estimation (path.cpp:56-67, scene.cpp:68-103)
                 if (n_em > 0) {
                     f2 u = counter_pair(key, pb + 0);

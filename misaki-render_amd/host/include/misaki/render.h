@@ -18,6 +18,8 @@ public:
     // (render/srgb.h:8-19) optionally multiplied by a scaled D65 table (spectra/srgb_d65.cpp:34-36)
     struct Flat { float coeff[3] = {0, 0, 0}; float scale = 1.f; float d65_scale = 0.f; bool uses_d65 = false; };
     virtual bool flatten(Flat &out) const { (void) out; return false; }
+    // plugins whose value varies with si.uv describe themselves as an msk_texture_desc instead
+    virtual bool flatten_texture(msk_texture_desc &out) const { (void) out; return false; }
     virtual float mean() const { return 0.f; }
     static ref<Texture> D65(float scale);
     MSK_DECLARE_CLASS()
@@ -97,7 +99,8 @@ protected:
 // include/misaki/render/bsdf.h
 class BSDF : public Object {
 public:
-    virtual bool flatten(msk_bsdf_desc &out) const { (void) out; return false; }
+    // `textures`: the scene's table of surface-varying textures; a BSDF that uses one appends it (msk_bsdf_desc::reflectance_texture)
+    virtual bool flatten(msk_bsdf_desc &out, std::vector<msk_texture_desc> &textures) const { (void) out; (void) textures; return false; }
     virtual const BSDF *nested(int side) const { (void) side; return nullptr; }   // twosided: the BSDF of side 0 / 1
     std::string id() const override { return m_id; }
     MSK_DECLARE_CLASS()
@@ -233,6 +236,7 @@ struct FlatScene {
     std::vector<msk_mesh_desc> meshes;
     std::vector<msk_bsdf_desc> bsdfs;
     std::vector<msk_emitter_desc> emitters;
+    std::vector<msk_texture_desc> textures;
     std::vector<float> vertices;
     std::vector<uint32_t> faces;
     msk_render_params params;

@@ -246,6 +246,35 @@ private:
 MSK_IMPLEMENT_CLASS(SRGBEmitterSpectrum, Texture)
 MSK_REGISTER_INSTANCE(SRGBEmitterSpectrum, "srgb_d65")
 
+// textures/checkerboard.cpp:10-15 — same plugin name and properties (color0 default .4, color1 default .2, to_uv);
+// evaluated on the MI355X from its flat description
+class CheckerboardTexture final : public Texture {
+public:
+    CheckerboardTexture(const Properties &props) : Texture(props) {
+        m_color0 = props.texture("color0", .4f);
+        m_color1 = props.texture("color1", .2f);
+        m_to_uv = props.transform("to_uv", Transform4f());
+    }
+    bool flatten_texture(msk_texture_desc &out) const override {
+        Flat c0, c1;
+        if (!m_color0->flatten(c0) || !m_color1->flatten(c1) || c0.uses_d65 || c1.uses_d65 || c0.scale != 1.f || c1.scale != 1.f) return false;
+        std::memset(&out, 0, sizeof out);
+        out.type = MSK_TEXTURE_CHECKERBOARD;
+        std::memcpy(out.color0, c0.coeff, sizeof c0.coeff);
+        std::memcpy(out.color1, c1.coeff, sizeof c1.coeff);
+        // Transform4f::extract (core/transform.h:142-148): the top-left 3x3 acts on (u, v, 1)
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) out.to_uv[r * 3 + c] = (float) m_to_uv.matrix().m[r][c];
+        return true;
+    }
+    float mean() const override { return m_color0->mean() + m_color1->mean(); }   // checkerboard.cpp:46 (a sum, as there)
+    MSK_DECLARE_CLASS()
+private:
+    ref<Texture> m_color0, m_color1;
+    Transform4f m_to_uv;
+};
+MSK_IMPLEMENT_CLASS(CheckerboardTexture, Texture)
+MSK_REGISTER_INSTANCE(CheckerboardTexture, "checkerboard")
+
 // =========================================================================== filter, sampler, film
 // filters/gaussian.cpp:10-20
 class GaussianFilter final : public ReconstructionFilter {
@@ -359,12 +388,19 @@ static void init_bsdf_desc(msk_bsdf_desc &out) {
 class SmoothDiffuse final : public BSDF {
 public:
     SmoothDiffuse(const Properties &props) : BSDF(props) { m_reflectance = props.texture("reflectance", 0.5f); }
-    bool flatten(msk_bsdf_desc &out) const override {
+    bool flatten(msk_bsdf_desc &out, std::vector<msk_texture_desc> &textures) const override {
         Texture::Flat f;
-        if (!m_reflectance->flatten(f) || f.uses_d65) return false;
+        msk_texture_desc td;
         init_bsdf_desc(out);
         out.type = MSK_BSDF_DIFFUSE;
-        std::memcpy(out.reflectance, f.coeff, sizeof f.coeff);
+        if (m_reflectance->flatten(f) && !f.uses_d65) {
+            std::memcpy(out.reflectance, f.coeff, sizeof f.coeff);
+        } else if (m_reflectance->flatten_texture(td)) {            // a reflectance that varies over the surface
+            textures.push_back(td);
+            out.reflectance_texture = (uint32_t) textures.size();
+        } else {
+            return false;
+        }
         return true;
     }
     MSK_DECLARE_CLASS()
@@ -408,7 +444,8 @@ public:
         else { const float v = props.float_(name); p.set_color("color", Color3{v, v, v}); }
         return InstanceManager::get()->create_instance<Texture>(p);
     }
-    bool flatten(msk_bsdf_desc &out) const override {
+    bool flatten(msk_bsdf_desc &out, std::vector<msk_texture_desc> &textures) const override {
+        (void) textures;
         Texture::Flat e, k, s;
         if (!m_eta->flatten(e) || !m_k->flatten(k) || !m_specular_reflectance->flatten(s) || e.uses_d65 || k.uses_d65 || s.uses_d65) return false;
         init_bsdf_desc(out);
@@ -452,7 +489,8 @@ public:
             m_alpha_u = m_alpha_v = props.float_("alpha", 0.1f);
         }
     }
-    bool flatten(msk_bsdf_desc &out) const override {
+    bool flatten(msk_bsdf_desc &out, std::vector<msk_texture_desc> &textures) const override {
+        (void) textures;
         Texture::Flat r, t;
         if (!m_specular_reflectance->flatten(r) || !m_specular_transmittance->flatten(t) || r.uses_d65 || t.uses_d65) return false;
         init_bsdf_desc(out);
@@ -485,7 +523,7 @@ public:
         if (!m_brdf[1]) m_brdf[1] = m_brdf[0];
     }
     const BSDF *nested(int i) const override { return m_brdf[i].get(); }
-    bool flatten(msk_bsdf_desc &out) const override { return m_brdf[0]->flatten(out); }   // front side; flatten_scene adds the back
+    bool flatten(msk_bsdf_desc &out, std::vector<msk_texture_desc> &textures) const override { return m_brdf[0]->flatten(out, textures); }   // front side; flatten_scene adds the back
     MSK_DECLARE_CLASS()
 private:
     ref<BSDF> m_brdf[2];
@@ -700,7 +738,7 @@ MSK_REGISTER_INSTANCE(OBJMesh, "obj")
 
 // =========================================================================== flatten
 void flatten_scene(const Scene *scene, const Sensor *sensor, FlatScene &out) {
-    out.meshes.clear(); out.bsdfs.clear(); out.emitters.clear(); out.vertices.clear(); out.faces.clear();
+    out.meshes.clear(); out.bsdfs.clear(); out.emitters.clear(); out.textures.clear(); out.vertices.clear(); out.faces.clear();
     // Scene::m_emitters order (scene.cpp:27-41) decides which emitter sample_emitter_direct picks (scene.cpp:80-84)
     std::map<const Emitter *, int> emitter_index;
     for (auto &e : scene->emitters()) {
@@ -718,14 +756,14 @@ void flatten_scene(const Scene *scene, const Sensor *sensor, FlatScene &out) {
         if (!shape->is_mesh()) Throw("Shape {} (\"{}\") is not a triangle mesh: not supported by the GPU path integrator", i, shape->id());
         const Mesh *mesh = static_cast<const Mesh *>(shape);
         msk_bsdf_desc bd;
-        if (!shape->bsdf()->flatten(bd))
+        if (!shape->bsdf()->flatten(bd, out.textures))
             Throw("BSDF \"{}\" of shape {} cannot be evaluated by the GPU path integrator", shape->bsdf()->clazz()->name(), i);
         if (const BSDF *back = shape->bsdf()->nested(1)) {          // twosided adapter (twosided.cpp:38-101)
             if (back == shape->bsdf()->nested(0)) {
                 bd.back_bsdf = (int32_t) out.bsdfs.size();
             } else {
                 msk_bsdf_desc bb;
-                if (!back->flatten(bb)) Throw("BSDF \"{}\" of shape {} cannot be evaluated by the GPU path integrator", back->clazz()->name(), i);
+                if (!back->flatten(bb, out.textures)) Throw("BSDF \"{}\" of shape {} cannot be evaluated by the GPU path integrator", back->clazz()->name(), i);
                 out.bsdfs.push_back(bb);
                 bd.back_bsdf = (int32_t) out.bsdfs.size() - 1;
             }
@@ -757,6 +795,7 @@ void flatten_scene(const Scene *scene, const Sensor *sensor, FlatScene &out) {
     d.film.filter_radius = film->filter()->radius();
     std::memcpy(d.film.filter_lut, film->filter()->values().data(), sizeof d.film.filter_lut);
     d.cie1931_xyz = cie1931_xyz_table(); d.d65 = d65_table();
+    d.n_textures = (uint32_t) out.textures.size(); d.textures = out.textures.data();
 }
 
 // =========================================================================== the "path" integrator

@@ -86,12 +86,15 @@ def perspective_camera(fov, near, far, width, height, origin, target, up):
 class MeshSpec:
     """One <shape type="obj"> of the scene: faces as 3- or 4-tuples of 3D points."""
 
-    def __init__(self, name, faces, reflectance, radiance=None, translate=(0, 0, 0), normals=None, bsdf=None):
+    def __init__(self, name, faces, reflectance, radiance=None, translate=(0, 0, 0), normals=None, bsdf=None, texcoords=None):
         """bsdf: None = <bsdf type="diffuse"> with `reflectance`; or a dict for a rough conductor
         {"type": "roughconductor", "alpha": a | ("alpha_u","alpha_v"), "eta": rgb, "k": rgb,
-         "specular_reflectance": rgb (default 1), "sample_visible": bool, "twosided": bool}."""
+         "specular_reflectance": rgb (default 1), "sample_visible": bool, "twosided": bool}, a rough dielectric, or
+        {"type": "diffuse", "twosided": bool, "texture": {"type": "checkerboard", "color0": rgb, "color1": rgb,
+         "scale": (sx, sy) | "matrix": 16 floats (the to_uv 4x4, row-major)}} (texture absent = `reflectance`).
+        texcoords: None, or per face a tuple of (u, v) per corner as written in the OBJ `vt` lines (the loader stores 1 - v)."""
         self.name, self.faces, self.reflectance, self.radiance = name, faces, reflectance, radiance
-        self.translate, self.normals, self.bsdf = translate, normals, bsdf
+        self.translate, self.normals, self.bsdf, self.texcoords = translate, normals, bsdf, texcoords
 
 
 def triangulate(mesh):
@@ -99,12 +102,14 @@ def triangulate(mesh):
     (obj.cpp:104-133); `to_world` translate applied to positions at load (obj.cpp:90)."""
     verts, faces = [], []
     tr = np.asarray(mesh.translate, np.float32)
-    for f in mesh.faces:
+    for fi, f in enumerate(mesh.faces):
         base = len(verts)
-        for p in f:
+        for ci, p in enumerate(f):
             # Transform4f::apply_point with a pure translation: p + t in fp32
             q = np.asarray(p, np.float32) + tr
-            verts.append([q[0], q[1], q[2], 0, 0, 0, 0, 0])
+            uv = mesh.texcoords[fi][ci] if mesh.texcoords is not None else (0, 0)
+            verts.append([q[0], q[1], q[2], 0, 0, 0, np.float32(uv[0]),
+                          (np.float32(1) - np.float32(uv[1])) if mesh.texcoords is not None else 0])   # flip_tex_coords, obj.cpp:96-97
         if len(f) == 3:
             faces.append([base, base + 1, base + 2])
         else:
@@ -118,10 +123,15 @@ def write_obj(mesh, path):
     with open(path, "w") as fh:
         fh.write(f"# {mesh.name}: synthetic Cornell-box mesh (classic Cornell data)\n")
         n = 0
-        for f in mesh.faces:
+        for fi, f in enumerate(mesh.faces):
             for p in f:
                 fh.write("v %.9g %.9g %.9g\n" % tuple(float(np.float32(c)) for c in p))
-            fh.write("f " + " ".join(str(n + i + 1) for i in range(len(f))) + "\n")
+            if mesh.texcoords is not None:
+                for uv in mesh.texcoords[fi]:
+                    fh.write("vt %.9g %.9g\n" % tuple(float(np.float32(c)) for c in uv))
+                fh.write("f " + " ".join("%d/%d" % (n + i + 1, n + i + 1) for i in range(len(f))) + "\n")
+            else:
+                fh.write("f " + " ".join(str(n + i + 1) for i in range(len(f))) + "\n")
             n += len(f)
 
 
@@ -130,6 +140,20 @@ def _bsdf_xml(m, v3):
     spec = m.bsdf
     if spec is None:
         return ['        <bsdf type="diffuse">', '            <rgb name="reflectance" value="%s"/>' % v3(m.reflectance), '        </bsdf>']
+    if spec["type"] == "diffuse":
+        tex = spec.get("texture")
+        if tex is None:
+            body = ['<rgb name="reflectance" value="%s"/>' % v3(m.reflectance)]
+        else:     # textures/checkerboard.cpp:11-15 parameter names, as in results/Figure_2_RoughConductor/roughconductor.xml:35-41
+            xf = '<scale x="%.9g" y="%.9g"/>' % tuple(tex["scale"]) if "scale" in tex else \
+                 '<matrix value="%s"/>' % " ".join("%.9g" % float(np.float32(x)) for x in tex["matrix"])
+            body = ['<texture name="reflectance" type="%s">' % tex["type"], '    <rgb name="color0" value="%s"/>' % v3(tex["color0"]),
+                    '    <rgb name="color1" value="%s"/>' % v3(tex["color1"]), '    <transform name="to_uv">', '        ' + xf,
+                    '    </transform>', '</texture>']
+        inner = ['<bsdf type="diffuse">'] + ['    ' + b for b in body] + ['</bsdf>']
+        if spec.get("twosided"):
+            inner = ['<bsdf type="twosided">'] + ['    ' + b for b in inner] + ['</bsdf>']
+        return ['        ' + b for b in inner]
     body = []
     a = spec.get("alpha", 0.1)
     if np.isscalar(a):
@@ -277,7 +301,23 @@ def spectrum_desc(rgb, fetch):
     return abi.SpectrumDesc((C.c_float * 3)(*fetch(tuple(float(x) for x in rgb / scale))), float(scale))
 
 
-def _bsdf_desc(m, fetch, index):
+def _texture_desc(tex, fetch):
+    """textures/checkerboard.cpp:11-15: m_transform = the top-left 3x3 of the to_uv 4x4 (transform.h:142-148)."""
+    if tex["type"] != "checkerboard":
+        raise ValueError(tex["type"])
+    t = abi.TextureDesc()
+    t.type = abi.MSK_TEXTURE_CHECKERBOARD
+    t.color0[:] = fetch(tuple(tex["color0"]))
+    t.color1[:] = fetch(tuple(tex["color1"]))
+    if "scale" in tex:
+        m4 = np.diag([tex["scale"][0], tex["scale"][1], 1.0, 1.0]).astype(np.float32)
+    else:
+        m4 = np.asarray(tex["matrix"], np.float32).reshape(4, 4)
+    t.to_uv[:] = [float(x) for x in (m4[0, 0], m4[0, 1], m4[0, 2], m4[1, 0], m4[1, 1], m4[1, 2])]
+    return t
+
+
+def _bsdf_desc(m, fetch, index, textures=None):
     b = abi.BsdfDesc()
     b.back_bsdf = -1
     one = abi.SpectrumDesc((C.c_float * 3)(0.0, 0.0, float("inf")), 1.0)
@@ -287,6 +327,9 @@ def _bsdf_desc(m, fetch, index):
     if spec["type"] == "diffuse":
         b.type = abi.MSK_BSDF_DIFFUSE
         b.reflectance[:] = fetch(tuple(m.reflectance))
+        if spec.get("texture") is not None:
+            textures.append(_texture_desc(spec["texture"], fetch))
+            b.reflectance_texture = len(textures)
     elif spec["type"] == "roughconductor":
         b.type = abi.MSK_BSDF_ROUGHCONDUCTOR
         a = spec.get("alpha", 0.1)
@@ -342,7 +385,7 @@ def flatten(meshes, width, height, camera=None, filter_stddev=0.5, coeff_lookup=
     fetch = coeff_lookup or rgb2spec.srgb_model_fetch
     camera = camera or CBOX_CAMERA
     fs = FlatScene()
-    all_v, all_f, md, bd, ed = [], [], [], [], []
+    all_v, all_f, md, bd, ed, td = [], [], [], [], [], []
     nv = nf = 0
 
     def env_desc():
@@ -352,13 +395,13 @@ def flatten(meshes, width, height, camera=None, filter_stddev=0.5, coeff_lookup=
         ed.append(env_desc())
     for i, m in enumerate(meshes):
         v, f = triangulate(m)
-        bd.append(_bsdf_desc(m, fetch, len(bd)))
+        bd.append(_bsdf_desc(m, fetch, len(bd), td))
         eid = -1
         if m.radiance is not None:
             ce, d65_scale = _radiance_desc(m.radiance, fetch)
             ed.append(abi.EmitterDesc(abi.MSK_EMITTER_AREA, i, (C.c_float * 3)(*ce), float(d65_scale)))
             eid = len(ed) - 1
-        md.append(abi.MeshDesc(nv, len(v), nf, len(f), i, eid, 0, 0))
+        md.append(abi.MeshDesc(nv, len(v), nf, len(f), i, eid, 0, 1 if m.texcoords is not None else 0))
         all_v.append(v)
         all_f.append(f)
         nv += len(v)
@@ -371,11 +414,13 @@ def flatten(meshes, width, height, camera=None, filter_stddev=0.5, coeff_lookup=
     meshes_a = (abi.MeshDesc * len(md))(*md)
     bsdfs_a = (abi.BsdfDesc * len(bd))(*bd)
     emit_a = (abi.EmitterDesc * max(1, len(ed)))(*ed)
-    fs.keep += [verts, faces, cie, d65, meshes_a, bsdfs_a, emit_a]
+    tex_a = (abi.TextureDesc * max(1, len(td)))(*td)
+    fs.keep += [verts, faces, cie, d65, meshes_a, bsdfs_a, emit_a, tex_a]
     d = fs.desc
     d.abi_version = abi.MSK_ABI_VERSION
     d.n_meshes, d.n_bsdfs, d.n_emitters = len(md), len(bd), len(ed)
     d.meshes, d.bsdfs, d.emitters = meshes_a, bsdfs_a, emit_a
+    d.n_textures, d.textures = len(td), tex_a
     d.vertices = verts.ctypes.data_as(C.POINTER(C.c_float))
     d.faces = faces.ctypes.data_as(C.POINTER(C.c_uint32))
     d.n_vertices, d.n_faces = nv, nf

@@ -102,6 +102,7 @@ struct Scene {
     std::vector<msk_mesh_desc> meshes;
     std::vector<msk_bsdf_desc> bsdfs;
     std::vector<msk_emitter_desc> emitters;
+    std::vector<msk_texture_desc> textures;
     std::vector<float> vertices;
     std::vector<uint32_t> faces;
     msk_camera_desc camera;
@@ -214,6 +215,7 @@ static Scene *scene_from_desc(const msk_scene_desc *d) {
     sc->meshes.assign(d->meshes, d->meshes + d->n_meshes);
     sc->bsdfs.assign(d->bsdfs, d->bsdfs + d->n_bsdfs);
     sc->emitters.assign(d->emitters, d->emitters + d->n_emitters);
+    if (d->n_textures) sc->textures.assign(d->textures, d->textures + d->n_textures);
     sc->vertices.assign(d->vertices, d->vertices + (size_t) d->n_vertices * 8);
     sc->faces.assign(d->faces, d->faces + (size_t) d->n_faces * 3);
     sc->camera = d->camera;
@@ -773,13 +775,29 @@ static S4 roughdielectric_sample(const msk_bsdf_desc &b, V3 wi, float sample1, V
     return weight;
 }
 
-// one-sided evaluation (wi already on the front side for twosided)
-static void bsdf_eval_pdf(const msk_bsdf_desc &b, V3 wi, V3 wo, S4 wl, S4 *val, float *pdf) {
+// textures/checkerboard.cpp:24-33: which of the two colours the texture shows at uv.  The 3x3 product of
+// Transform3f::transform_affine_point (core/transform.h:41-48) is Eigen's coefficient-based one: each row is
+// a 3-element reduction a0 + (a1 + a2), like every other 3-vector sum here.
+static const float *checkerboard_lookup(const msk_texture_desc &t, V2 uv) {
+    const float x = t.to_uv[0] * uv.x + (t.to_uv[1] * uv.y + t.to_uv[2] * 1.f);
+    const float y = t.to_uv[3] * uv.x + (t.to_uv[4] * uv.y + t.to_uv[5] * 1.f);
+    const float u = x - std::floor(x), v = y - std::floor(y);
+    return ((u > .5f) == (v > .5f)) ? t.color0 : t.color1;
+}
+// SmoothDiffuse::m_reflectance->eval(si) (diffuse.cpp:31,44): the coefficients of the spectrum the reflectance
+// texture shows at the hit
+static const float *reflectance_at(const Scene &sc, const msk_bsdf_desc &b, V2 uv) {
+    if (b.reflectance_texture == 0) return b.reflectance;
+    return checkerboard_lookup(sc.textures[b.reflectance_texture - 1], uv);
+}
+
+// one-sided evaluation (wi already on the front side for twosided); refl = reflectance_at() of the hit
+static void bsdf_eval_pdf(const msk_bsdf_desc &b, const float *refl, V3 wi, V3 wo, S4 wl, S4 *val, float *pdf) {
     *val = s4(0.f); *pdf = 0.f;
     float cos_i = wi.z, cos_o = wo.z;
     if (b.type == MSK_BSDF_DIFFUSE) {                                  // diffuse.cpp:35-57
         if (cos_i > 0.f && cos_o > 0.f) {
-            *val = srgb_model_eval(b.reflectance, wl) * kInvPi * cos_o;
+            *val = srgb_model_eval(refl, wl) * kInvPi * cos_o;
             *pdf = square_to_cosine_hemisphere_pdf(wo);
         }
         return;
@@ -804,7 +822,7 @@ static void bsdf_eval_pdf(const msk_bsdf_desc &b, V3 wi, V3 wo, S4 wl, S4 *val, 
         else *pdf = (distr_eval(m, au, av) * m.z) / (4.f * dot(wo, m));
     }
 }
-static S4 bsdf_sample(const msk_bsdf_desc &b, V3 wi, float sample1, V2 sample, S4 wl, BSDFSampleRec *bs) {
+static S4 bsdf_sample(const msk_bsdf_desc &b, const float *refl, V3 wi, float sample1, V2 sample, S4 wl, BSDFSampleRec *bs) {
     bs->wo = mk3(0, 0, 0); bs->pdf = 0.f; bs->eta = 1.f; bs->sampled_type = 0;       // render/bsdf.h:75-77
     if (b.type == MSK_BSDF_ROUGHDIELECTRIC) return roughdielectric_sample(b, wi, sample1, sample, wl, bs);
     float cos_i = wi.z;
@@ -813,7 +831,7 @@ static S4 bsdf_sample(const msk_bsdf_desc &b, V3 wi, float sample1, V2 sample, S
         bs->wo = square_to_cosine_hemisphere(sample);
         bs->pdf = square_to_cosine_hemisphere_pdf(bs->wo);
         bs->sampled_type = kDiffuseReflection;
-        return bs->pdf > 0.f ? srgb_model_eval(b.reflectance, wl) : s4(0.f);
+        return bs->pdf > 0.f ? srgb_model_eval(refl, wl) : s4(0.f);
     }
     // roughconductor.cpp:52-80
     const float au = clamp_alpha(b.alpha_u), av = clamp_alpha(b.alpha_v);
@@ -874,7 +892,7 @@ static S4 path_sample(const Scene &sc, Sampler &sampler, Ray ray, S4 wl, const m
                 const msk_bsdf_desc *bb = bsdf_side(sc, bsdf, &wi_s, &flipped);
                 if (flipped) wo.z *= -1.f;
                 S4 bsdf_val; float bsdf_pdf;
-                bsdf_eval_pdf(*bb, wi_s, wo, wl, &bsdf_val, &bsdf_pdf);
+                bsdf_eval_pdf(*bb, reflectance_at(sc, *bb, si.uv), wi_s, wo, wl, &bsdf_val, &bsdf_pdf);
                 float weight = mis_weight(ds.pdf, bsdf_pdf);
                 if (g_trace_path)
                     std::printf("  d%d NEE: ds.pdf %.9g bsdf_pdf %.9g w %.9g emitter_val %.9g bsdf_val %.9g %.9g %.9g %.9g thr %.9g wo_local %.9g %.9g %.9g wi %.9g %.9g %.9g\n", depth, ds.pdf,
@@ -890,7 +908,7 @@ static S4 path_sample(const Scene &sc, Sampler &sampler, Ray ray, S4 wl, const m
         {
             V3 wi_s = si.wi; bool flipped;
             const msk_bsdf_desc *bb = bsdf_side(sc, bsdf, &wi_s, &flipped);
-            bsdf_val = bsdf_sample(*bb, wi_s, sample1, u2, wl, &bs);
+            bsdf_val = bsdf_sample(*bb, reflectance_at(sc, *bb, si.uv), wi_s, sample1, u2, wl, &bs);
             if (flipped) bs.wo.z *= -1.f;
         }
         const V3 bs_wo = bs.wo; const float bs_pdf = bs.pdf, bs_eta = bs.eta;
@@ -1219,6 +1237,8 @@ void msk_oracle_sample_wavelength(float u, float *wl4, float *w4) {
     S4 a, b; sample_wavelength(u, &a, &b);
     for (int i = 0; i < 4; ++i) { wl4[i] = a.v[i]; w4[i] = b.v[i]; }
 }
+// KAT hook: 0 / 1 = the checkerboard shows color0 / color1 at uv
+int msk_oracle_checkerboard(const msk_texture_desc *t, float u, float v) { return checkerboard_lookup(*t, V2{u, v}) == t->color0 ? 0 : 1; }
 void msk_oracle_srgb_model_eval(const float *coeff3, const float *wl4, float *out4) {
     S4 w; for (int i = 0; i < 4; ++i) w.v[i] = wl4[i];
     S4 r = srgb_model_eval(coeff3, w);
@@ -1246,7 +1266,7 @@ void msk_oracle_bsdf_eval(const msk_bsdf_desc *bsdfs, int n, int id, const float
     S4 wl; for (int i = 0; i < 4; ++i) wl.v[i] = wl4[i];
     bool flipped; const msk_bsdf_desc *b = bsdf_side(sc, sc.bsdfs[id], &wi, &flipped);
     if (flipped) wo.z *= -1.f;
-    S4 v; bsdf_eval_pdf(*b, wi, wo, wl, &v, pdf);
+    S4 v; bsdf_eval_pdf(*b, b->reflectance, wi, wo, wl, &v, pdf);
     for (int i = 0; i < 4; ++i) val4[i] = v.v[i];
 }
 void msk_oracle_bsdf_sample(const msk_bsdf_desc *bsdfs, int n, int id, const float *wi3, const float *u2, const float *wl4,
@@ -1255,7 +1275,7 @@ void msk_oracle_bsdf_sample(const msk_bsdf_desc *bsdfs, int n, int id, const flo
     V3 wi = mk3(wi3[0], wi3[1], wi3[2]);
     S4 wl; for (int i = 0; i < 4; ++i) wl.v[i] = wl4[i];
     bool flipped; const msk_bsdf_desc *b = bsdf_side(sc, sc.bsdfs[id], &wi, &flipped);
-    BSDFSampleRec bs; S4 w = bsdf_sample(*b, wi, 0.f, V2{u2[0], u2[1]}, wl, &bs);
+    BSDFSampleRec bs; S4 w = bsdf_sample(*b, b->reflectance, wi, 0.f, V2{u2[0], u2[1]}, wl, &bs);
     if (flipped) bs.wo.z *= -1.f;
     wo3[0] = bs.wo.x; wo3[1] = bs.wo.y; wo3[2] = bs.wo.z; *pdf = bs.pdf;
     for (int i = 0; i < 4; ++i) weight4[i] = w.v[i];
@@ -1267,7 +1287,7 @@ void msk_oracle_bsdf_sample2(const msk_bsdf_desc *bsdfs, int n, int id, const fl
     V3 wi = mk3(wi3[0], wi3[1], wi3[2]);
     S4 wl; for (int i = 0; i < 4; ++i) wl.v[i] = wl4[i];
     bool flipped; const msk_bsdf_desc *b = bsdf_side(sc, sc.bsdfs[id], &wi, &flipped);
-    BSDFSampleRec bs; S4 w = bsdf_sample(*b, wi, sample1, V2{u2[0], u2[1]}, wl, &bs);
+    BSDFSampleRec bs; S4 w = bsdf_sample(*b, b->reflectance, wi, sample1, V2{u2[0], u2[1]}, wl, &bs);
     if (flipped) bs.wo.z *= -1.f;
     wo3[0] = bs.wo.x; wo3[1] = bs.wo.y; wo3[2] = bs.wo.z; *pdf = bs.pdf; *eta = bs.eta; *sampled_type = bs.sampled_type;
     for (int i = 0; i < 4; ++i) weight4[i] = w.v[i];

@@ -100,6 +100,11 @@ class Oracle:
         self.lib.msk_oracle_det_math2(x, _p(o))
         return o
 
+    def checkerboard(self, tex, u, v):
+        """0 / 1 = which colour the checkerboard texture descriptor shows at (u, v)"""
+        self.lib.msk_oracle_checkerboard.restype = C.c_int
+        return int(self.lib.msk_oracle_checkerboard(C.byref(tex), C.c_float(u), C.c_float(v)))
+
     def bsdf_eval(self, bsdfs, idx, wi, wo, wl=(450, 520, 600, 680)):
         arr = (self.abi.BsdfDesc * len(bsdfs))(*bsdfs)
         wi, wo, wl = (np.asarray(v, np.float32) for v in (wi, wo, wl))

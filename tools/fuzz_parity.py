@@ -44,6 +44,17 @@ def random_scene(rng):
         elif t == 3:
             bsdf = {"type": "roughconductor", "alpha": (float(rng.uniform(0.02, 0.5)), float(rng.uniform(0.02, 0.5))),
                     "eta": (1.5, 1.5, 1.5), "k": (3.0, 3.0, 3.0), "twosided": True}
+        if t == 0:
+            # textured reflectance on some diffuse surfaces; drawn from a side stream so that the seed -> geometry mapping of
+            # earlier sweeps stays what it was
+            trng = np.random.RandomState(int(refl[0] * 1e9) % (2 ** 31))
+            if trng.randint(0, 3) == 0:
+                m = np.zeros(16)
+                m[[0, 1, 2, 4, 5, 6]] = trng.uniform(-12, 12, 6) * (trng.uniform(size=6) < 0.8)
+                m[15] = 1
+                bsdf = {"type": "diffuse", "twosided": bool(trng.randint(0, 2)),
+                        "texture": {"type": "checkerboard", "color0": refl, "color1": tuple(float(x) for x in trng.uniform(0.02, 0.98, 3)),
+                                    "matrix": [float(np.float32(x)) for x in m]}}
         rad = tuple(float(x) for x in rng.uniform(1, 30, 3)) if i < n_light else None
         meshes.append(hm.MeshSpec("m%d" % i, faces, refl, radiance=rad, bsdf=bsdf))
     if rng.randint(0, 7) == 0:      # a mesh big enough for the HBM traversal kernels (tree > 48 KB)
