@@ -738,6 +738,8 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
             const float4 *res_rec = g == 0 ? d_rec_a.as<float4>() : ws.aov_rec[slot].as<float4>();
             float *res_buf = g == 0 ? d_block_buf.as<float>() : ws.aov_block_buf[slot].as<float>();
             if (tile_x == 2 && tile_y == 2) MSK_RESOLVE(2, 2);
+            else if (tile_x == 2 && tile_y == 3) MSK_RESOLVE(2, 3);
+            else if (tile_x == 2 && tile_y == 4) MSK_RESOLVE(2, 4);
             else if (tile_x == 1 && tile_y == 1) MSK_RESOLVE(1, 1);
             else if (tile_x == 1 && tile_y == 2) MSK_RESOLVE(1, 2);
             else if (tile_x == 1 && tile_y == 3) MSK_RESOLVE(1, 3);

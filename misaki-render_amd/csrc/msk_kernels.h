@@ -1271,8 +1271,10 @@ k_resolve_blocks(DeviceScene sc, const BlockInfo *blocks, uint32_t n_blocks, con
     const int tx0 = (int) (t % (uint32_t) tiles_x) * TX, ty0 = (int) (t / (uint32_t) tiles_x) * TY;
     if (tx0 >= sx || ty0 >= sy) return;
     const float radius = sc.filter_radius, scale = sc.filter_scale;
-    // a sample of source pixel x lands on bordered targets within border-r-.5 .. border+r+.5 of x
-    const int span = (int) ceilf(radius + 0.5f);
+    // a sample of source pixel x sits at bordered position px in [x + border - .5, x + border + .5] (x + u in fp32 may round
+    // up to x + 1) and lands on the integer targets t with |t - px| <= r, i.e. |t - border - x| <= floor(r + .5): for the
+    // Gaussian's r = 2 a target gathers from 5 x 5 source pixels
+    const int span = (int) floorf(radius + 0.5f);
     // channels X, Y, Z and one accumulator for A and W (both receive w * 1, integrator.cpp:119-123: identical sums)
     float acc[TY][TX][4];
 #pragma unroll
