@@ -115,7 +115,7 @@ def triangulate(mesh):
         else:
             faces.append([base, base + 1, base + 2])
             faces.append([base + 3, base, base + 2])
-    return np.array(verts, np.float32), np.array(faces, np.uint32)
+    return np.array(verts, np.float32).reshape(-1, 8), np.array(faces, np.uint32).reshape(-1, 3)
 
 
 def write_obj(mesh, path):
@@ -408,11 +408,11 @@ def flatten(meshes, width, height, camera=None, filter_stddev=0.5, coeff_lookup=
         nf += len(f)
     if env is not None and not env.get("first"):
         ed.append(env_desc())
-    verts = np.ascontiguousarray(np.concatenate(all_v), np.float32)
-    faces = np.ascontiguousarray(np.concatenate(all_f), np.uint32)
+    verts = np.ascontiguousarray(np.concatenate(all_v + [np.zeros((0, 8), np.float32)]), np.float32).reshape(-1, 8)
+    faces = np.ascontiguousarray(np.concatenate(all_f + [np.zeros((0, 3), np.uint32)]), np.uint32).reshape(-1, 3)
     cie, d65 = cie_tables()
-    meshes_a = (abi.MeshDesc * len(md))(*md)
-    bsdfs_a = (abi.BsdfDesc * len(bd))(*bd)
+    meshes_a = (abi.MeshDesc * max(1, len(md)))(*md)
+    bsdfs_a = (abi.BsdfDesc * max(1, len(bd)))(*bd)
     emit_a = (abi.EmitterDesc * max(1, len(ed)))(*ed)
     tex_a = (abi.TextureDesc * max(1, len(td)))(*td)
     fs.keep += [verts, faces, cie, d65, meshes_a, bsdfs_a, emit_a, tex_a]

@@ -331,3 +331,17 @@ def test_scene_lifecycle_releases_device_memory(gpu_ctx, abi, hostmirror, golden
     assert np.array_equal(g2.render(prm)[0].view(np.uint32), first.view(np.uint32))
     g2.close()
     other.close()
+
+
+def test_degenerate_scenes_bit_exact(gpu_ctx, oracle, abi, hostmirror):
+    from test_oracle_kat import degenerate_scenes
+    for name, (meshes, env) in degenerate_scenes(hostmirror).items():
+        flat = hostmirror.flatten(meshes, 24, 16, env=env)
+        g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+        for kw in (dict(), dict(hide_emitters=1), dict(max_depth=1)):
+            prm = abi.render_params(4, seed=1, **kw)
+            film, st = g.render(prm)
+            ref, rst = o.render(prm, threads=2)
+            assert np.array_equal(film.view(np.uint32), ref.view(np.uint32)), (name, kw)
+            assert st.samples == rst.samples
+        g.close(); o.close()

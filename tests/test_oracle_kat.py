@@ -342,3 +342,24 @@ def test_oracle_films_match_the_committed_anchor(oracle, hostmirror, abi):
         assert hashlib.sha256(film.tobytes()).hexdigest() == a["sha256"], name
         seen += 1
     assert seen == 3
+
+
+def degenerate_scenes(hostmirror):
+    """Scenes at the edges of the descriptor: nothing at all, an environment and no geometry, a mesh without faces, an area
+    light of zero area, one triangle."""
+    light = hostmirror.MeshSpec("l", [((0, 0, 0), (0, 0, 0), (0, 0, 0))], hostmirror.WHITE, radiance=(1, 1, 1))
+    tri = hostmirror.MeshSpec("t", [((100, 100, 300), (280, 420, 280), (450, 120, 320))], hostmirror.RED, radiance=(3, 2, 1))
+    return {"nothing": ([], None), "environment only": ([], {"radiance": None}),
+            "mesh without faces": ([hostmirror.MeshSpec("e", [], hostmirror.WHITE)], {"radiance": (0.2, 0.3, 0.4)}),
+            "zero-area light": ([light] + hostmirror.cbox_meshes()[1:4], None),
+            "one emitting triangle": ([tri], None)}
+
+
+def test_oracle_renders_degenerate_scenes(oracle, abi, hostmirror):
+    for name, (meshes, env) in degenerate_scenes(hostmirror).items():
+        sc = oracle.scene(hostmirror.flatten(meshes, 24, 16, env=env))
+        film, st = sc.render(abi.render_params(4, seed=1), threads=2)
+        sc.close()
+        assert np.isfinite(film).all() and film[..., 4].min() > 0 and st.samples == 24 * 16 * 4, name
+        lit = film[..., :3].sum() > 0
+        assert lit == (name in ("environment only", "mesh without faces", "one emitting triangle")), name
