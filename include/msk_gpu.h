@@ -119,7 +119,9 @@ typedef struct msk_bsdf_desc {
     msk_spectrum_desc eta, k, specular_reflectance, specular_transmittance;
     float   ior_eta, ior_inv_eta;
     uint32_t reflectance_texture;
-    float   reserved;
+    float   reflectance_scale;   /* diffuse reflectance = S(reflectance, l) * reflectance_scale: 1 for an `srgb` spectrum; a
+                                    `uniform` spectrum of value c (spectra/uniform.cpp:16-27, what <spectrum value="c"/> makes
+                                    outside an emitter, xml.cpp:285-292) is {0, 0, +inf} with scale c */
 } msk_bsdf_desc;
 
 /*

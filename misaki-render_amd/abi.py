@@ -38,7 +38,7 @@ class BsdfDesc(C.Structure):
                 ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("sample_visible", C.c_int32),
                 ("eta", SpectrumDesc), ("k", SpectrumDesc), ("specular_reflectance", SpectrumDesc),
                 ("specular_transmittance", SpectrumDesc), ("ior_eta", C.c_float), ("ior_inv_eta", C.c_float),
-                ("reflectance_texture", C.c_uint32), ("reserved", C.c_float)]
+                ("reflectance_texture", C.c_uint32), ("reflectance_scale", C.c_float)]
 
 
 class TextureDesc(C.Structure):

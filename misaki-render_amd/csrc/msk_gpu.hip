@@ -230,6 +230,8 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
             return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: the relative index of refraction must be positive", b);
         if (bd.reflectance_texture > d->n_textures)
             return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: reflectance_texture %u out of range", b, bd.reflectance_texture);
+        if (bd.type == MSK_BSDF_DIFFUSE && !(bd.reflectance_scale >= 0.f && bd.reflectance_scale < INFINITY))
+            return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: reflectance_scale must be finite and non-negative (1 for an srgb reflectance)", b);
         if (bd.reflectance_texture && bd.type != MSK_BSDF_DIFFUSE)
             return fail(ctx, MSK_ERR_UNSUPPORTED, "bsdf %u: only the diffuse reflectance can be textured", b);
         if (bd.type != MSK_BSDF_DIFFUSE || bd.back_bsdf >= 0 || bd.reflectance_texture) all_diffuse = false;

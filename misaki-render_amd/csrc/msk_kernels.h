@@ -653,7 +653,7 @@ MSK_DEV spec emitter_radiance(const SceneTables &sc, int e, spec wl) {
 // ------------------------------------------------------------------------------------------
 // BSDF layer (bsdfs/diffuse.cpp:18-57, bsdfs/roughconductor.cpp:52-120, bsdfs/twosided.cpp:38-101).
 // A bsdf record is msk_bsdf_desc as 7 float4: {type, back, r0, r1} {r2, au, av, sample_visible} eta k spec trans
-// {ior_eta, ior_inv_eta, -, -}.
+// {ior_eta, ior_inv_eta, texture record offset, reflectance_scale}.
 // ------------------------------------------------------------------------------------------
 struct BsdfRec { float4 a, b, eta, k, spec, trans, ior; };
 MSK_DEV BsdfRec load_bsdf(const SceneTables &tb, int id) {
@@ -956,12 +956,13 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
             if (alive) {
                 const uint32_t pb = 3 + 3 * (depth - 1);
                 spec refl = splat(0.f);                  // SmoothDiffuse::m_reflectance->eval(si) (diffuse.cpp:31,44): once per bounce
-                if (DIFFUSE_ONLY) refl = srgb_model_eval(bs.a.z, bs.a.w, bs.b.x, wl);
+                if (DIFFUSE_ONLY) refl = srgb_model_eval(bs.a.z, bs.a.w, bs.b.x, wl) * bs.ior.w;      // * reflectance_scale
                 else if (__float_as_int(bs.a.x) == 0) {
                     f3 c = mk3(bs.a.z, bs.a.w, bs.b.x);
+                    float scale = bs.ior.w;
                     const uint32_t tex = __float_as_uint(bs.ior.z);
-                    if (tex) c = checkerboard_coeffs(tb, tex, hit);
-                    refl = srgb_model_eval(c.x, c.y, c.z, wl);
+                    if (tex) { c = checkerboard_coeffs(tb, tex, hit); scale = 1.f; }
+                    refl = srgb_model_eval(c.x, c.y, c.z, wl) * scale;
                 }
                 // ---- next-event estimation (path.cpp:56-67, scene.cpp:68-103)
                 if (n_em > 0) {

@@ -188,6 +188,19 @@ private:
 MSK_IMPLEMENT_CLASS(SRGBReflectanceSpectrum, Texture)
 MSK_REGISTER_INSTANCE(SRGBReflectanceSpectrum, "srgb")
 
+// spectra/uniform.cpp:12-27: the same value at every wavelength (what <spectrum value="c"/> creates outside an emitter)
+class UniformSpectrum final : public Texture {
+public:
+    UniformSpectrum(const Properties &props) : Texture(props) { m_value = props.float_("value"); }
+    bool flatten(Flat &out) const override { out.coeff[0] = out.coeff[1] = 0.f; out.coeff[2] = INFINITY; out.scale = m_value; out.uses_d65 = false; return true; }
+    float mean() const override { return m_value; }
+    MSK_DECLARE_CLASS()
+private:
+    float m_value;
+};
+MSK_IMPLEMENT_CLASS(UniformSpectrum, Texture)
+MSK_REGISTER_INSTANCE(UniformSpectrum, "uniform")
+
 // srgb with the normalisation of spectra/srgb_d65.cpp:18-22 but no illuminant: value = scale * S(fetch(rgb / scale))
 // for colours above 1 (conductor eta / k given as <rgb>), plain srgb otherwise
 class SRGBUnboundedSpectrum final : public Texture {
@@ -381,6 +394,7 @@ static void init_bsdf_desc(msk_bsdf_desc &out) {
     const msk_spectrum_desc one{{0.f, 0.f, INFINITY}, 1.f};
     out.eta = out.k = out.specular_reflectance = out.specular_transmittance = one;
     out.ior_eta = out.ior_inv_eta = 1.f;
+    out.reflectance_scale = 1.f;
 }
 
 // =========================================================================== bsdf, emitter, sensor, shape
@@ -395,6 +409,7 @@ public:
         out.type = MSK_BSDF_DIFFUSE;
         if (m_reflectance->flatten(f) && !f.uses_d65) {
             std::memcpy(out.reflectance, f.coeff, sizeof f.coeff);
+            out.reflectance_scale = f.scale;
         } else if (m_reflectance->flatten_texture(td)) {            // a reflectance that varies over the surface
             textures.push_back(td);
             out.reflectance_texture = (uint32_t) textures.size();

@@ -281,8 +281,8 @@ std::pair<std::string, std::string> parse(Context &ctx, Node &n, Tag parent_tag,
                 if (n.attr("filename") || t.size() != 1) rd.fail(n.offset, "only constant <spectrum value=\"c\"/> is supported by this loader");
                 float c = parse_float(rd, n, t[0]);
                 // xml.cpp:279-300: uniform c (reflectance) or D65 * c (inside an emitter)
-                Properties p(within_emitter ? "d65" : "srgb");
-                if (within_emitter) p.set_float("scale", c); else p.set_color("color", Color3{c, c, c});
+                Properties p(within_emitter ? "d65" : "uniform");
+                if (within_emitter) p.set_float("scale", c); else p.set_float("value", c);
                 ref<Object> o = InstanceManager::get()->create_instance(p, Class::for_name("Texture"));
                 auto ex = o->expand();
                 props.set_object(n.value("name"), ex.empty() ? o : ex[0]);

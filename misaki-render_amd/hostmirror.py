@@ -138,12 +138,14 @@ def write_obj(mesh, path):
 def _bsdf_xml(m, v3):
     """The <bsdf> element of one shape (reference plugin parameter names)."""
     spec = m.bsdf
+    refl_xml = '<spectrum name="reflectance" value="%.9g"/>' % float(m.reflectance) if np.isscalar(m.reflectance) else \
+               '<rgb name="reflectance" value="%s"/>' % v3(m.reflectance)
     if spec is None:
-        return ['        <bsdf type="diffuse">', '            <rgb name="reflectance" value="%s"/>' % v3(m.reflectance), '        </bsdf>']
+        return ['        <bsdf type="diffuse">', '            ' + refl_xml, '        </bsdf>']
     if spec["type"] == "diffuse":
         tex = spec.get("texture")
         if tex is None:
-            body = ['<rgb name="reflectance" value="%s"/>' % v3(m.reflectance)]
+            body = [refl_xml]
         else:     # textures/checkerboard.cpp:11-15 parameter names, as in results/Figure_2_RoughConductor/roughconductor.xml:35-41
             xf = '<scale x="%.9g" y="%.9g"/>' % tuple(tex["scale"]) if "scale" in tex else \
                  '<matrix value="%s"/>' % " ".join("%.9g" % float(np.float32(x)) for x in tex["matrix"])
@@ -323,10 +325,16 @@ def _bsdf_desc(m, fetch, index, textures=None):
     one = abi.SpectrumDesc((C.c_float * 3)(0.0, 0.0, float("inf")), 1.0)
     b.eta, b.k, b.specular_reflectance, b.specular_transmittance = one, one, one, one
     b.ior_eta = b.ior_inv_eta = 1.0
+    b.reflectance_scale = 1.0
     spec = m.bsdf or {"type": "diffuse"}
     if spec["type"] == "diffuse":
         b.type = abi.MSK_BSDF_DIFFUSE
-        b.reflectance[:] = fetch(tuple(m.reflectance))
+        if np.isscalar(m.reflectance):        # <spectrum name="reflectance" value="c"/>: the `uniform` plugin (spectra/uniform.cpp)
+            b.reflectance[:] = (0.0, 0.0, float("inf"))
+            b.reflectance_scale = float(m.reflectance)
+        else:
+            b.reflectance[:] = fetch(tuple(m.reflectance))
+            b.reflectance_scale = 1.0
         if spec.get("texture") is not None:
             textures.append(_texture_desc(spec["texture"], fetch))
             b.reflectance_texture = len(textures)

@@ -786,18 +786,20 @@ static const float *checkerboard_lookup(const msk_texture_desc &t, V2 uv) {
 }
 // SmoothDiffuse::m_reflectance->eval(si) (diffuse.cpp:31,44): the coefficients of the spectrum the reflectance
 // texture shows at the hit
-static const float *reflectance_at(const Scene &sc, const msk_bsdf_desc &b, V2 uv) {
-    if (b.reflectance_texture == 0) return b.reflectance;
-    return checkerboard_lookup(sc.textures[b.reflectance_texture - 1], uv);
+struct Reflectance { const float *coeff; float scale; };
+static Reflectance reflectance_at(const Scene &sc, const msk_bsdf_desc &b, V2 uv) {
+    if (b.reflectance_texture == 0) return {b.reflectance, b.reflectance_scale};
+    return {checkerboard_lookup(sc.textures[b.reflectance_texture - 1], uv), 1.f};
 }
+static S4 reflectance_eval(Reflectance r, S4 wl) { return srgb_model_eval(r.coeff, wl) * r.scale; }
 
 // one-sided evaluation (wi already on the front side for twosided); refl = reflectance_at() of the hit
-static void bsdf_eval_pdf(const msk_bsdf_desc &b, const float *refl, V3 wi, V3 wo, S4 wl, S4 *val, float *pdf) {
+static void bsdf_eval_pdf(const msk_bsdf_desc &b, Reflectance refl, V3 wi, V3 wo, S4 wl, S4 *val, float *pdf) {
     *val = s4(0.f); *pdf = 0.f;
     float cos_i = wi.z, cos_o = wo.z;
     if (b.type == MSK_BSDF_DIFFUSE) {                                  // diffuse.cpp:35-57
         if (cos_i > 0.f && cos_o > 0.f) {
-            *val = srgb_model_eval(refl, wl) * kInvPi * cos_o;
+            *val = reflectance_eval(refl, wl) * kInvPi * cos_o;
             *pdf = square_to_cosine_hemisphere_pdf(wo);
         }
         return;
@@ -822,7 +824,7 @@ static void bsdf_eval_pdf(const msk_bsdf_desc &b, const float *refl, V3 wi, V3 w
         else *pdf = (distr_eval(m, au, av) * m.z) / (4.f * dot(wo, m));
     }
 }
-static S4 bsdf_sample(const msk_bsdf_desc &b, const float *refl, V3 wi, float sample1, V2 sample, S4 wl, BSDFSampleRec *bs) {
+static S4 bsdf_sample(const msk_bsdf_desc &b, Reflectance refl, V3 wi, float sample1, V2 sample, S4 wl, BSDFSampleRec *bs) {
     bs->wo = mk3(0, 0, 0); bs->pdf = 0.f; bs->eta = 1.f; bs->sampled_type = 0;       // render/bsdf.h:75-77
     if (b.type == MSK_BSDF_ROUGHDIELECTRIC) return roughdielectric_sample(b, wi, sample1, sample, wl, bs);
     float cos_i = wi.z;
@@ -831,7 +833,7 @@ static S4 bsdf_sample(const msk_bsdf_desc &b, const float *refl, V3 wi, float sa
         bs->wo = square_to_cosine_hemisphere(sample);
         bs->pdf = square_to_cosine_hemisphere_pdf(bs->wo);
         bs->sampled_type = kDiffuseReflection;
-        return bs->pdf > 0.f ? srgb_model_eval(refl, wl) : s4(0.f);
+        return bs->pdf > 0.f ? reflectance_eval(refl, wl) : s4(0.f);
     }
     // roughconductor.cpp:52-80
     const float au = clamp_alpha(b.alpha_u), av = clamp_alpha(b.alpha_v);
@@ -1266,7 +1268,7 @@ void msk_oracle_bsdf_eval(const msk_bsdf_desc *bsdfs, int n, int id, const float
     S4 wl; for (int i = 0; i < 4; ++i) wl.v[i] = wl4[i];
     bool flipped; const msk_bsdf_desc *b = bsdf_side(sc, sc.bsdfs[id], &wi, &flipped);
     if (flipped) wo.z *= -1.f;
-    S4 v; bsdf_eval_pdf(*b, b->reflectance, wi, wo, wl, &v, pdf);
+    S4 v; bsdf_eval_pdf(*b, Reflectance{b->reflectance, b->reflectance_scale}, wi, wo, wl, &v, pdf);
     for (int i = 0; i < 4; ++i) val4[i] = v.v[i];
 }
 void msk_oracle_bsdf_sample(const msk_bsdf_desc *bsdfs, int n, int id, const float *wi3, const float *u2, const float *wl4,
@@ -1275,7 +1277,7 @@ void msk_oracle_bsdf_sample(const msk_bsdf_desc *bsdfs, int n, int id, const flo
     V3 wi = mk3(wi3[0], wi3[1], wi3[2]);
     S4 wl; for (int i = 0; i < 4; ++i) wl.v[i] = wl4[i];
     bool flipped; const msk_bsdf_desc *b = bsdf_side(sc, sc.bsdfs[id], &wi, &flipped);
-    BSDFSampleRec bs; S4 w = bsdf_sample(*b, b->reflectance, wi, 0.f, V2{u2[0], u2[1]}, wl, &bs);
+    BSDFSampleRec bs; S4 w = bsdf_sample(*b, Reflectance{b->reflectance, b->reflectance_scale}, wi, 0.f, V2{u2[0], u2[1]}, wl, &bs);
     if (flipped) bs.wo.z *= -1.f;
     wo3[0] = bs.wo.x; wo3[1] = bs.wo.y; wo3[2] = bs.wo.z; *pdf = bs.pdf;
     for (int i = 0; i < 4; ++i) weight4[i] = w.v[i];
@@ -1287,7 +1289,7 @@ void msk_oracle_bsdf_sample2(const msk_bsdf_desc *bsdfs, int n, int id, const fl
     V3 wi = mk3(wi3[0], wi3[1], wi3[2]);
     S4 wl; for (int i = 0; i < 4; ++i) wl.v[i] = wl4[i];
     bool flipped; const msk_bsdf_desc *b = bsdf_side(sc, sc.bsdfs[id], &wi, &flipped);
-    BSDFSampleRec bs; S4 w = bsdf_sample(*b, b->reflectance, wi, sample1, V2{u2[0], u2[1]}, wl, &bs);
+    BSDFSampleRec bs; S4 w = bsdf_sample(*b, Reflectance{b->reflectance, b->reflectance_scale}, wi, sample1, V2{u2[0], u2[1]}, wl, &bs);
     if (flipped) bs.wo.z *= -1.f;
     wo3[0] = bs.wo.x; wo3[1] = bs.wo.y; wo3[2] = bs.wo.z; *pdf = bs.pdf; *eta = bs.eta; *sampled_type = bs.sampled_type;
     for (int i = 0; i < 4; ++i) weight4[i] = w.v[i];

@@ -262,3 +262,62 @@ def test_figure_style_scene_renders_like_the_oracle(hostmirror, oracle, tmp_path
     assert got.shape == (36, 64, 5) and st.samples == 64 * 36 * 4
     assert np.array_equal(got.view(np.uint32), film.view(np.uint32)), float(np.abs(got - film).max())
     assert np.allclose(rgba, hostmirror.develop(film), rtol=1e-6, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# `uniform` spectrum (spectra/uniform.cpp): what <spectrum name="reflectance" value="c"/> creates outside an emitter
+# (xml.cpp:285-292) — the value c at every wavelength, not the sRGB upsampling of (c, c, c)
+# ---------------------------------------------------------------------------------------------------------------------
+def uniform_scene(hostmirror, w, h, c=0.37):
+    meshes = hostmirror.cbox_meshes()
+    for m in meshes:
+        if m.name in ("cbox_floor", "cbox_back"):
+            m.reflectance = c
+    return meshes, hostmirror.flatten(meshes, w, h)
+
+
+def test_uniform_reflectance_descriptor_and_eval(oracle, hostmirror, abi):
+    meshes, flat = uniform_scene(hostmirror, 16, 16)
+    d = flat.desc
+    floor = next(i for i, m in enumerate(meshes) if m.name == "cbox_floor")
+    b = d.bsdfs[d.meshes[floor].bsdf_id]
+    assert list(b.reflectance[:2]) == [0, 0] and np.isinf(b.reflectance[2]) and b.reflectance_scale == np.float32(0.37)
+    other = d.bsdfs[d.meshes[floor + 1].bsdf_id]
+    assert other.reflectance_scale == 1.0
+    # diffuse.cpp:44: f = reflectance / pi * cos(theta_o), the same at every wavelength
+    bs = [d.bsdfs[i] for i in range(d.n_bsdfs)]
+    wo = np.array([0.3, -0.2, np.sqrt(1 - 0.13)], np.float32)
+    val, pdf = oracle.bsdf_eval(bs, d.meshes[floor].bsdf_id, (0, 0, 1), wo, wl=(380, 500, 620, 800))
+    want = np.float32(0.37) * np.float32(1 / np.pi) * wo[2]
+    assert np.all(val == val[0]) and np.isclose(val[0], want, rtol=3e-7) and np.isclose(pdf, wo[2] / np.pi, rtol=3e-7)
+
+
+def test_uniform_reflectance_xml_round_trip(hostmirror, tmp_path, abi):
+    import __graft_entry__ as ge
+    ge.build_gpu_library()
+    ge.build_host_library()
+    hostlib = importlib.import_module("misaki-render_amd.hostlib")
+    meshes, ref = uniform_scene(hostmirror, 16, 16)
+    xml = hostmirror.write_scene_xml(meshes, str(tmp_path), 16, 16, 1)
+    assert '<spectrum name="reflectance" value="0.37"/>' in open(xml).read()
+    d, r = hostlib.HostScene(xml).flatten().desc, ref.desc
+    for i in range(d.n_meshes):
+        a, b = d.bsdfs[d.meshes[i].bsdf_id], r.bsdfs[r.meshes[i].bsdf_id]
+        assert a.reflectance_scale == b.reflectance_scale and np.isinf(a.reflectance[2]) == np.isinf(b.reflectance[2])
+
+
+@pytest.mark.gpu
+def test_gpu_matches_oracle_with_uniform_reflectances(gpu_ctx, oracle, hostmirror, abi):
+    for c in (0.37, 1.0, 0.0):
+        _, flat = uniform_scene(hostmirror, 64, 64, c)
+        g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+        prm = abi.render_params(spp=8, seed=3)
+        film, st = g.render(prm)
+        ref, rst = o.render(prm, threads=8)
+        assert np.array_equal(film.view(np.uint32), ref.view(np.uint32)), c
+        g.close(); o.close()
+    _, flat = uniform_scene(hostmirror, 16, 16)
+    flat.desc.bsdfs[0].reflectance_scale = float("nan")
+    with pytest.raises(abi.MskError) as e:
+        abi.Scene(gpu_ctx, flat)
+    assert "reflectance_scale" in str(e.value)

@@ -48,7 +48,9 @@ def random_scene(rng):
             # textured reflectance on some diffuse surfaces; drawn from a side stream so that the seed -> geometry mapping of
             # earlier sweeps stays what it was
             trng = np.random.RandomState(int(refl[0] * 1e9) % (2 ** 31))
-            if trng.randint(0, 3) == 0:
+            if trng.randint(0, 6) == 0:
+                refl = float(trng.choice([0.0, 1.0, trng.uniform(0.05, 0.95)]))       # a `uniform` spectrum (spectra/uniform.cpp)
+            elif trng.randint(0, 3) == 0:
                 m = np.zeros(16)
                 m[[0, 1, 2, 4, 5, 6]] = trng.uniform(-12, 12, 6) * (trng.uniform(size=6) < 0.8)
                 m[15] = 1
