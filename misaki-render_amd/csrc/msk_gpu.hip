@@ -92,7 +92,7 @@ extern "C" int msk_gpu_init(const int *device_ids, int n, msk_ctx **out_ctx) {
     if (e == hipSuccess) e = hipHostMalloc((void **) &ctx->h_ctrl, sizeof(Ctrl), hipHostMallocDefault);
     if (e != hipSuccess) {
         int rc = fail(nullptr, MSK_ERR_HIP, "msk_gpu_init: %s", hipGetErrorString(e));
-        delete ctx;
+        msk_gpu_shutdown(ctx);             // releases whichever of stream / pinned block exist
         return rc;
     }
     if (std::string(ctx->prop.gcnArchName).find("gfx950") == std::string::npos &&
