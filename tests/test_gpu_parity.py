@@ -333,6 +333,22 @@ def test_scene_lifecycle_releases_device_memory(gpu_ctx, abi, hostmirror, golden
     other.close()
 
 
+@pytest.mark.parametrize("stddev,block", [(0.3, 8), (0.625, 16), (1.0, 32), (1.7, 32), (0.125, 4)])
+def test_other_filter_widths_bit_exact(gpu_ctx, oracle, abi, hostmirror, golden_lookup, stddev, block):
+    """GaussianFilter's stddev property (gaussian.cpp:12-14): radius = 4 stddev, border = ceil(radius - .5) (rfilter.cpp:22)
+    — the film replay's gather window and the block borders follow the radius."""
+    flat = hostmirror.flatten(hostmirror.cbox_meshes(), 83, 61, coeff_lookup=golden_lookup, filter_stddev=stddev)
+    g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+    prm = abi.render_params(spp=5, seed=4, block_size=block)
+    film, st = g.render(prm)
+    ref, rst = o.render(prm, threads=8)
+    assert np.array_equal(film.view(np.uint32), ref.view(np.uint32)), float(np.abs(film - ref).max())
+    if 2 * int(np.ceil(4 * stddev - .5)) > 4:
+        with pytest.raises(abi.MskError):                      # a block must hold its neighbours' borders
+            g.render(abi.render_params(spp=1, block_size=4))
+    g.close(); o.close()
+
+
 def test_degenerate_scenes_bit_exact(gpu_ctx, oracle, abi, hostmirror):
     from test_oracle_kat import degenerate_scenes
     for name, (meshes, env) in degenerate_scenes(hostmirror).items():

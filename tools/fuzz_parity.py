@@ -77,7 +77,9 @@ def random_scene(rng):
         c = hm.CBOX_CAMERA
         camera = dict(fov=float(rng.uniform(20, 90)), near=c["near"] * sc, far=c["far"] * sc, origin=tuple(v * sc for v in c["origin"]),
                       target=tuple(v * sc for v in c["target"]), up=c["up"])
-    flat = hm.flatten(meshes, 48, 40, env=env, camera=camera)
+    frng = np.random.RandomState(len(meshes) * 7919 + int(meshes[0].faces[0][0][0] * 1e3) % 100003)    # side stream: filter width
+    stddev = float(frng.choice([0.5, 0.5, 0.5, 0.3, 0.625, 0.9]))
+    flat = hm.flatten(meshes, 48, 40, env=env, camera=camera, filter_stddev=stddev)
     # vertex normals (perturbed face normals) and texture coordinates on some meshes: mesh.cpp:68-96
     verts, faces = flat.vertices, flat.faces
     for i in range(flat.desc.n_meshes):
