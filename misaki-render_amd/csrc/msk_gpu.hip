@@ -61,7 +61,7 @@ struct msk_scene {
     msk_ctx *ctx = nullptr;
     Workspace *ws = nullptr;           // render buffers, kept between calls (hipMalloc/hipFree of GBs costs milliseconds)
     DeviceScene dev;
-    DevBuf nodes, nodes4, tris, tri_bounds, tri_verts, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
+    DevBuf nodes, nodes4, tris, tri_bounds, tri_verts, tri_frames, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
     bool lds_scene = false, lds_tables = false, all_diffuse = true;
     int trace_mode = 0;                // 0 binary tree in LDS, 1 binary tree in HBM/L2, 2 4-wide tree in HBM/L2
     size_t trace_lds_bytes = 0, shade_lds_bytes = 0;
@@ -356,7 +356,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         s->trace_lds_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4;
     }
     // LDS plan of k_shade_gen: the small lookup tables (tri_verts, mesh/bsdf/emitter records, cdf, d65, cie)
-    const size_t table_bytes = ((size_t) ds.n_tris * 3 + ds.n_meshes + ds.n_bsdf_f4 + ds.n_emitters * 2 +
+    const size_t table_bytes = ((size_t) ds.n_tris * 6 + ds.n_meshes + ds.n_bsdf_f4 + ds.n_emitters * 2 +
                                 (ds.n_emitters * 95 + 3) / 4 + (ds.cdf_len + 3) / 4 + 72) * 16;
     s->lds_tables = table_bytes <= 40 * 1024;
     // + the waves' done-queues (k_shade_gen: 3 x MSK_DONE_Q float4 per wave)
@@ -364,6 +364,18 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     if (s->trace_lds_bytes > ctx->prop.sharedMemPerBlock) {
         delete s;
         return fail(ctx, MSK_ERR_UNSUPPORTED, "BVH depth %d needs %zu B of traversal stack per block", bvh.max_depth, stack_bytes);
+    }
+    // per-triangle shading constants, computed on the device by the code the per-hit path used to run (k_tri_frames)
+    {
+        hipError_t ef = s->tri_frames.alloc(std::max<size_t>((size_t) ds.n_tris * 48, 16));
+        if (ef != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(ef)); }
+        ds.tri_frames = s->tri_frames.as<float4>();
+        if (ds.n_tris) {
+            hipLaunchKernelGGL(k_tri_frames, dim3((ds.n_tris + MSK_BLOCK - 1) / MSK_BLOCK), dim3(MSK_BLOCK), 0, ctx->stream, ds,
+                               s->tri_frames.as<float4>());
+            ef = hipStreamSynchronize(ctx->stream);
+            if (ef != hipSuccess) { delete s; return fail(ctx, MSK_ERR_HIP, "k_tri_frames: %s", hipGetErrorString(ef)); }
+        }
     }
     *out = s;
     return MSK_OK;
@@ -409,19 +421,19 @@ static std::vector<HostBlock> spiral_blocks(int w, int h, int bs, int *nbx, int 
 // wavefront driver
 // ------------------------------------------------------------------------------------------
 struct StateBufs {
-    DevBuf id, wl, thr, res, ray_o, ray_d, sh, contrib, hit, bs_pdf, aux, counts, ctrl, stack_ovf;
+    DevBuf id, wl, thr, res, ray_o, ray_d, sh, contrib, hit, aux, counts, ctrl, stack_ovf;
     PathState st;
     hipError_t alloc(size_t n, uint32_t n_regions) {
         hipError_t e;
 #define A_(b, sz) if ((e = b.reserve(n * (sz))) != hipSuccess) return e;
         A_(id, 16) A_(wl, 16) A_(thr, 16) A_(res, 16) A_(ray_o, 16) A_(ray_d, 16) A_(sh, 16) A_(contrib, 16) A_(hit, 16)
-        A_(bs_pdf, 4) A_(aux, 8)
+        A_(aux, 8)
 #undef A_
         if ((e = counts.reserve((size_t) n_regions * sizeof(RegionCtl))) != hipSuccess) return e;
         if ((e = ctrl.reserve(sizeof(Ctrl))) != hipSuccess) return e;
         st.id = id.as<uint4>(); st.wl = wl.as<float4>(); st.thr = thr.as<float4>(); st.res = res.as<float4>();
         st.ray_o = ray_o.as<float4>(); st.ray_d = ray_d.as<float4>(); st.sh = sh.as<float4>();
-        st.contrib = contrib.as<float4>(); st.hit = hit.as<float4>(); st.bs_pdf = bs_pdf.as<float>(); st.aux = aux.as<float2>();
+        st.contrib = contrib.as<float4>(); st.hit = hit.as<float4>(); st.aux = aux.as<float2>();
         return hipSuccess;
     }
 };
@@ -658,8 +670,8 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     for (auto &b : owned) all_samples += (uint64_t) b.size_x * b.size_y * spp_owned;
     pool_shape(sc, all_samples, &region_size, &n_regions);
     const size_t n_slots = (size_t) region_size * n_regions;
-    const size_t state_bytes = n_slots * 148 + 4096;
-    const size_t held = ws.rec_a.bytes + ws.rec_b.bytes + ws.sb.id.bytes * 148 / 16;    // reusable: counts as free
+    const size_t state_bytes = n_slots * 144 + 4096;
+    const size_t held = ws.rec_a.bytes + ws.rec_b.bytes + ws.sb.id.bytes * 144 / 16;    // reusable: counts as free
     free_b += held;
     size_t budget = getenv("MSK_RECORD_BUDGET_MB") ? (size_t) atoll(getenv("MSK_RECORD_BUDGET_MB")) << 20
                                                    : (free_b > state_bytes ? (size_t) ((free_b - state_bytes) * 0.8) : 0);

@@ -42,6 +42,9 @@ struct DeviceScene {
                                 // triangles for LDS-resident scenes; trees in HBM recompute them from the record instead)
     float tri_pad;
     const float4 *tri_verts;    // 3 x float4 per triangle, scene-global order: p0|mesh p1|- p2|-
+    const float4 *tri_frames;   // 3 x float4 per triangle, written by k_tri_frames at scene creation: what make_interaction would
+                                // compute for every hit but is the same for every hit of a triangle — geometric normal | frame s
+                                // (dp_du for a mesh with vertex normals, whose frame follows the interpolated normal) | frame t
     const float4 *tri_normals;  // 3 x float4 per triangle (n0 n1 n2) or nullptr
     const float4 *tri_uvs;      // 2 x float4 per triangle (uv0 uv1 | uv2 -) or nullptr
     const int4 *mesh_info;      // {bsdf_id, emitter_id, flags(1=normals,2=texcoords), first_face}
@@ -71,11 +74,12 @@ struct PathState {
     uint4 *id;          // {pass pixel j, owned-sample index si, film pixel y*W+x, depth | MSK_FLAG_SHADOW}
     float4 *wl, *thr, *res;
     float4 *ray_o;      // o.xyz, tmin
-    float4 *ray_d;      // d.xyz, tmax
+    float4 *ray_d;      // d.xyz, then: camera ray: tmax (> 0); bounce ray (tmax = inf): minus the pdf of the BSDF sample that made
+                        // it (BSDFSample::pdf > 0, needed by the MIS weight at the next hit).  d = 0 marks a path whose
+                        // throughput is zero and which only waits for its shadow ray: such a ray hits nothing
     float4 *sh;         // shadow d.xyz, tmax
     float4 *contrib;    // NEE contribution added when the shadow ray is unoccluded
     float4 *hit;        // t,u,v,prim
-    float *bs_pdf;
     float2 *aux;        // {eta (path.cpp:29), pdf_emitter_direct of the last NEE record (path.cpp:103-106 on an environment hit)}
 };
 
@@ -344,6 +348,11 @@ MSK_DEV TraceLds stage_scene(const DeviceScene &sc, float4 *lds, bool use_lds, b
 // pre-pass costs more than it saves (trace +5..20 %).  Note for any future wave-level LDS exchange:
 // lanes communicating through LDS need a convergent `__builtin_amdgcn_wave_barrier()` + wavefront fence
 // between the phases — the compiler otherwise runs one side of a divergent region past the other's writes.
+// tmax of the extension ray in slot state (see PathState::ray_d)
+MSK_DEV float slot_tmax(float rd_w) {
+    const int m = __float_as_int(rd_w) >> 31;                 // all ones for a bounce ray (sign bit set)
+    return __int_as_float((__float_as_int(rd_w) & ~m) | (0x7f800000 & m));
+}
 #define MSK_HIT_UNOCCLUDED 0x80000000u
 #define MSK_PRIM_MASK 0x7fffffffu
 // MODE 0: binary tree staged in LDS; 1: binary tree in HBM/L2; 2: 4-wide tree in HBM/L2; 3: 4-wide tree staged in LDS
@@ -356,8 +365,7 @@ MSK_DEV bool traverse_scene(const DeviceScene &sc, const TraceLds &g, f3 o, f3 d
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(MSK_BLOCK)
-k_trace(DeviceScene sc, PathState st, PassParams pp) {
+MSK_DEV void trace_chunks(const DeviceScene &sc, const PathState &st, const PassParams &pp) {
     constexpr bool LDS_SCENE = MODE == 0 || MODE == 3;
     extern __shared__ float4 lds_dyn[];
     uint32_t *stack_base = (uint32_t *) lds_dyn;                         // stack_entries * MSK_BLOCK words
@@ -372,8 +380,10 @@ k_trace(DeviceScene sc, PathState st, PassParams pp) {
     const size_t base = (size_t) wave * pp.region_size;
     for (uint32_t c = lane; c < n; c += MSK_WAVE) {
         const size_t i = base + c;
-        const float4 ro = st.ray_o[i], rd = st.ray_d[i];
+        const float4 ro = st.ray_o[i];
+        float4 rd = st.ray_d[i];
         const uint32_t fl = st.id[i].w;
+        rd.w = slot_tmax(rd.w);
         const f3 o = mk3(ro.x, ro.y, ro.z);
         float bt, bu, bv; uint32_t bp;
         uint32_t unocc = 0;
@@ -387,6 +397,10 @@ k_trace(DeviceScene sc, PathState st, PassParams pp) {
         st.hit[i] = make_float4(valid ? bt : MSK_INF_F, bu, bv, __uint_as_float((valid ? bp : MSK_PRIM_MASK) | unocc));
     }
 }
+
+template <int MODE>
+__global__ void __launch_bounds__(MSK_BLOCK)
+k_trace(DeviceScene sc, PathState st, PassParams pp) { trace_chunks<MODE>(sc, st, pp); }
 
 // ------------------------------------------------------------------------------------------
 // k_trace_r: the same rays with lane replacement.  Every lane is a small state machine {slot, phase (shadow / closest),
@@ -492,7 +506,7 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
     uint32_t next = 0;                       // wave-uniform: first slot nobody has taken yet
     bool active = false, shadow_phase = false;
     size_t slot = 0;
-    float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 0, 0);
+    float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 0, 0);      // rd.w = the extension ray's tmax (slot_tmax)
     uint32_t unocc = 0;
     TravState t;
     t.cur = 0xffffffffu; t.sp = 0;
@@ -505,6 +519,7 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
                     slot = base + c;
                     ro = st.ray_o[slot]; rd = st.ray_d[slot];
                     const uint32_t fl = st.id[slot].w;
+                    rd.w = slot_tmax(rd.w);
                     unocc = 0; active = true;
                     shadow_phase = (fl & MSK_FLAG_SHADOW) != 0;
                     if (shadow_phase) {
@@ -574,20 +589,20 @@ struct Interaction {
 // Small read-only scene tables of the shading kernel; staged in LDS when they fit (every hit
 // looks them up through a chain of dependent indices, which from HBM/L2 costs a round trip each).
 struct SceneTables {
-    const float4 *tri_verts, *tri_normals, *tri_uvs;
+    const float4 *tri_verts, *tri_frames, *tri_normals, *tri_uvs;
     const int4 *mesh_info;
     const float4 *bsdfs, *emitters;
     const float *emitter_d65, *cdf, *cie;
 };
 MSK_DEV uint32_t tables_lds_float4s(const DeviceScene &sc) {
-    return sc.n_tris * 3 + sc.n_meshes + sc.n_bsdf_f4 + sc.n_emitters * 2 + (sc.n_emitters * 95 + 3) / 4 + (sc.cdf_len + 3) / 4 + 72;
+    return sc.n_tris * 6 + sc.n_meshes + sc.n_bsdf_f4 + sc.n_emitters * 2 + (sc.n_emitters * 95 + 3) / 4 + (sc.cdf_len + 3) / 4 + 72;
 }
 template <bool LDS_TABLES>
 MSK_DEV SceneTables stage_tables(const DeviceScene &sc, float4 *lds) {
     SceneTables t;
     t.tri_normals = sc.tri_normals; t.tri_uvs = sc.tri_uvs;
     if (!LDS_TABLES) {
-        t.tri_verts = sc.tri_verts; t.mesh_info = sc.mesh_info; t.bsdfs = sc.bsdfs; t.emitters = sc.emitters;
+        t.tri_verts = sc.tri_verts; t.tri_frames = sc.tri_frames; t.mesh_info = sc.mesh_info; t.bsdfs = sc.bsdfs; t.emitters = sc.emitters;
         t.emitter_d65 = sc.emitter_d65; t.cdf = sc.cdf; t.cie = sc.cie;
         return t;
     }
@@ -595,6 +610,7 @@ MSK_DEV SceneTables stage_tables(const DeviceScene &sc, float4 *lds) {
     auto copy4 = [&](const float4 *src, uint32_t n) { for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) p[i] = src[i]; float4 *r = p; p += n; return r; };
     auto copy1 = [&](const float *src, uint32_t n) { float *d = (float *) p; for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = src[i]; p += (n + 3) / 4; return d; };
     t.tri_verts = copy4(sc.tri_verts, sc.n_tris * 3);
+    t.tri_frames = copy4(sc.tri_frames, sc.n_tris * 3);
     t.mesh_info = (const int4 *) copy4((const float4 *) sc.mesh_info, sc.n_meshes);
     t.bsdfs = copy4(sc.bsdfs, sc.n_bsdf_f4);
     t.emitters = copy4(sc.emitters, sc.n_emitters * 2);
@@ -605,18 +621,16 @@ MSK_DEV SceneTables stage_tables(const DeviceScene &sc, float4 *lds) {
     return t;
 }
 
-// mesh.cpp:50-101 + interaction.cpp:23-37 + interaction.h:55-60
-MSK_DEV Interaction make_interaction(const SceneTables &sc, float4 hit, f3 ray_d) {
-    Interaction si;
-    const uint32_t prim = __float_as_uint(hit.w);
-    const float4 a = sc.tri_verts[(size_t) prim * 3], b = sc.tri_verts[(size_t) prim * 3 + 1],
-                 c = sc.tri_verts[(size_t) prim * 3 + 2];
+// The per-triangle part of mesh.cpp:50-101 / interaction.h:55-60: geometric normal, dp_du (coordinate_system of the normal,
+// or from the texcoords, mesh.cpp:66-80) and — for a mesh without vertex normals, whose shading normal is the geometric one —
+// the finished frame.  Runs once per scene with the arithmetic the per-hit code used to run, so hits see the same bits.
+__global__ void k_tri_frames(DeviceScene sc, float4 *out) {
+    const uint32_t prim = blockIdx.x * blockDim.x + threadIdx.x;
+    if (prim >= sc.n_tris) return;
+    const float4 a = sc.tri_verts[(size_t) prim * 3], b = sc.tri_verts[(size_t) prim * 3 + 1], c = sc.tri_verts[(size_t) prim * 3 + 2];
     const int4 mi = sc.mesh_info[__float_as_uint(a.w)];
     const f3 p0 = mk3(a.x, a.y, a.z), p1 = mk3(b.x, b.y, b.z), p2 = mk3(c.x, c.y, c.z);
-    const float b1 = hit.y, b2 = hit.z, b0 = 1.f - b1 - b2;
     const f3 dp0 = p1 - p0, dp1 = p2 - p0;
-    si.t = hit.x;
-    si.p = p0 * b0 + p1 * b1 + p2 * b2;
     const f3 n = normalized(cross(dp0, dp1));
     f3 dp_du, dp_dv;
     coordinate_system(n, &dp_du, &dp_dv);
@@ -629,16 +643,43 @@ MSK_DEV Interaction make_interaction(const SceneTables &sc, float4 hit, f3 ray_d
             dp_dv = (dp0 * (-d1x) + dp1 * d0x) * inv_det;
         }
     }
-    if (mi.z & 1) {                                   // mesh.cpp:81-96
+    f3 s = dp_du, t = mk3(0.f, 0.f, 0.f);
+    if (!(mi.z & 1)) {                                // interaction.h:55-60 with sh_frame.n = n
+        const f3 ff = (-n) * dot(n, dp_du) + dp_du;
+        s = normalized(ff);
+        t = cross(n, s);
+    }
+    out[(size_t) prim * 3] = make_float4(n.x, n.y, n.z, 0.f);
+    out[(size_t) prim * 3 + 1] = make_float4(s.x, s.y, s.z, 0.f);
+    out[(size_t) prim * 3 + 2] = make_float4(t.x, t.y, t.z, 0.f);
+}
+
+// mesh.cpp:50-101 + interaction.cpp:23-37 + interaction.h:55-60
+MSK_DEV Interaction make_interaction(const SceneTables &sc, float4 hit, f3 ray_d) {
+    Interaction si;
+    const uint32_t prim = __float_as_uint(hit.w);
+    const float4 a = sc.tri_verts[(size_t) prim * 3], b = sc.tri_verts[(size_t) prim * 3 + 1],
+                 c = sc.tri_verts[(size_t) prim * 3 + 2];
+    const float4 f1 = sc.tri_frames[(size_t) prim * 3 + 1];
+    const int4 mi = sc.mesh_info[__float_as_uint(a.w)];
+    const f3 p0 = mk3(a.x, a.y, a.z), p1 = mk3(b.x, b.y, b.z), p2 = mk3(c.x, c.y, c.z);
+    const float b1 = hit.y, b2 = hit.z, b0 = 1.f - b1 - b2;
+    si.t = hit.x;
+    si.p = p0 * b0 + p1 * b1 + p2 * b2;
+    if (mi.z & 1) {                                   // mesh.cpp:81-96: the frame follows the interpolated normal
         const float4 na = sc.tri_normals[(size_t) prim * 3], nb = sc.tri_normals[(size_t) prim * 3 + 1],
                      nc = sc.tri_normals[(size_t) prim * 3 + 2];
         si.sh.n = normalized(mk3(na.x, na.y, na.z) * b0 + mk3(nb.x, nb.y, nb.z) * b1 + mk3(nc.x, nc.y, nc.z) * b2);
-    } else {
-        si.sh.n = n;
+        const f3 dp_du = mk3(f1.x, f1.y, f1.z);
+        const f3 ff = (-si.sh.n) * dot(si.sh.n, dp_du) + dp_du;
+        si.sh.s = normalized(ff);
+        si.sh.t = cross(si.sh.n, si.sh.s);
+    } else {                                          // per-triangle constants (k_tri_frames)
+        const float4 f0 = sc.tri_frames[(size_t) prim * 3], f2 = sc.tri_frames[(size_t) prim * 3 + 2];
+        si.sh.n = mk3(f0.x, f0.y, f0.z);
+        si.sh.s = mk3(f1.x, f1.y, f1.z);
+        si.sh.t = mk3(f2.x, f2.y, f2.z);
     }
-    const f3 ff = (-si.sh.n) * dot(si.sh.n, dp_du) + dp_du;
-    si.sh.s = normalized(ff);
-    si.sh.t = cross(si.sh.n, si.sh.s);
     si.wi = si.sh.to_local(-ray_d);
     si.bsdf_id = mi.x; si.emitter_id = mi.y;
     return si;
@@ -889,7 +930,7 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
         if (active && (id.w & MSK_FLAG_SHADOW) && (__float_as_uint(hit.w) & MSK_HIT_UNOCCLUDED))
             res = res + from4(st.contrib[i]);
         hit.w = __uint_as_float(__float_as_uint(hit.w) & MSK_PRIM_MASK);
-        float bs_pdf = st.bs_pdf[i];
+        float bs_pdf = -rd4.w;                                             // meaningful for depth > 1 (PathState::ray_d)
         float eta = 1.f, nee_pdf = 0.f;                                    // carried only by the general variant
         if (!DIFFUSE_ONLY) { const float2 a = st.aux[i]; eta = a.x; nee_pdf = a.y; }
         uint32_t depth = id.w & MSK_DEPTH_MASK;
@@ -1001,7 +1042,8 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
                     const f3 ed0 = p1 - p0, ed1 = p2 - p0;                 // mesh.cpp:103-133
                     const f2 bc = square_to_uniform_triangle(u);
                     const f3 lp = p0 + ed0 * bc.x + ed1 * bc.y;
-                    f3 ln = normalized(cross(ed0, ed1));
+                    const float4 lf = tb.tri_frames[(size_t) lprim * 3];
+                    f3 ln = mk3(lf.x, lf.y, lf.z);                          // normalized(cross(ed0, ed1)), k_tri_frames
                     const int4 lmi = tb.mesh_info[__float_as_uint(la.w)];
                     if (lmi.z & 1) {
                         const float4 na = tb.tri_normals[(size_t) lprim * 3], nb = tb.tri_normals[(size_t) lprim * 3 + 1],
@@ -1055,7 +1097,7 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
                         const bool dead = !any_nonzero(thr);
                         if (dead && !has_shadow) alive = false;
                         new_o = make_float4(si.p.x, si.p.y, si.p.z, (1.f + max_abs(si.p)) * MSK_RAY_EPS_F);
-                        new_d = make_float4(wo.x, wo.y, wo.z, dead ? -1.f : MSK_INF_F);
+                        new_d = dead ? make_float4(0.f, 0.f, 0.f, -bs_pdf) : make_float4(wo.x, wo.y, wo.z, -bs_pdf);
                         depth += 1;
                     }
                 }
@@ -1098,7 +1140,6 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
             st.id[o] = make_uint4(id.x, id.y, id.z, depth | (has_shadow ? MSK_FLAG_SHADOW : 0u));
             st.wl[o] = to4(wl); st.thr[o] = to4(thr); st.res[o] = to4(res);
             st.ray_o[o] = new_o; st.ray_d[o] = new_d; st.sh[o] = new_sh; st.contrib[o] = to4(contrib);
-            st.bs_pdf[o] = bs_pdf;
             if (!DIFFUSE_ONLY) st.aux[o] = make_float2(eta, nee_pdf);
         }
         cursor += __popcll(m);
@@ -1149,7 +1190,6 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
         st.ray_o[o] = make_float4(ow.x, ow.y, ow.z, sc.near_clip * inv_z);
         st.ray_d[o] = make_float4(dw.x, dw.y, dw.z, sc.far_clip * inv_z);
         st.sh[o] = make_float4(0, 0, 0, 0); st.contrib[o] = make_float4(0, 0, 0, 0);
-        st.bs_pdf[o] = 0.f;
         if (!DIFFUSE_ONLY) st.aux[o] = make_float2(1.f, 0.f);
     }
     if (lane == 0) {

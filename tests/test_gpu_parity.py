@@ -312,7 +312,7 @@ def test_scene_lifecycle_releases_device_memory(gpu_ctx, abi, hostmirror, golden
     prm = abi.render_params(spp=4, seed=9)
     first = None
     free0 = None
-    for i in range(12):
+    for i in range(6):
         g = abi.Scene(gpu_ctx, flat)
         film, _ = g.render(prm)
         if i % 3 == 0:
