@@ -73,7 +73,8 @@ struct DeviceScene {
 struct PathState {
     uint4 *id;          // {pass pixel j, owned-sample index si, film pixel y*W+x, depth | MSK_FLAG_SHADOW}
     float4 *wl, *thr, *res;
-    float4 *ray_o;      // o.xyz, tmin
+    float4 *ray_o;      // o.xyz, tmin (>= 0) with the sign bit set when the slot also carries a shadow ray (so that the trace
+                        // kernels need no other word of the state to know)
     float4 *ray_d;      // d.xyz, then: camera ray: tmax (> 0); bounce ray (tmax = inf): minus the pdf of the BSDF sample that made
                         // it (BSDFSample::pdf > 0, needed by the MIS weight at the next hit).  d = 0 marks a path whose
                         // throughput is zero and which only waits for its shadow ray: such a ray hits nothing
@@ -380,14 +381,15 @@ MSK_DEV void trace_chunks(const DeviceScene &sc, const PathState &st, const Pass
     const size_t base = (size_t) wave * pp.region_size;
     for (uint32_t c = lane; c < n; c += MSK_WAVE) {
         const size_t i = base + c;
-        const float4 ro = st.ray_o[i];
+        float4 ro = st.ray_o[i];
         float4 rd = st.ray_d[i];
-        const uint32_t fl = st.id[i].w;
+        const bool has_shadow = __float_as_int(ro.w) < 0;
+        ro.w = fabsf(ro.w);
         rd.w = slot_tmax(rd.w);
         const f3 o = mk3(ro.x, ro.y, ro.z);
         float bt, bu, bv; uint32_t bp;
         uint32_t unocc = 0;
-        if (fl & MSK_FLAG_SHADOW) {
+        if (has_shadow) {
             const float4 s = st.sh[i];
             const bool occ = traverse_scene<MODE, true>(sc, g, o, mk3(s.x, s.y, s.z), ro.w, s.w, stack, &bt, &bu, &bv, &bp);
             unocc = occ ? 0u : MSK_HIT_UNOCCLUDED;
@@ -518,10 +520,10 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
                 if (c < n) {
                     slot = base + c;
                     ro = st.ray_o[slot]; rd = st.ray_d[slot];
-                    const uint32_t fl = st.id[slot].w;
+                    shadow_phase = __float_as_int(ro.w) < 0;
+                    ro.w = fabsf(ro.w);
                     rd.w = slot_tmax(rd.w);
                     unocc = 0; active = true;
-                    shadow_phase = (fl & MSK_FLAG_SHADOW) != 0;
                     if (shadow_phase) {
                         const float4 s = st.sh[slot];
                         trav_begin(t, MODE == 2 ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(s.x, s.y, s.z), ro.w, s.w);
@@ -1139,6 +1141,7 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
             const size_t o = base + cursor + off;
             st.id[o] = make_uint4(id.x, id.y, id.z, depth | (has_shadow ? MSK_FLAG_SHADOW : 0u));
             st.wl[o] = to4(wl); st.thr[o] = to4(thr); st.res[o] = to4(res);
+            if (has_shadow) new_o.w = __int_as_float(__float_as_int(new_o.w) | (int) 0x80000000);       // PathState::ray_o
             st.ray_o[o] = new_o; st.ray_d[o] = new_d; st.sh[o] = new_sh; st.contrib[o] = to4(contrib);
             if (!DIFFUSE_ONLY) st.aux[o] = make_float2(eta, nee_pdf);
         }
