@@ -1192,7 +1192,7 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
         st.wl[o] = to4(wl); st.thr[o] = make_float4(1.f, 1.f, 1.f, 1.f); st.res[o] = make_float4(0.f, 0.f, 0.f, 0.f);
         st.ray_o[o] = make_float4(ow.x, ow.y, ow.z, sc.near_clip * inv_z);
         st.ray_d[o] = make_float4(dw.x, dw.y, dw.z, sc.far_clip * inv_z);
-        st.sh[o] = make_float4(0, 0, 0, 0); st.contrib[o] = make_float4(0, 0, 0, 0);
+        // sh / contrib stay as they are: nothing reads them for a slot without a shadow ray (ray_o.w >= 0, no MSK_FLAG_SHADOW)
         if (!DIFFUSE_ONLY) st.aux[o] = make_float2(1.f, 0.f);
     }
     if (lane == 0) {
