@@ -79,7 +79,8 @@ def random_scene(rng):
                       target=tuple(v * sc for v in c["target"]), up=c["up"])
     frng = np.random.RandomState(len(meshes) * 7919 + int(meshes[0].faces[0][0][0] * 1e3) % 100003)    # side stream: filter width
     stddev = float(frng.choice([0.5, 0.5, 0.5, 0.3, 0.625, 0.9]))
-    flat = hm.flatten(meshes, 48, 40, env=env, camera=camera, filter_stddev=stddev)
+    fw, fh = [(48, 40), (48, 40), (33, 17), (64, 64), (7, 5), (100, 3), (1, 1), (37, 53)][frng.randint(0, 8)]      # ragged films, films smaller than a block
+    flat = hm.flatten(meshes, fw, fh, env=env, camera=camera, filter_stddev=stddev)
     # vertex normals (perturbed face normals) and texture coordinates on some meshes: mesh.cpp:68-96
     verts, faces = flat.vertices, flat.faces
     for i in range(flat.desc.n_meshes):
