@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard", choices=("samples", "tiles"), default="samples",
                     help="N > 1: which axis the ranks split (misaki-render_amd/multigpu.py); both end in one film reduce")
+    ap.add_argument("--no-balance", action="store_true",
+                    help="N > 1: keep the equal interleaved sample split even when the GPUs differ in speed")
     args = ap.parse_args()
 
     import torch
@@ -97,8 +99,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    warm = [step() for _ in range(args.warmup)]
+    balance = None
+    if dist is not None and args.shard == "samples" and not args.no_balance and warm:
+        # The GPUs of a node are not equally fast on this workload (the shading kernel differs by up to 20 %
+        # between boxes of the pool) and an equal split waits for the slowest.  Every rank's device time of the last
+        # warm-up step decides speed-proportional contiguous sample ranges; the per-GPU average stays args.spp.
+        mine = torch.tensor([warm[-1].ms_total], dtype=torch.float64, device="cuda")
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        times = [float(x.item()) for x in gathered]
+        if min(times) > 0 and max(times) / min(times) > 1.03:
+            shares = mg.balanced_shares(spp_total, times)
+            prm = mg.shard_params(abi, spp_total, rank, world, mode="range", shares=shares, seed=0)
+            step()                       # untimed: the new shares' plan and record buffers are set up here
+            balance = {"equal_split_step_ms": [round(t, 2) for t in times], "spp_shares": shares}
     fence()
     t0 = time.perf_counter()
     stats = []
@@ -149,7 +164,7 @@ def main():
                                    f"path integrator (NEE+MIS, RR from depth 4), counter RNG, Gaussian filter, "
                                    f"ordered film resolve included",
                        "parallelism": f"{args.shard[:-1]}-shard x{world} + RCCL film reduce" if world > 1 else "single GPU",
-                       "samples_per_step": samples_step,
+                       "samples_per_step": samples_step, "balance": balance,
                        "segments_per_sample": round(seg / max(smp, 1), 3)},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

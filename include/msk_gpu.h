@@ -206,8 +206,9 @@ typedef struct msk_render_params {
     /* shard: this call renders the spiral blocks id with
        id % block_stride == block_first (imageblock.cpp:187-247 order) ...     */
     uint32_t block_first, block_stride;
-    /* ... and of every pixel the sample indices s with
-       s % sample_stride == sample_first.  (0,1) = everything.                 */
+    /* ... and of every pixel the sample indices s = sample_first + k * sample_stride (k = 0, 1, ...) below spp.
+       (0,1) = everything; (r,G) = rank r's interleaved share of G; (a,1) with spp = b = the contiguous range [a, b),
+       which lets shares of unequal size be handed out (misaki-render_amd/multigpu.py).                           */
     uint32_t sample_first, sample_stride;
 } msk_render_params;
 

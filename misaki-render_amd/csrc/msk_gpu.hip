@@ -598,8 +598,8 @@ static int check_params(msk_ctx *ctx, const msk_render_params *p, int block_min)
         return fail(ctx, MSK_ERR_INVALID_ARG, "\"max_depth\" must be set to -1 (infinite) or a value >= 0");
     if (p->block_size < block_min || p->block_size > 64)
         return fail(ctx, MSK_ERR_INVALID_ARG, "block_size %d outside [%d, 64]", p->block_size, block_min);
-    const uint32_t bs = p->block_stride ? p->block_stride : 1, ss = p->sample_stride ? p->sample_stride : 1;
-    if (p->block_first >= bs || p->sample_first >= ss) return fail(ctx, MSK_ERR_INVALID_ARG, "shard selector out of range");
+    const uint32_t bs = p->block_stride ? p->block_stride : 1;
+    if (p->block_first >= bs) return fail(ctx, MSK_ERR_INVALID_ARG, "shard selector out of range");
     return MSK_OK;
 }
 

@@ -16,14 +16,41 @@ film then differs from the single-GPU one by fp32 re-association of G partial su
 """
 
 
-def shard_params(abi, spp_total, rank, world, mode="tiles", **kw):
+def shard_params(abi, spp_total, rank, world, mode="tiles", shares=None, **kw):
     """Render parameters of rank `rank`.  mode "tiles": blocks id % world == rank, every sample of those blocks;
-    mode "samples": every block, sample indices s % world == rank."""
+    mode "samples": every block, sample indices s % world == rank; mode "range": every block, the contiguous sample
+    indices [sum(shares[:rank]), sum(shares[:rank + 1])) — shares of unequal size for GPUs of unequal speed."""
     if mode == "tiles":
         return abi.render_params(spp=spp_total, block_first=rank, block_stride=world, **kw)
     if mode == "samples":
         return abi.render_params(spp=spp_total, sample_first=rank, sample_stride=world, **kw)
+    if mode == "range":
+        if shares is None or len(shares) != world or sum(shares) != spp_total or min(shares) < 1:
+            raise ValueError("shares must be %d positive integers that sum to %d" % (world, spp_total))
+        begin = sum(shares[:rank])
+        return abi.render_params(spp=begin + shares[rank], sample_first=begin, sample_stride=1, **kw)
     raise ValueError(mode)
+
+
+def balanced_shares(spp_total, step_ms):
+    """Split spp_total samples per pixel over the ranks in proportion to their measured speed (1 / step_ms of an equal
+    split), largest-remainder rounding, at least one sample each.  Same input on every rank -> same shares on every rank."""
+    world = len(step_ms)
+    if spp_total < world or min(step_ms) <= 0:
+        raise ValueError("cannot balance %d samples over %d ranks" % (spp_total, world))
+    speed = [1.0 / t for t in step_ms]
+    total = sum(speed)
+    exact = [spp_total * v / total for v in speed]
+    shares = [max(1, int(x)) for x in exact]
+    order = sorted(range(world), key=lambda r: (exact[r] - int(exact[r]), -r), reverse=True)
+    k = 0
+    while sum(shares) < spp_total:
+        shares[order[k % world]] += 1
+        k += 1
+    while sum(shares) > spp_total:                       # only after the max(1, .) clamp
+        r = max(range(world), key=lambda q: shares[q])
+        shares[r] -= 1
+    return shares
 
 
 def reduce_film(film, dist=None, dst=0):

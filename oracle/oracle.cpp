@@ -1118,7 +1118,7 @@ static void render(const Scene &sc, const msk_render_params &prm, float *film, C
                 for (int x = 0; x < bd.size_x; ++x) {
                     V2 pos{(float) x + (float) bd.off_x, (float) y + (float) bd.off_y};
                     for (uint32_t s = 0; s < prm.spp; ++s) {
-                        if (s % sstride != prm.sample_first) continue;
+                        if (s < prm.sample_first || (s - prm.sample_first) % sstride != 0) continue;   // msk_gpu.h: s = first + k stride
                         if (prm.rng_mode == MSK_RNG_COUNTER)
                             sampler.key = counter_key(prm.seed, (uint32_t) ((y + bd.off_y) * W + (x + bd.off_x)), s);
                         V2 ps;

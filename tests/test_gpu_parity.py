@@ -349,6 +349,30 @@ def test_other_filter_widths_bit_exact(gpu_ctx, oracle, abi, hostmirror, golden_
     g.close(); o.close()
 
 
+def test_sample_ranges_bit_exact_and_sum_to_the_whole(scene256, abi, hostmirror):
+    """msk_render_params: s = sample_first + k * sample_stride below spp — contiguous ranges (stride 1) and offsets beyond
+    the stride, the selectors the speed-proportional multi-GPU split uses."""
+    g, o, flat = scene256
+    whole, _ = g.render(abi.render_params(spp=9, seed=2))
+    acc = np.zeros_like(whole, dtype=np.float64)
+    n = 0
+    for first, stride, spp in ((0, 1, 4), (4, 1, 7), (7, 1, 9)):
+        prm = abi.render_params(spp=spp, seed=2, sample_first=first, sample_stride=stride)
+        film, st = g.render(prm)
+        ref, rst = o.render(prm, threads=8)
+        assert np.array_equal(film.view(np.uint32), ref.view(np.uint32)), (first, stride, spp)
+        assert st.samples == rst.samples == (spp - first) * 256 * 256
+        acc += film
+        n += st.samples
+    assert n == 9 * 256 * 256 and np.allclose(acc, whole, rtol=2e-6, atol=1e-6)
+    prm = abi.render_params(spp=12, seed=2, sample_first=5, sample_stride=3)           # s = 5, 8, 11
+    film, st = g.render(prm)
+    ref, rst = o.render(prm, threads=8)
+    assert np.array_equal(film.view(np.uint32), ref.view(np.uint32)) and st.samples == rst.samples == 3 * 256 * 256
+    film, st = g.render(abi.render_params(spp=4, seed=2, sample_first=4))              # empty range: zeros, no error
+    assert st.samples == 0 and not film.any()
+
+
 def test_degenerate_scenes_bit_exact(gpu_ctx, oracle, abi, hostmirror):
     from test_oracle_kat import degenerate_scenes
     for name, (meshes, env) in degenerate_scenes(hostmirror).items():

@@ -26,8 +26,21 @@ def _worker(rank, world, port, out_path, mode="tiles"):
     flat = hm.cbox_scene(96, 64, coeff_lookup=lambda rgb: (0.0, 0.0, 1.0))
     sc = orc.scene(flat)
     spp_total = mg.weak_scaling_spp(2, world)
-    prm = mg.shard_params(abi, spp_total, rank, world, mode=mode, seed=5)
-    if mode == "tiles":
+    if mode == "range":
+        # the speed-proportional split bench.py switches to when the GPUs of a node differ: every rank derives the same
+        # shares from the gathered step times, then renders its contiguous range of sample indices
+        t = torch.tensor([30.0 if rank == 0 else 90.0], dtype=torch.float64)
+        ts = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(ts, t)
+        shares = mg.balanced_shares(spp_total, [float(x.item()) for x in ts])
+        assert shares == [3, 1]
+        prm = mg.shard_params(abi, spp_total, rank, world, mode="range", shares=shares, seed=5)
+        assert (prm.sample_first, prm.sample_stride, prm.spp) == ((0, 1, 3) if rank == 0 else (3, 1, 4))
+    else:
+        prm = mg.shard_params(abi, spp_total, rank, world, mode=mode, seed=5)
+    if mode == "range":
+        pass
+    elif mode == "tiles":
         assert prm.block_first == rank and prm.block_stride == world and prm.spp == 2 * world
     else:
         assert prm.sample_first == rank and prm.sample_stride == world and prm.spp == 2 * world and prm.block_stride == 1
@@ -74,3 +87,32 @@ def test_two_rank_sample_shard_and_film_reduce(tmp_path):
     hm = importlib.import_module("misaki-render_amd.hostmirror")
     err = np.linalg.norm(hm.develop(reduced)[..., :3] - hm.develop(full)[..., :3], axis=-1)
     assert err.max() < 1e-4                                           # the north star's per-pixel L2 tolerance
+
+
+def test_two_rank_speed_proportional_ranges(tmp_path):
+    """Unequal shares (3 : 1) as contiguous sample ranges: every sample still rendered exactly once."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "film_r.npz")
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out, "range"), nprocs=2, join=True)
+    d = np.load(out)
+    reduced, full = d["reduced"], d["full"]
+    assert d["samples"][0] == d["full_samples"] == 96 * 64 * 4
+    assert np.allclose(reduced, full, rtol=3e-6, atol=1e-6)
+
+
+def test_balanced_shares():
+    mg = importlib.import_module("misaki-render_amd.multigpu")
+    for times in ([54, 54, 60, 60, 55, 57, 54, 60], [50, 50], [10, 1000], [1, 1, 1]):
+        for total in (len(times), 512 * len(times), 4097):
+            sh = mg.balanced_shares(total, times)
+            assert sum(sh) == total and min(sh) >= 1 and len(sh) == len(times)
+            if total >= 64 * len(times):
+                # proportional to speed within one sample
+                speed = np.array([1.0 / t for t in times]); want = total * speed / speed.sum()
+                assert np.abs(np.array(sh) - want).max() <= 1.0 + 1e-9
+    assert mg.balanced_shares(1024, [50, 50]) == [512, 512]
+    abi = importlib.import_module("misaki-render_amd.abi")
+    import pytest
+    with pytest.raises(ValueError):
+        mg.shard_params(abi, 8, 0, 2, mode="range", shares=[5, 4])

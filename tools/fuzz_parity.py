@@ -110,8 +110,10 @@ def random_params(rng):
         world = int(rng.randint(2, 5))
         if rng.randint(0, 2):
             kw.update(block_first=int(rng.randint(0, world)), block_stride=world)
-        else:
+        elif rng.randint(0, 2):
             kw.update(sample_first=int(rng.randint(0, world)), sample_stride=world)
+        else:                        # a contiguous sample range [a, spp)
+            kw.update(sample_first=int(rng.randint(0, kw["spp"])), sample_stride=1)
     return kw
 
 
