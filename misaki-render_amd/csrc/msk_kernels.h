@@ -108,6 +108,7 @@ struct PassParams {
     float4 *rec_a;                // per sample {X,Y,Z,pos.x}; record of (j, si) = rec0(j) + si * npix(j):
     float *rec_b;                 // per sample pos.y           i.e. [block][sample][pixel], pixel fastest
     uint32_t region_size, n_regions;
+    uint32_t trace_split;         // waves per region in k_trace (each takes every trace_split-th chunk); shading is one wave per region
     RegionCtl *regions;
     uint32_t *stack_ovf;          // traversal-stack overflow (LaneStack), (stack_total - stack_entries) x lanes words, or nullptr
     float4 *aov_rgb;              // nullptr, or per sample {R,G,B,pos.x} of the nested path integrator (aov.cpp:124-141)
@@ -374,12 +375,13 @@ MSK_DEV void trace_chunks(const DeviceScene &sc, const PathState &st, const Pass
     TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE, MODE == 3);
     const LaneStack<MSK_OVF(MODE)> stack{stack_base + threadIdx.x, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
                                      (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK};
-    const uint32_t wave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
+    const uint32_t gwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
+    const uint32_t wave = gwave / pp.trace_split, sub = gwave % pp.trace_split;      // region, and which of its chunks
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
     if (wave >= pp.n_regions) return;
     const uint32_t n = pp.regions[wave].count;
     const size_t base = (size_t) wave * pp.region_size;
-    for (uint32_t c = lane; c < n; c += MSK_WAVE) {
+    for (uint32_t c = sub * MSK_WAVE + lane; c < n; c += MSK_WAVE * pp.trace_split) {
         const size_t i = base + c;
         float4 ro = st.ray_o[i];
         float4 rd = st.ray_d[i];
