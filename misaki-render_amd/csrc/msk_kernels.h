@@ -1097,7 +1097,7 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
                         thr = thr * bsdf_val;                              // path.cpp:99
                         eta *= bs_eta;                                     // path.cpp:100
                         // A path whose throughput is now zero can only add zeros from here on; it lives one more
-                        // iteration iff a shadow ray is pending (tmax < 0: the extension ray finds nothing).
+                        // iteration iff a shadow ray is pending (zero direction: the extension ray finds nothing).
                         const bool dead = !any_nonzero(thr);
                         if (dead && !has_shadow) alive = false;
                         new_o = make_float4(si.p.x, si.p.y, si.p.z, (1.f + max_abs(si.p)) * MSK_RAY_EPS_F);
