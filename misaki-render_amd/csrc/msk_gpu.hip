@@ -7,6 +7,7 @@
 #include "msk_kernels.h"
 #include "msk_bvh.h"
 #include "../../include/msk_gpu.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -466,7 +467,7 @@ static uint32_t env_u32(const char *name, uint32_t def) {
 struct EventPool {
     msk_ctx *ctx; size_t next = 0;
     hipEvent_t get() {
-        if (next == ctx->events.size()) { hipEvent_t e; (void) hipEventCreate(&e); ctx->events.push_back(e); }
+        while (next >= ctx->events.size()) { hipEvent_t e; (void) hipEventCreate(&e); ctx->events.push_back(e); }
         return ctx->events[next++];
     }
 };
@@ -477,7 +478,9 @@ static void sum_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, float 
     for (auto &p : v) { float t = 0; if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) *ms += t; }
 }
 
-static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st, const PassParams &pp) {
+// t0 / t1: events that take the kernel's own start / end timestamps (hipExtLaunchKernelGGL: no extra packets in the queue,
+// unlike hipEventRecord, which cost 2 % of a bench step at three records per iteration), or nullptr
+static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st, const PassParams &pp, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
     const uint32_t grid = (pp.n_regions * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
     // Lane replacement pays when rays are long (tree in HBM/L2: trace -35 % on the 70 k-triangle scene) and costs when they
     // are short (LDS-resident cbox: +50 %): on by default for modes 1 and 2 only.  MSK_TRACE_REFILL=0 turns it off.
@@ -486,19 +489,19 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
     const int refill = (sc->trace_mode == 3) ? 0 : refill_env >= 0 ? refill_env : (sc->trace_mode == 0 ? 0 : 16);
     const size_t lds = sc->trace_lds_bytes + (size_t) env_u32("MSK_TRACE_PAD_LDS_KB", 0) * 1024;      // occupancy experiments only
     if (refill > 0) {        // k_trace_r
-        if (sc->trace_mode == 0) hipLaunchKernelGGL(k_trace_r<0>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp, refill, max_inner);
-        else if (sc->trace_mode == 1) hipLaunchKernelGGL(k_trace_r<1>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp, refill, max_inner);
-        else hipLaunchKernelGGL(k_trace_r<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp, refill, max_inner);
+        if (sc->trace_mode == 0) hipExtLaunchKernelGGL(k_trace_r<0>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
+        else if (sc->trace_mode == 1) hipExtLaunchKernelGGL(k_trace_r<1>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
+        else hipExtLaunchKernelGGL(k_trace_r<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         return;
     }
     if (sc->trace_mode == 0) {     // pp.trace_split waves per region (LDS-resident scene: no stack overflow array to size).
         // Measured: 2 waves per region -6 % trace on the cbox (twice the waves to balance the tail of a launch), 4 the same.
         const uint32_t grid_s = (pp.n_regions * pp.trace_split * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
-        hipLaunchKernelGGL(k_trace<0>, dim3(grid_s), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp);
+        hipExtLaunchKernelGGL(k_trace<0>, dim3(grid_s), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
     }
-    else if (sc->trace_mode == 1) hipLaunchKernelGGL(k_trace<1>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp);
-    else if (sc->trace_mode == 2) hipLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp);
-    else hipLaunchKernelGGL(k_trace<3>, dim3(grid), dim3(MSK_BLOCK), lds, stream, sc->dev, st, pp);
+    else if (sc->trace_mode == 1) hipExtLaunchKernelGGL(k_trace<1>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
+    else if (sc->trace_mode == 2) hipExtLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
+    else hipExtLaunchKernelGGL(k_trace<3>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
 }
 
 // Renders the samples of `pix` (pass pixel table, host) into records; leaves records on device.
@@ -552,35 +555,51 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     static const size_t shade_pad_lds = (size_t) env_u32("MSK_SHADE_PAD_LDS_KB", 0) * 1024;   // occupancy experiments only
     const bool timing = stats != nullptr;
     uint32_t it = 0;
-    const size_t ev_mark = ev.next;        // the group's events are read at its sync point and reused by the next group
-    for (;;) {
+    // Two alternating sets of events: a group's timestamps are read (hipEventElapsedTime is a host call of a few microseconds,
+    // 32 of them per group) after the NEXT group has been queued, not while the GPU waits for work.
+    const size_t ev_mark = ev.next;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pend_shade, pend_trace;
+    auto read_pending = [&]() {
+        if (!timing) return;
+        sum_events(pend_shade, &stats->ms_shade); sum_events(pend_trace, &stats->ms_trace);
+        stats->n_shade_launches += (uint32_t) pend_shade.size(); stats->n_trace_launches += (uint32_t) pend_trace.size();
+        pend_shade.clear(); pend_trace.clear();
+    };
+    uint32_t parity = 0;
+    // A timed dispatch costs ~6 us more than an untimed one (completion signal + timestamps): 2 % of a bench step when every
+    // launch is timed.  MSK_TIMING_EVERY=n times the launches of every n-th sync group only (rotating from render to render so
+    // that repeated renders cover all groups); msk_stats::ms_trace / ms_shade / n_*_launches then describe that sample.
+    const uint32_t every = std::max(1u, env_u32("MSK_TIMING_EVERY", 1));
+    static uint32_t timing_phase = 0;
+    const uint32_t phase = timing_phase++;
+    for (uint32_t gi = 0;; ++gi) {
+        ev.next = ev_mark + (size_t) parity * 4 * group;
+        const bool timed = timing && (gi + phase) % every == 0;
         for (uint32_t g = 0; g < group; ++g, ++it) {
-            hipEvent_t a = nullptr, b = nullptr, c = nullptr;
-            if (timing) { a = ev.get(); b = ev.get(); c = ev.get(); (void) hipEventRecord(a, stream); }
-#define MSK_SHADE(L, D) hipLaunchKernelGGL((k_shade_gen<L, D>), dim3(grid), dim3(MSK_BLOCK), sc->shade_lds_bytes + shade_pad_lds, stream, sc->dev, sb.st, pp)
+            hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
+            if (timed) { a = ev.get(); b = ev.get(); c = ev.get(); d = ev.get(); }
+#define MSK_SHADE(L, D) hipExtLaunchKernelGGL((k_shade_gen<L, D>), dim3(grid), dim3(MSK_BLOCK), sc->shade_lds_bytes + shade_pad_lds, stream, a, b, 0, sc->dev, sb.st, pp)
             if (sc->lds_tables) { if (diffuse_only) MSK_SHADE(true, true); else MSK_SHADE(true, false); }
             else { if (diffuse_only) MSK_SHADE(false, true); else MSK_SHADE(false, false); }
 #undef MSK_SHADE
-            if (timing) (void) hipEventRecord(b, stream);
-            launch_trace(sc, stream, sb.st, pp);
+            launch_trace(sc, stream, sb.st, pp, c, d);
             if (aov && aov->n_groups) hipLaunchKernelGGL(k_aov_primary, dim3(grid), dim3(MSK_BLOCK), 0, stream, sc->dev, sb.st, pp, *aov);
-            if (timing) { (void) hipEventRecord(c, stream); ev_shade.push_back({a, b}); ev_trace.push_back({b, c}); }
+            if (timed) { ev_shade.push_back({a, b}); ev_trace.push_back({c, d}); }
         }
+        read_pending();                     // the previous group's, while this one runs
         HIP_TRY(ctx, hipMemsetAsync(sb.ctrl.p, 0, sizeof(Ctrl), stream));
         hipLaunchKernelGGL(k_reduce_ctl, dim3(std::min(64u, (n_regions + MSK_BLOCK - 1) / MSK_BLOCK)), dim3(MSK_BLOCK), 0, stream,
                            sb.counts.as<RegionCtl>(), n_regions, sb.ctrl.as<Ctrl>());
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctrl, sb.ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
         HIP_TRY(ctx, hipStreamSynchronize(stream));
-        if (timing) {
-            sum_events(ev_shade, &stats->ms_shade); sum_events(ev_trace, &stats->ms_trace);
-            stats->n_shade_launches += (uint32_t) ev_shade.size(); stats->n_trace_launches += (uint32_t) ev_trace.size();
-            ev_shade.clear(); ev_trace.clear(); ev.next = ev_mark;
-        }
+        pend_shade.swap(ev_shade); pend_trace.swap(ev_trace); ev_shade.clear(); ev_trace.clear(); parity ^= 1u;
         const Ctrl &h = *ctx->h_ctrl;
         if (h.remaining == 0 && h.live == 0) break;
         if (it > 100000000u) return fail(ctx, MSK_ERR_HIP, "wavefront loop did not terminate");
     }
+    read_pending();
+    ev.next = ev_mark;                              // every timestamp has been read: the events are free again
     if (stats) {
         stats->samples += ctx->h_ctrl->samples_done;
         stats->segments += ctx->h_ctrl->segments;
