@@ -111,12 +111,8 @@ def main():
         # warm-up step decides speed-proportional contiguous sample ranges; the per-GPU average stays args.spp.
         # (kernel time of the wavefront launches that carried events — the same sync groups on every rank — not the step's
         # wall or device total, which on a first step also holds the one-off uploads of the render plan)
-        mine = torch.tensor([warm[-1].ms_trace + warm[-1].ms_shade], dtype=torch.float64, device="cuda")
-        gathered = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        times = [float(x.item()) for x in gathered]
-        if min(times) > 0 and max(times) / min(times) > 1.04:
-            shares = mg.balanced_shares(spp_total, times)
+        shares, times = mg.speed_proportional_shares(dist, warm[-1].ms_trace + warm[-1].ms_shade, spp_total, device="cuda")
+        if shares is not None:
             prm = mg.shard_params(abi, spp_total, rank, world, mode="range", shares=shares, seed=0)
             step()                       # untimed: the new shares' plan and record buffers are set up here
             balance = {"equal_split_kernel_ms": [round(t, 2) for t in times], "spp_shares": shares}

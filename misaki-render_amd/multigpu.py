@@ -64,3 +64,18 @@ def weak_scaling_spp(spp_per_gpu, world):
     """Weak scaling: per-GPU work constant.  Each rank owns 1/world of the tiles, so the whole job
     renders spp_per_gpu * world samples per pixel."""
     return spp_per_gpu * world
+
+
+def speed_proportional_shares(dist, kernel_ms, spp_total, device="cpu", threshold=1.04):
+    """One all_gather of this rank's kernel time for an equal split -> the same decision on every rank: None (keep the
+    equal split: the ranks are within `threshold` of each other, or a time is missing) or the speed-proportional shares
+    plus the gathered times."""
+    import torch
+    world = dist.get_world_size()
+    mine = torch.tensor([float(kernel_ms)], dtype=torch.float64, device=device)
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    times = [float(x.item()) for x in gathered]
+    if min(times) <= 0 or max(times) / min(times) <= threshold or spp_total < world:
+        return None, times
+    return balanced_shares(spp_total, times), times

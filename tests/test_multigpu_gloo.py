@@ -29,11 +29,10 @@ def _worker(rank, world, port, out_path, mode="tiles"):
     if mode == "range":
         # the speed-proportional split bench.py switches to when the GPUs of a node differ: every rank derives the same
         # shares from the gathered step times, then renders its contiguous range of sample indices
-        t = torch.tensor([30.0 if rank == 0 else 90.0], dtype=torch.float64)
-        ts = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(ts, t)
-        shares = mg.balanced_shares(spp_total, [float(x.item()) for x in ts])
-        assert shares == [3, 1]
+        none, times = mg.speed_proportional_shares(dist, 50.0 if rank == 0 else 51.0, spp_total)        # within 4 %: keep the equal split
+        assert none is None and times == [50.0, 51.0]
+        shares, times = mg.speed_proportional_shares(dist, 30.0 if rank == 0 else 90.0, spp_total)
+        assert shares == [3, 1] and times == [30.0, 90.0]
         prm = mg.shard_params(abi, spp_total, rank, world, mode="range", shares=shares, seed=5)
         assert (prm.sample_first, prm.sample_stride, prm.spp) == ((0, 1, 3) if rank == 0 else (3, 1, 4))
     else:
