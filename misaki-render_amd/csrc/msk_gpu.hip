@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace msk;
@@ -27,8 +28,9 @@ struct msk_ctx {
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop;
     std::string last_error;
-    Ctrl *h_ctrl = nullptr;            // pinned
-    std::vector<hipEvent_t> events;
+    hipStream_t stream2 = nullptr;     // the second half of the pool runs here (run_wavefront)
+    Ctrl *h_ctrl = nullptr;            // pinned, [2]: one per half
+    std::vector<hipEvent_t> events, events2;
 };
 
 static int fail(msk_ctx *ctx, int code, const char *fmt, ...) {
@@ -90,7 +92,8 @@ extern "C" int msk_gpu_init(const int *device_ids, int n, msk_ctx **out_ctx) {
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, ctx->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc((void **) &ctx->h_ctrl, sizeof(Ctrl), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **) &ctx->h_ctrl, 2 * sizeof(Ctrl), hipHostMallocDefault);
     if (e != hipSuccess) {
         int rc = fail(nullptr, MSK_ERR_HIP, "msk_gpu_init: %s", hipGetErrorString(e));
         msk_gpu_shutdown(ctx);             // releases whichever of stream / pinned block exist
@@ -111,6 +114,8 @@ extern "C" void msk_gpu_shutdown(msk_ctx *ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
     for (auto ev : ctx->events) (void) hipEventDestroy(ev);
+    for (auto ev : ctx->events2) (void) hipEventDestroy(ev);
+    if (ctx->stream2) (void) hipStreamDestroy(ctx->stream2);
     if (ctx->h_ctrl) (void) hipHostFree(ctx->h_ctrl);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -422,7 +427,7 @@ static std::vector<HostBlock> spiral_blocks(int w, int h, int bs, int *nbx, int 
 // wavefront driver
 // ------------------------------------------------------------------------------------------
 struct StateBufs {
-    DevBuf id, wl, thr, res, ray_o, ray_d, sh, contrib, hit, aux, counts, ctrl, stack_ovf;
+    DevBuf id, wl, thr, res, ray_o, ray_d, sh, contrib, hit, aux, counts, ctrl, stack_ovf, stack_ovf2;
     PathState st;
     hipError_t alloc(size_t n, uint32_t n_regions) {
         hipError_t e;
@@ -431,7 +436,7 @@ struct StateBufs {
         A_(aux, 8)
 #undef A_
         if ((e = counts.reserve((size_t) n_regions * sizeof(RegionCtl))) != hipSuccess) return e;
-        if ((e = ctrl.reserve(sizeof(Ctrl))) != hipSuccess) return e;
+        if ((e = ctrl.reserve(2 * sizeof(Ctrl))) != hipSuccess) return e;
         st.id = id.as<uint4>(); st.wl = wl.as<float4>(); st.thr = thr.as<float4>(); st.res = res.as<float4>();
         st.ray_o = ray_o.as<float4>(); st.ray_d = ray_d.as<float4>(); st.sh = sh.as<float4>();
         st.contrib = contrib.as<float4>(); st.hit = hit.as<float4>(); st.aux = aux.as<float2>();
@@ -465,10 +470,11 @@ static uint32_t env_u32(const char *name, uint32_t def) {
 }
 
 struct EventPool {
-    msk_ctx *ctx; size_t next = 0;
+    msk_ctx *ctx; size_t next = 0; std::vector<hipEvent_t> *pool = nullptr;       // pool: ctx->events unless told otherwise
     hipEvent_t get() {
-        while (next >= ctx->events.size()) { hipEvent_t e; (void) hipEventCreate(&e); ctx->events.push_back(e); }
-        return ctx->events[next++];
+        std::vector<hipEvent_t> &v = pool ? *pool : ctx->events;
+        while (next >= v.size()) { hipEvent_t e; (void) hipEventCreate(&e); v.push_back(e); }
+        return v[next++];
     }
 };
 
@@ -481,7 +487,7 @@ static void sum_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, float 
 // t0 / t1: events that take the kernel's own start / end timestamps (hipExtLaunchKernelGGL: no extra packets in the queue,
 // unlike hipEventRecord, which cost 2 % of a bench step at three records per iteration), or nullptr
 static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st, const PassParams &pp, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
-    const uint32_t grid = (pp.n_regions * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
+    const uint32_t grid = (pp.region_count * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
     // Lane replacement pays when rays are long (tree in HBM/L2: trace -35 % on the 70 k-triangle scene) and costs when they
     // are short (LDS-resident cbox: +50 %): on by default for modes 1 and 2 only.  MSK_TRACE_REFILL=0 turns it off.
     const int refill_env = getenv("MSK_TRACE_REFILL") ? atoi(getenv("MSK_TRACE_REFILL")) : -1;
@@ -496,7 +502,7 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
     }
     if (sc->trace_mode == 0) {     // pp.trace_split waves per region (LDS-resident scene: no stack overflow array to size).
         // Measured: 2 waves per region -6 % trace on the cbox (twice the waves to balance the tail of a launch), 4 the same.
-        const uint32_t grid_s = (pp.n_regions * pp.trace_split * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
+        const uint32_t grid_s = (pp.region_count * pp.trace_split * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
         hipExtLaunchKernelGGL(k_trace<0>, dim3(grid_s), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
     }
     else if (sc->trace_mode == 1) hipExtLaunchKernelGGL(k_trace<1>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
@@ -536,78 +542,138 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
         }
     }
     if (wsp) HIP_TRY(ctx, hipMemcpyAsync(sb.counts.p, wsp->counts_init.p, (size_t) n_regions * sizeof(RegionCtl), hipMemcpyDeviceToDevice, stream));
-    PassParams pp;
-    pp.seed = prm->seed; pp.spp_owned = spp_owned; pp.sample_first = prm->sample_first;
-    pp.sample_stride = prm->sample_stride ? prm->sample_stride : 1;
-    pp.rr_depth = prm->rr_depth; pp.max_depth = prm->max_depth; pp.hide_emitters = prm->hide_emitters;
-    pp.pix_table = d_pix; pp.rec_a = rec_a; pp.rec_b = rec_b;
-    pp.region_size = region_size; pp.n_regions = n_regions; pp.regions = sb.counts.as<RegionCtl>();
-    pp.trace_split = sc->trace_mode == 0 ? std::max(1u, env_u32("MSK_TRACE_SPLIT", 2)) : 1u;
-    pp.aov_rgb = aov_rgb;
+    PassParams pp0;
+    pp0.seed = prm->seed; pp0.spp_owned = spp_owned; pp0.sample_first = prm->sample_first;
+    pp0.sample_stride = prm->sample_stride ? prm->sample_stride : 1;
+    pp0.rr_depth = prm->rr_depth; pp0.max_depth = prm->max_depth; pp0.hide_emitters = prm->hide_emitters;
+    pp0.pix_table = d_pix; pp0.rec_a = rec_a; pp0.rec_b = rec_b;
+    pp0.region_size = region_size; pp0.n_regions = n_regions; pp0.regions = sb.counts.as<RegionCtl>();
+    pp0.region_first = 0; pp0.region_count = n_regions;
+    pp0.trace_split = sc->trace_mode == 0 ? std::max(1u, env_u32("MSK_TRACE_SPLIT", 2)) : 1u;
+    pp0.aov_rgb = aov_rgb;
+    pp0.stack_ovf = nullptr;
     const bool diffuse_only = sc->all_diffuse && !aov_rgb;      // the AOV RGB record lives in the general shading variant
-    const uint32_t grid = (n_regions * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
-    pp.stack_ovf = nullptr;
-    if (sc->dev.stack_total > sc->dev.stack_entries) {          // LaneStack overflow: one word per lane per extra entry
-        HIP_TRY(ctx, sb.stack_ovf.reserve((size_t) (sc->dev.stack_total - sc->dev.stack_entries) * grid * MSK_BLOCK * 4));
-        pp.stack_ovf = sb.stack_ovf.as<uint32_t>();
-    }
     const uint32_t group = env_u32("MSK_SYNC_GROUP", 8);
     static const size_t shade_pad_lds = (size_t) env_u32("MSK_SHADE_PAD_LDS_KB", 0) * 1024;   // occupancy experiments only
     const bool timing = stats != nullptr;
-    uint32_t it = 0;
-    // Two alternating sets of events: a group's timestamps are read (hipEventElapsedTime is a host call of a few microseconds,
-    // 32 of them per group) after the NEXT group has been queued, not while the GPU waits for work.
-    const size_t ev_mark = ev.next;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pend_shade, pend_trace;
-    auto read_pending = [&]() {
-        if (!timing) return;
-        sum_events(pend_shade, &stats->ms_shade); sum_events(pend_trace, &stats->ms_trace);
-        stats->n_shade_launches += (uint32_t) pend_shade.size(); stats->n_trace_launches += (uint32_t) pend_trace.size();
-        pend_shade.clear(); pend_trace.clear();
-    };
-    uint32_t parity = 0;
     // A timed dispatch costs ~6 us more than an untimed one (completion signal + timestamps): 2 % of a bench step when every
     // launch is timed.  MSK_TIMING_EVERY=n times the launches of every n-th sync group only (rotating from render to render so
     // that repeated renders cover all groups); msk_stats::ms_trace / ms_shade / n_*_launches then describe that sample.
     const uint32_t every = std::max(1u, env_u32("MSK_TIMING_EVERY", 1));
     static uint32_t timing_phase = 0;
     const uint32_t phase = timing_phase++;
-    for (uint32_t gi = 0;; ++gi) {
-        ev.next = ev_mark + (size_t) parity * 4 * group;
-        const bool timed = timing && (gi + phase) % every == 0;
-        for (uint32_t g = 0; g < group; ++g, ++it) {
-            hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
-            if (timed) { a = ev.get(); b = ev.get(); c = ev.get(); d = ev.get(); }
-#define MSK_SHADE(L, D) hipExtLaunchKernelGGL((k_shade_gen<L, D>), dim3(grid), dim3(MSK_BLOCK), sc->shade_lds_bytes + shade_pad_lds, stream, a, b, 0, sc->dev, sb.st, pp)
-            if (sc->lds_tables) { if (diffuse_only) MSK_SHADE(true, true); else MSK_SHADE(true, false); }
-            else { if (diffuse_only) MSK_SHADE(false, true); else MSK_SHADE(false, false); }
+
+    // The wavefront loop over the regions [first, first + count) on one stream.  The pool's two halves run this at the same
+    // time on two streams (two host threads): regions are independent — each owns its slots, its share of the samples and
+    // its counters — and a shading launch of one half fills the gaps of a traversal launch of the other (and the other way
+    // round), which one launch at a time leaves open at its start, its end and wherever its waves wait.  Measured with two
+    // concurrent half-size renders before this was built: 49.3 against 55.0 ms for the bench step.
+    struct Half { uint32_t first, count; hipStream_t stream; Ctrl *d_ctrl, *h_ctrl; EventPool ev; uint32_t *stack_ovf;
+                  msk_stats st; int rc; unsigned long long expected; };
+    auto run_range = [&](Half &hf) -> int {
+        (void) hipSetDevice(ctx->device);               // the current device is per host thread
+        PassParams pp = pp0;
+        pp.region_first = hf.first; pp.region_count = hf.count; pp.stack_ovf = hf.stack_ovf;
+        hipStream_t stream_h = hf.stream;
+        EventPool &ev_h = hf.ev;
+        msk_stats *st = &hf.st;
+        const uint32_t grid = (hf.count * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
+        uint32_t it = 0;
+        // Two alternating sets of events: a group's timestamps are read (hipEventElapsedTime is a host call of a few
+        // microseconds, 32 of them per group) after the NEXT group has been queued, not while the GPU waits for work.
+        const size_t ev_mark = ev_h.next;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> cur_shade, cur_trace, pend_shade, pend_trace;
+        auto read_pending = [&]() {
+            if (!timing) return;
+            sum_events(pend_shade, &st->ms_shade); sum_events(pend_trace, &st->ms_trace);
+            st->n_shade_launches += (uint32_t) pend_shade.size(); st->n_trace_launches += (uint32_t) pend_trace.size();
+            pend_shade.clear(); pend_trace.clear();
+        };
+        uint32_t parity = 0;
+        for (uint32_t gi = 0;; ++gi) {
+            ev_h.next = ev_mark + (size_t) parity * 4 * group;
+            const bool timed = timing && (gi + phase) % every == 0;
+            for (uint32_t g = 0; g < group; ++g, ++it) {
+                hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
+                if (timed) { a = ev_h.get(); b = ev_h.get(); c = ev_h.get(); d = ev_h.get(); }
+#define MSK_SHADE(L, D) hipExtLaunchKernelGGL((k_shade_gen<L, D>), dim3(grid), dim3(MSK_BLOCK), sc->shade_lds_bytes + shade_pad_lds, stream_h, a, b, 0, sc->dev, sb.st, pp)
+                if (sc->lds_tables) { if (diffuse_only) MSK_SHADE(true, true); else MSK_SHADE(true, false); }
+                else { if (diffuse_only) MSK_SHADE(false, true); else MSK_SHADE(false, false); }
 #undef MSK_SHADE
-            launch_trace(sc, stream, sb.st, pp, c, d);
-            if (aov && aov->n_groups) hipLaunchKernelGGL(k_aov_primary, dim3(grid), dim3(MSK_BLOCK), 0, stream, sc->dev, sb.st, pp, *aov);
-            if (timed) { ev_shade.push_back({a, b}); ev_trace.push_back({c, d}); }
+                launch_trace(sc, stream_h, sb.st, pp, c, d);
+                if (aov && aov->n_groups) hipLaunchKernelGGL(k_aov_primary, dim3(grid), dim3(MSK_BLOCK), 0, stream_h, sc->dev, sb.st, pp, *aov);
+                if (timed) { cur_shade.push_back({a, b}); cur_trace.push_back({c, d}); }
+            }
+            read_pending();                     // the previous group's, while this one runs
+            HIP_TRY(ctx, hipMemsetAsync(hf.d_ctrl, 0, sizeof(Ctrl), stream_h));
+            hipLaunchKernelGGL(k_reduce_ctl, dim3(std::min(64u, (hf.count + MSK_BLOCK - 1) / MSK_BLOCK)), dim3(MSK_BLOCK), 0, stream_h,
+                               sb.counts.as<RegionCtl>() + hf.first, hf.count, hf.d_ctrl);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipMemcpyAsync(hf.h_ctrl, hf.d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream_h));
+            HIP_TRY(ctx, hipStreamSynchronize(stream_h));
+            pend_shade.swap(cur_shade); pend_trace.swap(cur_trace); cur_shade.clear(); cur_trace.clear(); parity ^= 1u;
+            const Ctrl &h = *hf.h_ctrl;
+            if (h.remaining == 0 && h.live == 0) break;
+            if (it > 100000000u) return fail(ctx, MSK_ERR_HIP, "wavefront loop did not terminate");
         }
-        read_pending();                     // the previous group's, while this one runs
-        HIP_TRY(ctx, hipMemsetAsync(sb.ctrl.p, 0, sizeof(Ctrl), stream));
-        hipLaunchKernelGGL(k_reduce_ctl, dim3(std::min(64u, (n_regions + MSK_BLOCK - 1) / MSK_BLOCK)), dim3(MSK_BLOCK), 0, stream,
-                           sb.counts.as<RegionCtl>(), n_regions, sb.ctrl.as<Ctrl>());
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctrl, sb.ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(ctx, hipStreamSynchronize(stream));
-        pend_shade.swap(ev_shade); pend_trace.swap(ev_trace); ev_shade.clear(); ev_trace.clear(); parity ^= 1u;
-        const Ctrl &h = *ctx->h_ctrl;
-        if (h.remaining == 0 && h.live == 0) break;
-        if (it > 100000000u) return fail(ctx, MSK_ERR_HIP, "wavefront loop did not terminate");
+        read_pending();
+        ev_h.next = ev_mark;                            // every timestamp has been read: the events are free again
+        st->samples = hf.h_ctrl->samples_done; st->segments = hf.h_ctrl->segments; st->shadow_rays = hf.h_ctrl->shadow_rays;
+        st->iterations = it;
+        if (hf.h_ctrl->samples_done != hf.expected)
+            return fail(ctx, MSK_ERR_HIP, "internal error: %llu of %llu samples finished", hf.h_ctrl->samples_done, hf.expected);
+        return MSK_OK;
+    };
+
+    // samples the regions [first, first + count) own (the same static partition as the init above)
+    auto share = [&](uint32_t first, uint32_t count) {
+        const unsigned long long n_chunks = (total + 63) / 64;
+        unsigned long long sum = 0;
+        for (uint32_t r = first; r < first + count; ++r) {
+            const unsigned long long mine = n_chunks > r ? (n_chunks - r + n_regions - 1) / n_regions : 0;
+            unsigned long long n = mine * 64;
+            if (mine && (mine - 1) * n_regions + r == n_chunks - 1) n -= n_chunks * 64 - total;
+            sum += n;
+        }
+        return sum;
+    };
+    const bool two = env_u32("MSK_STREAMS", 2) >= 2 && n_regions >= 1024 && stream == ctx->stream;
+    const uint32_t n0 = two ? n_regions / 2 : n_regions;
+    const uint32_t ovf_words = sc->dev.stack_total > sc->dev.stack_entries ? sc->dev.stack_total - sc->dev.stack_entries : 0;
+    Half h0{0, n0, stream, sb.ctrl.as<Ctrl>(), ctx->h_ctrl, EventPool{ctx, ev.next, ev.pool}, nullptr, msk_stats{}, MSK_OK, share(0, n0)};
+    Half h1{n0, n_regions - n0, ctx->stream2, sb.ctrl.as<Ctrl>() + 1, ctx->h_ctrl + 1, EventPool{ctx, 0, &ctx->events2}, nullptr, msk_stats{},
+            MSK_OK, two ? share(n0, n_regions - n0) : 0ull};
+    if (ovf_words) {                                    // LaneStack overflow: one word per lane per extra entry, per launch
+        const size_t lanes0 = (size_t) ((h0.count * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK) * MSK_BLOCK;
+        HIP_TRY(ctx, sb.stack_ovf.reserve((size_t) ovf_words * lanes0 * 4));
+        h0.stack_ovf = sb.stack_ovf.as<uint32_t>();
+        if (two) {
+            const size_t lanes1 = (size_t) ((h1.count * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK) * MSK_BLOCK;
+            HIP_TRY(ctx, sb.stack_ovf2.reserve((size_t) ovf_words * lanes1 * 4));
+            h1.stack_ovf = sb.stack_ovf2.as<uint32_t>();
+        }
     }
-    read_pending();
-    ev.next = ev_mark;                              // every timestamp has been read: the events are free again
+    std::memset(&h0.st, 0, sizeof h0.st); std::memset(&h1.st, 0, sizeof h1.st);
+    if (two) {
+        HIP_TRY(ctx, hipStreamSynchronize(stream));     // the regions' initial records (queued above) before stream2 reads them
+        std::thread other([&]() { h1.rc = run_range(h1); });
+        h0.rc = run_range(h0);
+        other.join();
+    } else {
+        h0.rc = run_range(h0);
+    }
+    if (h0.rc) return h0.rc;
+    if (two && h1.rc) return h1.rc;
     if (stats) {
-        stats->samples += ctx->h_ctrl->samples_done;
-        stats->segments += ctx->h_ctrl->segments;
-        stats->shadow_rays += ctx->h_ctrl->shadow_rays;
-        stats->iterations += it;
+        for (const Half *hf : {&h0, &h1}) {
+            if (hf == &h1 && !two) break;
+            stats->samples += hf->st.samples; stats->segments += hf->st.segments; stats->shadow_rays += hf->st.shadow_rays;
+            stats->iterations += hf->st.iterations;
+            stats->ms_trace += hf->st.ms_trace; stats->ms_shade += hf->st.ms_shade;
+            stats->n_trace_launches += hf->st.n_trace_launches; stats->n_shade_launches += hf->st.n_shade_launches;
+        }
     }
-    if (ctx->h_ctrl->samples_done != total)
-        return fail(ctx, MSK_ERR_HIP, "internal error: %llu of %llu samples finished", ctx->h_ctrl->samples_done, total);
+    (void) ev_trace; (void) ev_shade;
     return MSK_OK;
 }
 

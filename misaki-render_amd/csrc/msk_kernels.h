@@ -107,7 +107,8 @@ struct PassParams {
     const uint4 *pix_table;       // pass pixel j -> {film index y*W+x, rec0 lo, rec0 hi, pixels in its block}
     float4 *rec_a;                // per sample {X,Y,Z,pos.x}; record of (j, si) = rec0(j) + si * npix(j):
     float *rec_b;                 // per sample pos.y           i.e. [block][sample][pixel], pixel fastest
-    uint32_t region_size, n_regions;
+    uint32_t region_size, n_regions;      // n_regions: all regions of the pass (the samples' static partition is over all of them)
+    uint32_t region_first, region_count;  // the regions this launch covers (the pool's halves run on two streams)
     uint32_t trace_split;         // waves per region in k_trace (each takes every trace_split-th chunk); shading is one wave per region
     RegionCtl *regions;
     uint32_t *stack_ovf;          // traversal-stack overflow (LaneStack), (stack_total - stack_entries) x lanes words, or nullptr
@@ -376,9 +377,10 @@ MSK_DEV void trace_chunks(const DeviceScene &sc, const PathState &st, const Pass
     const LaneStack<MSK_OVF(MODE)> stack{stack_base + threadIdx.x, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
                                      (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK};
     const uint32_t gwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
-    const uint32_t wave = gwave / pp.trace_split, sub = gwave % pp.trace_split;      // region, and which of its chunks
+    const uint32_t lwave = gwave / pp.trace_split, sub = gwave % pp.trace_split;     // region of this launch, and which of its chunks
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
-    if (wave >= pp.n_regions) return;
+    if (lwave >= pp.region_count) return;
+    const uint32_t wave = pp.region_first + lwave;
     const uint32_t n = pp.regions[wave].count;
     const size_t base = (size_t) wave * pp.region_size;
     for (uint32_t c = sub * MSK_WAVE + lane; c < n; c += MSK_WAVE * pp.trace_split) {
@@ -502,9 +504,10 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
     TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE, MODE == 3);
     const LaneStack<MSK_OVF(MODE)> stack{stack_base + threadIdx.x, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
                                      (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK};
-    const uint32_t wave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
+    const uint32_t lwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
-    if (wave >= pp.n_regions) return;
+    if (lwave >= pp.region_count) return;
+    const uint32_t wave = pp.region_first + lwave;
     const uint32_t n = pp.regions[wave].count;
     const size_t base = (size_t) wave * pp.region_size;
     uint32_t next = 0;                       // wave-uniform: first slot nobody has taken yet
@@ -905,7 +908,8 @@ __global__ void __launch_bounds__(MSK_BLOCK)
 k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
     extern __shared__ float4 lds_dyn[];
     const SceneTables tb = stage_tables<LDS_TABLES>(sc, lds_dyn);
-    const uint32_t wave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
+    const uint32_t lwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
+    const uint32_t wave = pp.region_first + lwave;
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
     // this wave's done-queue: after the staged tables, 3 x MSK_DONE_Q float4 per wave
     DoneQueue dq;
@@ -914,7 +918,7 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
         dq.wl = qbase; dq.res = qbase + MSK_DONE_Q; dq.id = (uint4 *) (qbase + 2 * MSK_DONE_Q);
     }
     uint32_t n_queued = 0;
-    if (wave >= pp.n_regions) return;
+    if (lwave >= pp.region_count) return;
     RegionCtl rc = pp.regions[wave];
     const uint32_t n_in = rc.count;
     const size_t base = (size_t) wave * pp.region_size;
@@ -1209,9 +1213,10 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
 // has just been traced (depth 1) and writes their record groups.  A miss writes zeros.
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_aov_primary(DeviceScene sc, PathState st, PassParams pp, AovParams ap) {
-    const uint32_t wave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
+    const uint32_t lwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
-    if (wave >= pp.n_regions) return;
+    if (lwave >= pp.region_count) return;
+    const uint32_t wave = pp.region_first + lwave;
     const uint32_t n_in = pp.regions[wave].count;
     const size_t base = (size_t) wave * pp.region_size;
     for (uint32_t c = lane; c < n_in; c += MSK_WAVE) {
