@@ -155,6 +155,8 @@ def main():
         bytes_per_launch = b / max(iters, 1)
         avg_launch_ms = ms / max(nl, 1)                        # over the timed launches (nl of iters)
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        ms_wavefront = sum(s.ms_total - s.ms_resolve for s in stats)
+        pair_achieved = (bytes_trace + bytes_shade) / (ms_wavefront * 1e-3) / 1e9 if ms_wavefront > 0 else 0.0
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(prof):
@@ -175,6 +177,10 @@ def main():
                        "segments_per_sample": round(seg / max(smp, 1), 3)},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         # the pool's halves run on two streams, so a launch of this kernel shares the GPU with a launch of the
+                         # other one for most of its duration: its wall duration is what `achieved` divides by.
+                         # pair_*: both kernels' algorithmic bytes over the wall time of the wavefront phase they share.
+                         "pair_achieved": round(pair_achieved, 1), "pair_frac": round(pair_achieved / HBM_PEAK_GBS, 4),
                          "bytes_per_launch": round(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
                          "launches": iters, "timed_launches": nl, "timed": "launches of every %s-th sync group" % os.environ.get("MSK_TIMING_EVERY", "1"),
                          "ms_trace_timed": round(ms_trace, 2), "ms_shade_timed": round(ms_shade, 2),
