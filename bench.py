@@ -157,14 +157,32 @@ def main():
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         ms_wavefront = sum(s.ms_total - s.ms_resolve for s in stats)
         pair_achieved = (bytes_trace + bytes_shade) / (ms_wavefront * 1e-3) / 1e9 if ms_wavefront > 0 else 0.0
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(prof):
+        def pmc_traffic(prefix):
+            prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
             try:
                 pm = json.load(open(prof))
-                traffic = next((round(v["hbm_bytes_per_launch"]) for k, v in pm.items() if k.startswith(name)), None)
+                return next((v["hbm_bytes_per_launch"] for k, v in pm.items() if k.startswith(prefix)), None)
             except Exception:
-                traffic = None
+                return None
+        n_streams = int(os.environ.get("MSK_STREAMS", "4"))
+        per_kernel = {"kernel": name, "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+                      "bytes_per_launch": round(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
+                      "avg_launch_ms_shade": round(ms_shade / max(n_shade, 1), 4), "avg_launch_ms_trace": round(ms_trace / max(n_trace, 1), 4)}
+        if n_streams > 1:
+            # The wavefront loop runs on several streams at once: at any moment a few launches of BOTH kernels
+            # share the GPU, a launch's wall duration says how long it shared, not how fast it could go, and the unit that
+            # has a bandwidth is the phase: both kernels' algorithmic bytes of one iteration over the wall time an iteration
+            # takes.  The per-launch figures (what a rocprofv3 kernel trace of this command shows) stay under `per_kernel`.
+            name = "k_shade_gen || k_trace (%d streams)" % n_streams
+            achieved = pair_achieved
+            per_iter = max(iters // n_streams, 1)            # iterations of the whole pool (every stream launches its own)
+            bytes_per_launch = (bytes_trace + bytes_shade) / per_iter
+            avg_launch_ms = ms_wavefront / per_iter
+            ts, tt = pmc_traffic("k_shade_gen"), pmc_traffic("k_trace")
+            traffic = round((ts + tt) * n_streams) if ts is not None and tt is not None else None   # PMC run = the same 4-stream launches
+        else:
+            t = pmc_traffic(name)
+            traffic = round(t) if t is not None else None
         out = {
             "metric": "Msamples/s (paths x spp) on cbox@512spp", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -177,12 +195,8 @@ def main():
                        "segments_per_sample": round(seg / max(smp, 1), 3)},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         # the pool's halves run on two streams, so a launch of this kernel shares the GPU with a launch of the
-                         # other one for most of its duration: its wall duration is what `achieved` divides by.
-                         # pair_*: both kernels' algorithmic bytes over the wall time of the wavefront phase they share.
-                         "pair_achieved": round(pair_achieved, 1), "pair_frac": round(pair_achieved / HBM_PEAK_GBS, 4),
                          "bytes_per_launch": round(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
-                         "launches": iters, "timed_launches": nl, "timed": "launches of every %s-th sync group" % os.environ.get("MSK_TIMING_EVERY", "1"),
+                         "per_kernel": per_kernel, "launches": iters, "timed_launches": nl, "timed": "launches of every %s-th sync group" % os.environ.get("MSK_TIMING_EVERY", "1"),
                          "ms_trace_timed": round(ms_trace, 2), "ms_shade_timed": round(ms_shade, 2),
                          "ms_resolve": round(sum(s.ms_resolve for s in stats), 2),
                          "ms_total_device": round(sum(s.ms_total for s in stats), 2)},

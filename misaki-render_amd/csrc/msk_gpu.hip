@@ -28,9 +28,10 @@ struct msk_ctx {
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop;
     std::string last_error;
-    hipStream_t stream2 = nullptr;     // the second half of the pool runs here (run_wavefront)
-    Ctrl *h_ctrl = nullptr;            // pinned, [2]: one per half
-    std::vector<hipEvent_t> events, events2;
+#define MSK_MAX_STREAMS 4
+    hipStream_t more_streams[MSK_MAX_STREAMS - 1] = {};   // the other parts of the pool run here (run_wavefront)
+    Ctrl *h_ctrl = nullptr;            // pinned, [MSK_MAX_STREAMS]: one per part
+    std::vector<hipEvent_t> events, more_events[MSK_MAX_STREAMS - 1];
 };
 
 static int fail(msk_ctx *ctx, int code, const char *fmt, ...) {
@@ -92,8 +93,8 @@ extern "C" int msk_gpu_init(const int *device_ids, int n, msk_ctx **out_ctx) {
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, ctx->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc((void **) &ctx->h_ctrl, 2 * sizeof(Ctrl), hipHostMallocDefault);
+    for (int k = 0; k < MSK_MAX_STREAMS - 1; ++k) if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->more_streams[k], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **) &ctx->h_ctrl, MSK_MAX_STREAMS * sizeof(Ctrl), hipHostMallocDefault);
     if (e != hipSuccess) {
         int rc = fail(nullptr, MSK_ERR_HIP, "msk_gpu_init: %s", hipGetErrorString(e));
         msk_gpu_shutdown(ctx);             // releases whichever of stream / pinned block exist
@@ -114,8 +115,10 @@ extern "C" void msk_gpu_shutdown(msk_ctx *ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
     for (auto ev : ctx->events) (void) hipEventDestroy(ev);
-    for (auto ev : ctx->events2) (void) hipEventDestroy(ev);
-    if (ctx->stream2) (void) hipStreamDestroy(ctx->stream2);
+    for (int k = 0; k < MSK_MAX_STREAMS - 1; ++k) {
+        for (auto ev : ctx->more_events[k]) (void) hipEventDestroy(ev);
+        if (ctx->more_streams[k]) (void) hipStreamDestroy(ctx->more_streams[k]);
+    }
     if (ctx->h_ctrl) (void) hipHostFree(ctx->h_ctrl);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -427,7 +430,7 @@ static std::vector<HostBlock> spiral_blocks(int w, int h, int bs, int *nbx, int 
 // wavefront driver
 // ------------------------------------------------------------------------------------------
 struct StateBufs {
-    DevBuf id, wl, thr, res, ray_o, ray_d, sh, contrib, hit, aux, counts, ctrl, stack_ovf, stack_ovf2;
+    DevBuf id, wl, thr, res, ray_o, ray_d, sh, contrib, hit, aux, counts, ctrl, stack_ovf[MSK_MAX_STREAMS];
     PathState st;
     hipError_t alloc(size_t n, uint32_t n_regions) {
         hipError_t e;
@@ -436,7 +439,7 @@ struct StateBufs {
         A_(aux, 8)
 #undef A_
         if ((e = counts.reserve((size_t) n_regions * sizeof(RegionCtl))) != hipSuccess) return e;
-        if ((e = ctrl.reserve(2 * sizeof(Ctrl))) != hipSuccess) return e;
+        if ((e = ctrl.reserve(MSK_MAX_STREAMS * sizeof(Ctrl))) != hipSuccess) return e;
         st.id = id.as<uint4>(); st.wl = wl.as<float4>(); st.thr = thr.as<float4>(); st.res = res.as<float4>();
         st.ray_o = ray_o.as<float4>(); st.ray_d = ray_d.as<float4>(); st.sh = sh.as<float4>();
         st.contrib = contrib.as<float4>(); st.hit = hit.as<float4>(); st.aux = aux.as<float2>();
@@ -637,40 +640,44 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
         }
         return sum;
     };
-    const bool two = env_u32("MSK_STREAMS", 2) >= 2 && n_regions >= 1024 && stream == ctx->stream;
-    const uint32_t n0 = two ? n_regions / 2 : n_regions;
+    // how many loops: 4 by default (DESIGN.md §6 has 1 / 2 / 3 / 4); one for small jobs and caller-supplied streams
+    uint32_t n_parts = std::min<uint32_t>(MSK_MAX_STREAMS, std::max(1u, env_u32("MSK_STREAMS", 4)));
+    if (n_regions < 1024 || stream != ctx->stream) n_parts = 1;
     const uint32_t ovf_words = sc->dev.stack_total > sc->dev.stack_entries ? sc->dev.stack_total - sc->dev.stack_entries : 0;
-    Half h0{0, n0, stream, sb.ctrl.as<Ctrl>(), ctx->h_ctrl, EventPool{ctx, ev.next, ev.pool}, nullptr, msk_stats{}, MSK_OK, share(0, n0)};
-    Half h1{n0, n_regions - n0, ctx->stream2, sb.ctrl.as<Ctrl>() + 1, ctx->h_ctrl + 1, EventPool{ctx, 0, &ctx->events2}, nullptr, msk_stats{},
-            MSK_OK, two ? share(n0, n_regions - n0) : 0ull};
-    if (ovf_words) {                                    // LaneStack overflow: one word per lane per extra entry, per launch
-        const size_t lanes0 = (size_t) ((h0.count * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK) * MSK_BLOCK;
-        HIP_TRY(ctx, sb.stack_ovf.reserve((size_t) ovf_words * lanes0 * 4));
-        h0.stack_ovf = sb.stack_ovf.as<uint32_t>();
-        if (two) {
-            const size_t lanes1 = (size_t) ((h1.count * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK) * MSK_BLOCK;
-            HIP_TRY(ctx, sb.stack_ovf2.reserve((size_t) ovf_words * lanes1 * 4));
-            h1.stack_ovf = sb.stack_ovf2.as<uint32_t>();
+    std::vector<Half> parts;
+    // Parts of slightly different sizes: equal parts can fall into step (all launches starting and draining together, which
+    // is one big launch again; measured as a bimodal 48 / 52 ms), unequal ones keep sliding past each other.
+    const double skew = env_u32("MSK_STREAM_SKEW", 10) / 100.0;          // relative size step between neighbouring parts
+    std::vector<double> cum(n_parts + 1, 0.0);
+    for (uint32_t k = 0; k < n_parts; ++k) cum[k + 1] = cum[k] + 1.0 + skew * ((double) (n_parts - 1) / 2.0 - k);
+    for (uint32_t k = 0; k < n_parts; ++k) {
+        const uint32_t first = (uint32_t) (n_regions * (cum[k] / cum[n_parts])), last = k + 1 == n_parts ? n_regions : (uint32_t) (n_regions * (cum[k + 1] / cum[n_parts]));
+        parts.push_back(Half{first, last - first, k ? ctx->more_streams[k - 1] : stream, sb.ctrl.as<Ctrl>() + k, ctx->h_ctrl + k,
+                             k ? EventPool{ctx, 0, &ctx->more_events[k - 1]} : EventPool{ctx, ev.next, ev.pool}, nullptr, msk_stats{}, MSK_OK,
+                             share(first, last - first)});
+        std::memset(&parts.back().st, 0, sizeof(msk_stats));
+        if (ovf_words) {                                // LaneStack overflow: one word per lane per extra entry, per launch
+            const size_t lanes = (size_t) (((last - first) * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK) * MSK_BLOCK;
+            HIP_TRY(ctx, sb.stack_ovf[k].reserve((size_t) ovf_words * lanes * 4));
+            parts.back().stack_ovf = sb.stack_ovf[k].as<uint32_t>();
         }
     }
-    std::memset(&h0.st, 0, sizeof h0.st); std::memset(&h1.st, 0, sizeof h1.st);
-    if (two) {
-        HIP_TRY(ctx, hipStreamSynchronize(stream));     // the regions' initial records (queued above) before stream2 reads them
-        std::thread other([&]() { h1.rc = run_range(h1); });
-        h0.rc = run_range(h0);
-        other.join();
+    if (n_parts > 1) {
+        HIP_TRY(ctx, hipStreamSynchronize(stream));     // the regions' initial records (queued above) before the other streams read them
+        std::vector<std::thread> others;
+        for (uint32_t k = 1; k < n_parts; ++k) others.emplace_back([&, k]() { parts[k].rc = run_range(parts[k]); });
+        parts[0].rc = run_range(parts[0]);
+        for (auto &t : others) t.join();
     } else {
-        h0.rc = run_range(h0);
+        parts[0].rc = run_range(parts[0]);
     }
-    if (h0.rc) return h0.rc;
-    if (two && h1.rc) return h1.rc;
+    for (auto &hf : parts) if (hf.rc) return hf.rc;
     if (stats) {
-        for (const Half *hf : {&h0, &h1}) {
-            if (hf == &h1 && !two) break;
-            stats->samples += hf->st.samples; stats->segments += hf->st.segments; stats->shadow_rays += hf->st.shadow_rays;
-            stats->iterations += hf->st.iterations;
-            stats->ms_trace += hf->st.ms_trace; stats->ms_shade += hf->st.ms_shade;
-            stats->n_trace_launches += hf->st.n_trace_launches; stats->n_shade_launches += hf->st.n_shade_launches;
+        for (const Half &hf : parts) {
+            stats->samples += hf.st.samples; stats->segments += hf.st.segments; stats->shadow_rays += hf.st.shadow_rays;
+            stats->iterations += hf.st.iterations;
+            stats->ms_trace += hf.st.ms_trace; stats->ms_shade += hf.st.ms_shade;
+            stats->n_trace_launches += hf.st.n_trace_launches; stats->n_shade_launches += hf.st.n_shade_launches;
         }
     }
     (void) ev_trace; (void) ev_shade;
