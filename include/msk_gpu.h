@@ -23,8 +23,10 @@
  *   - the caller owns every host array for the duration of the call that takes
  *     it; the library copies what it needs into HBM.
  *   - handles are opaque and destroyed explicitly.
- *   - one host thread per msk_ctx (the reference calls render() from a single
- *     worker thread, src/apps/main.cpp:37).
+ *   - one calling thread per msk_ctx at a time (the reference calls render()
+ *     from a single worker thread, src/apps/main.cpp:37).  A render call uses
+ *     up to three short-lived helper threads and four HIP streams of its own
+ *     inside the library; it returns when all of them are done.
  */
 #ifndef MSK_GPU_H
 #define MSK_GPU_H
