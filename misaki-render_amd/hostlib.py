@@ -8,7 +8,7 @@ import numpy as np
 from . import abi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libmisaki-render.so")
+LIB_PATH = os.environ.get("MSK_HOST_LIB") or os.path.join(_PKG, "lib", "libmisaki-render.so")     # (override: a sanitizer build)
 _lib = None
 
 

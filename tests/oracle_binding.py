@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "oracle", "liboracle.so")
+LIB = os.environ.get("MSK_ORACLE_LIB") or os.path.join(ROOT, "oracle", "liboracle.so")     # (override: a sanitizer build)
 
 
 def _p(a):
