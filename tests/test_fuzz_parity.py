@@ -66,6 +66,13 @@ def test_gpu_equals_oracle_on_random_scenes(gpu_ctx, oracle):
     assert _fuzz().sweep(gpu_ctx, oracle, list(range(5000, 5060)) + [20657]) == []
 
 
+@pytest.mark.gpu
+def test_gpu_equals_oracle_on_random_scenes_with_many_samples(gpu_ctx, oracle):
+    """The same random scenes at 400 spp: enough samples (>= 1024 regions) for the wavefront loop to run as four loops on
+    four streams with every material, emitter and shard kind the generator makes."""
+    assert _fuzz().sweep(gpu_ctx, oracle, list(range(7000, 7008)), verbose=False, spp=400) == []
+
+
 def _fuzz_rays():
     spec = importlib.util.spec_from_file_location("fuzz_rays", os.path.join(ROOT, "tools", "fuzz_rays.py"))
     mod = importlib.util.module_from_spec(spec)
