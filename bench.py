@@ -5,16 +5,26 @@ Cornell box at 512x512, 512 spp per GPU (BASELINE.json configs[1]), diffuse BSDF
     python bench.py --gpus N --steps K --warmup W
 
 A step = one complete render through the C ABI (msk_gpu_render_device): wavefront path tracing
-of every sample + the ordered film resolve, film left in HBM.  Inputs (scene, BVH) are resident
-in HBM before the timed region.  For N > 1 the driver launches one rank per GPU
-(torch.distributed.run); rank r renders the spiral blocks id = r (mod N) at 512*N spp — per-GPU
-work is constant (weak scaling) — and the films are summed onto rank 0 with one RCCL reduce
-inside the timed region.  Rank 0 prints ONE JSON line.
+of every sample + the ordered film replay, film left in HBM.  Inputs (scene, BVH) are resident
+in HBM before the timed region.
+
+N > 1: one process per GPU.  Under torch.distributed.run (WORLD_SIZE set) this process is one rank;
+from a bare shell (`python bench.py --gpus 8`) this process only spawns the N ranks — before anything
+touches a GPU — waits for them and passes rank 0's JSON line on.  Rank r renders every tile for the
+sample indices s = r (mod N) of 512*N spp (`--shard samples`, the default; speed-proportional contiguous
+ranges when the GPUs differ) or the spiral blocks id = r (mod N) (`--shard tiles`): per-GPU work is
+constant (weak scaling), and the films are summed onto rank 0 with one RCCL reduce inside the timed region.
+Rank 0 prints ONE JSON line.
+
+`--dry-run` exercises the launch / rendezvous / reduce / timing plumbing without a GPU (gloo backend, a
+host tensor as the film, no render): what tests/test_bench_launch.py runs on CPU.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,88 +34,188 @@ sys.path.insert(0, ROOT)
 WIDTH = HEIGHT = 512
 SPP_PER_GPU = 512
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+# VALU issue peak: 256 CUs x 4 SIMD-32, one wave64 instruction per 2 cycles per SIMD at 2.4 GHz (same guide)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
 
 
-def cpu_baseline(abi, hm, flat, seconds_target=15.0):
-    """The CPU oracle (a port of the reference's Embree3+TBB loop, see oracle/oracle.cpp) timed on
-    this box's host cores on a bounded sample of the same workload.  Reported, never the target."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_binding
-    orc = oracle_binding.load()
-    threads = min(8, os.cpu_count() or 1)         # the reference CLI caps TBB at 8 threads (main.cpp:43-44)
-    sc = orc.scene(flat)
-    spp = 1
-    prm = abi.render_params(spp=spp, rng_mode=abi.MSK_RNG_PCG_BLOCK)
-    t0 = time.perf_counter()
-    sc.render(prm, threads)
-    dt = time.perf_counter() - t0
-    spp = int(max(1, min(64, seconds_target / max(dt, 1e-3))))
-    prm = abi.render_params(spp=spp, rng_mode=abi.MSK_RNG_PCG_BLOCK)
-    t0 = time.perf_counter()
-    _, st = sc.render(prm, threads)
-    dt = time.perf_counter() - t0
-    sc.close()
-    return {"value": round(st.samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": f"cbox {WIDTH}x{HEIGHT} @ {spp} spp ({st.samples} samples, {dt:.1f} s), pcg_block sampler, "
-                      f"own BVH instead of Embree", "host_cpus": os.cpu_count()}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=SPP_PER_GPU, help="spp per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the config 3 / 4 / 5 class renders that N = 1 adds under `other_configs`")
     ap.add_argument("--shard", choices=("samples", "tiles"), default="samples",
                     help="N > 1: which axis the ranks split (misaki-render_amd/multigpu.py); both end in one film reduce")
     ap.add_argument("--no-balance", action="store_true",
                     help="N > 1: keep the equal interleaved sample split even when the GPUs differ in speed")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: launch, rendezvous (gloo), reduce and timing only")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` from a bare shell: start N ranks as CHILD processes (this process has not touched a
+    GPU and never will), one per GPU, rendezvous on 127.0.0.1.  Returns the exit code for the shell."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def cpu_baseline(abi, hm, flat, threads, seconds_target=12.0):
+    """The CPU oracle (a port of the reference's Embree3+TBB loop, see oracle/oracle.cpp) timed on
+    this box's host cores on a bounded sample of the same workload.  Reported, never the target."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding
+    orc = oracle_binding.load()
+    sc = orc.scene(flat)
+    spp = 1
+    prm = abi.render_params(spp=spp, rng_mode=abi.MSK_RNG_PCG_BLOCK)
+    t0 = time.perf_counter()
+    sc.render(prm, threads)
+    dt = time.perf_counter() - t0
+    spp = int(max(1, min(512, seconds_target / max(dt, 1e-3))))
+    prm = abi.render_params(spp=spp, rng_mode=abi.MSK_RNG_PCG_BLOCK)
+    t0 = time.perf_counter()
+    _, st = sc.render(prm, threads)
+    dt = time.perf_counter() - t0
+    sc.close()
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if quota[0] == "max" else round(int(quota[0]) / int(quota[1]), 2)
+    except Exception:
+        quota = None
+    return {"value": round(st.samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "affinity_cpus": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": quota,
+            "sample": f"cbox {WIDTH}x{HEIGHT} @ {spp} spp ({st.samples} samples, {dt:.1f} s), pcg_block sampler, "
+                      f"own BVH instead of Embree, one 32x32 tile per task", "host_cpus": os.cpu_count()}
+
+
+def other_configs(abi, hm, ctx):
+    """BASELINE configs 3, 4 and 5 as one GPU sees them (N = 1 only, after the timed region): config 4 whole on this GPU,
+    configs 3 / 5 on the bunny- / teapot-class stand-ins (the reference ships no meshes), config 5 at the 128-spp share
+    one GPU of eight renders.  Two renders each, the second is reported (the first one also allocates the workspace)."""
+    out = []
+    jobs = [
+        ("config 3 class: 70 k-triangle rough-conductor mesh in the Cornell room, 1024x1024 @ 256 spp",
+         lambda: hm.bunny_class_scene(1024), 256),
+        ("config 5 class: 146 k-triangle rough-dielectric mesh in the Cornell room, 1024x1024 @ 128 spp (one GPU's share of 1024 spp on 8)",
+         lambda: hm.teapot_class_scene(1024), 128),
+        ("config 4 on ONE GPU: cbox 1920x1080 @ 4096 spp", lambda: hm.cbox_scene(1920, 1080), 4096),
+    ]
+    for name, make, spp in jobs:
+        try:
+            flat = make()
+            t0 = time.perf_counter()
+            sc = abi.Scene(ctx, flat)
+            t_scene = time.perf_counter() - t0
+            prm = abi.render_params(spp=spp)
+            film = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                film, st = sc.render(prm)
+                dt = time.perf_counter() - t0
+            out.append({"workload": name, "triangles": int(flat.desc.n_faces), "samples": int(st.samples),
+                        "value": round(st.samples / dt / 1e6, 1), "unit": "Msamples/s", "ms": round(dt * 1e3, 1),
+                        "ms_device": round(st.ms_total, 1), "segments_per_sample": round(st.segments / max(st.samples, 1), 3),
+                        "iterations": int(st.iterations), "passes": int(st.passes), "ms_resolve": round(st.ms_resolve, 1),
+                        "scene_create_s": round(t_scene, 2), "finite": bool(__import__("numpy").isfinite(film).all()),
+                        "timing": "wall time of msk_gpu_render incl. the film copy-back (PCIe)"})
+            sc.close()
+        except Exception as e:                                       # reported, never fatal for the headline line
+            out.append({"workload": name, "error": str(e)[:300]})
+    return out
+
+
+def profile_counters():
+    """Per-launch counters of the committed rocprofv3 PMC passes (profiles/pmc_summary.json, profiles/*_sq.json):
+    NOT measured in this run — they describe the build and configuration the profile was taken on."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+    except Exception:
+        pm = {}
+    return pm
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     # Per-kernel HIP-event timing on every 4th sync group (8 iterations each), rotating over the steps: a timed dispatch costs
     # ~6 us, 2 % of a step if every launch carries events (DESIGN.md §8).  The roofline's average launch duration is the
     # average over the timed launches.
     os.environ.setdefault("MSK_TIMING_EVERY", "4")
     import torch
-    abi = importlib.import_module("misaki-render_amd.abi")
-    hm = importlib.import_module("misaki-render_amd.hostmirror")
     mg = importlib.import_module("misaki-render_amd.multigpu")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    n = args.gpus
-    if world != n and world > 1:
-        n = world
-    torch.cuda.set_device(local_rank)
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the launcher's world size wins", file=sys.stderr)
+    dev = "cpu" if args.dry_run else "cuda"
+    if not args.dry_run:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dry_run:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    flat = hm.cbox_scene(WIDTH, HEIGHT)
-    ctx = abi.Context(local_rank)
-    scene = abi.Scene(ctx, flat)
     spp_total = mg.weak_scaling_spp(args.spp, world)
-    prm = mg.shard_params(abi, spp_total, rank, world, mode=args.shard, seed=0)
-    film = torch.zeros((HEIGHT, WIDTH, 5), dtype=torch.float32, device="cuda")
+    if args.dry_run:
+        film = torch.ones((8, 8, 5), dtype=torch.float32)
+        abi = hm = scene = ctx = flat = None
 
-    def step():
-        st = scene.render_device(prm, film.data_ptr())
-        mg.reduce_film(film, dist)
-        return st
+        def step():
+            film.fill_(1.0)
+            mg.reduce_film(film, dist)
+            return None
+    else:
+        abi = importlib.import_module("misaki-render_amd.abi")
+        hm = importlib.import_module("misaki-render_amd.hostmirror")
+        flat = hm.cbox_scene(WIDTH, HEIGHT)
+        ctx = abi.Context(local_rank)
+        scene = abi.Scene(ctx, flat)
+        prm = mg.shard_params(abi, spp_total, rank, world, mode=args.shard, seed=0)
+        film = torch.zeros((HEIGHT, WIDTH, 5), dtype=torch.float32, device="cuda")
+
+        def step():
+            # render_device returns when the film is complete on the library's stream; reduce_film returns when the
+            # reduce has finished reading it (multigpu.reduce_film synchronises): the next render may overwrite it
+            st = scene.render_device(prm, film.data_ptr())
+            mg.reduce_film(film, dist)
+            return st
 
     def fence():
-        torch.cuda.synchronize()
+        if not args.dry_run:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not args.dry_run:
+                torch.cuda.synchronize()
 
     warm = [step() for _ in range(args.warmup)]
     balance = None
-    if dist is not None and args.shard == "samples" and not args.no_balance and warm:
+    if dist is not None and args.shard == "samples" and not args.no_balance and warm and not args.dry_run:
         # The GPUs of a node are not equally fast on this workload (DESIGN.md §8: the shading kernel differs by up to 20 %
         # between boxes of the pool) and an equal split waits for the slowest.  Every rank's device time of the last
         # warm-up step decides speed-proportional contiguous sample ranges; the per-GPU average stays args.spp.
@@ -124,11 +234,18 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    if rank == 0:
+    if rank == 0 and args.dry_run:
+        ok = bool((film == float(world)).all())
+        print(json.dumps({"metric": "Msamples/s (paths x spp) on cbox@512spp", "value": None, "unit": "Msamples/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "dry_run": True, "reduce_ok": ok,
+                          "config": {"workload": "none (launch / rendezvous / reduce only)", "samples_per_step": WIDTH * HEIGHT * spp_total}}),
+              flush=True)
+    elif rank == 0:
         samples_step = WIDTH * HEIGHT * spp_total              # all ranks together
         value = samples_step * args.steps / dt / 1e6
         # ---- roofline of the dominant kernel, from the HIP events the library records around every
@@ -140,7 +257,7 @@ def main():
         ms_shade = sum(s.ms_shade for s in stats)
         n_trace = sum(s.n_trace_launches for s in stats)
         n_shade = sum(s.n_shade_launches for s in stats)
-        # algorithmic bytes of the SoA path state each kernel must move (DESIGN.md §bytes):
+        # algorithmic bytes of the SoA path state each kernel must move (DESIGN.md §5):
         #   k_trace      48 B/segment (ray_o, ray_d in; hit out) + 16 B/shadow ray (sh in)
         #   k_shade_gen  224 B/segment (96 in, 128 out) + 16 B/shadow ray (contrib in) + 20 B/sample (record out)
         bytes_trace = seg * 48 + shd * 16
@@ -157,13 +274,10 @@ def main():
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         ms_wavefront = sum(s.ms_total - s.ms_resolve for s in stats)
         pair_achieved = (bytes_trace + bytes_shade) / (ms_wavefront * 1e-3) / 1e9 if ms_wavefront > 0 else 0.0
-        def pmc_traffic(prefix):
-            prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
-            try:
-                pm = json.load(open(prof))
-                return next((v["hbm_bytes_per_launch"] for k, v in pm.items() if k.startswith(prefix)), None)
-            except Exception:
-                return None
+        pm = profile_counters()
+
+        def prof(prefix, key):
+            return next((v.get(key) for k, v in pm.items() if k.startswith(prefix) and isinstance(v, dict)), None)
         n_streams = int(os.environ.get("MSK_STREAMS", "4"))
         per_kernel = {"kernel": name, "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
                       "bytes_per_launch": round(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
@@ -178,11 +292,22 @@ def main():
             per_iter = max(iters // n_streams, 1)            # iterations of the whole pool (every stream launches its own)
             bytes_per_launch = (bytes_trace + bytes_shade) / per_iter
             avg_launch_ms = ms_wavefront / per_iter
-            ts, tt = pmc_traffic("k_shade_gen"), pmc_traffic("k_trace")
+            ts, tt = prof("k_shade_gen", "hbm_bytes_per_launch"), prof("k_trace", "hbm_bytes_per_launch")
             traffic = round((ts + tt) * n_streams) if ts is not None and tt is not None else None   # PMC run = the same 4-stream launches
         else:
-            t = pmc_traffic(name)
+            t = prof(name, "hbm_bytes_per_launch")
             traffic = round(t) if t is not None else None
+        # VALU side (the kernels are issue-bound, not HBM-bound — DESIGN.md §8): wave-level VALU instructions per path
+        # segment from the committed SQ counter pass, times this run's segments, over the wavefront phase's wall time
+        valu = None
+        vs, vt = prof("k_shade_gen", "valu_insts_per_segment"), prof("k_trace", "valu_insts_per_segment")
+        if vs is not None and vt is not None and ms_wavefront > 0:
+            ginst = (vs + vt) * seg / (ms_wavefront * 1e-3) / 1e9
+            valu = {"bound": "valu", "achieved": round(ginst, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instr/s",
+                    "frac": round(ginst / VALU_PEAK_GINST, 4), "insts_per_segment": {"k_shade_gen": vs, "k_trace": vt},
+                    "source": pm.get("_source", "profiles/pmc_summary.json"),
+                    "note": "wave64 VALU instructions (SQ_INSTS_VALU of the committed profile / its segments) x this run's segments "
+                            "/ wavefront-phase wall time; peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction"}
         out = {
             "metric": "Msamples/s (paths x spp) on cbox@512spp", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -194,20 +319,32 @@ def main():
                        "samples_per_step": samples_step, "balance": balance,
                        "segments_per_sample": round(seg / max(smp, 1), 3)},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic,
+                         "traffic_source": "NOT measured in this run: per-launch FETCH_SIZE/WRITE_SIZE of the committed rocprofv3 PMC "
+                                           "passes (%s)" % pm.get("_source", "profiles/pmc_summary.json"),
                          "bytes_per_launch": round(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
                          "per_kernel": per_kernel, "launches": iters, "timed_launches": nl, "timed": "launches of every %s-th sync group" % os.environ.get("MSK_TIMING_EVERY", "1"),
                          "ms_trace_timed": round(ms_trace, 2), "ms_shade_timed": round(ms_shade, 2),
                          "ms_resolve": round(sum(s.ms_resolve for s in stats), 2),
-                         "ms_total_device": round(sum(s.ms_total for s in stats), 2)},
+                         "ms_total_device": round(sum(s.ms_total for s in stats), 2),
+                         "valu": valu},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(abi, hm, flat)
+            # the reference CLI caps TBB at 8 threads (main.cpp:43-44): that run is `cpu_baseline`; the same port on every
+            # hardware thread of this host rides along (SURVEY §8d asks for both)
+            out["cpu_baseline"] = cpu_baseline(abi, hm, flat, min(8, os.cpu_count() or 1))
+            n_all = len(os.sched_getaffinity(0))
+            if n_all > 8:
+                out["cpu_baseline_all_threads"] = cpu_baseline(abi, hm, flat, n_all)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_other_configs:
+            out["other_configs"] = other_configs(abi, hm, ctx)
         print(json.dumps(out), flush=True)
-    scene.close()
-    ctx.close()
+    if scene is not None:
+        scene.close()
+        ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -221,7 +221,15 @@ typedef struct msk_stats {
     uint32_t iterations;     /* wavefront iterations                           */
     uint32_t passes;         /* block groups (record-buffer passes)            */
     float    ms_total;       /* device time of the whole call                  */
-    float    ms_generate, ms_trace, ms_shade, ms_resolve; /* per-kernel sums   */
+    float    ms_generate;    /* always 0: camera-ray generation is fused into the shading kernel (its time
+                                is part of ms_shade); the field keeps the struct layout of ABI v4 */
+    /* Sums of the kernel durations of the launches that carried timing events, and how many did
+       (n_*_launches).  With the environment variable MSK_TIMING_EVERY=n (default 1) only the launches of
+       every n-th group of wavefront iterations are timed: ms_trace / ms_shade are then SAMPLES — divide by
+       n_*_launches for an average launch, scale by iterations / n_*_launches for an estimate of the total.
+       When the wavefront loop runs on several streams launches overlap, so these sums can
+       exceed ms_total.  ms_resolve (film replay + Film::put) is always complete. */
+    float    ms_trace, ms_shade, ms_resolve;
     uint32_t n_trace_launches, n_shade_launches;
 } msk_stats;
 

@@ -32,6 +32,8 @@ struct msk_ctx {
     hipStream_t more_streams[MSK_MAX_STREAMS - 1] = {};   // the other parts of the pool run here (run_wavefront)
     Ctrl *h_ctrl = nullptr;            // pinned, [MSK_MAX_STREAMS]: one per part
     std::vector<hipEvent_t> events, more_events[MSK_MAX_STREAMS - 1];
+    uint32_t timing_phase = 0;         // which sync groups carry timing events rotates from render to render (MSK_TIMING_EVERY);
+                                       // a context is used by one host thread at a time (msk_gpu.h), so a plain counter
 };
 
 static int fail(msk_ctx *ctx, int code, const char *fmt, ...) {
@@ -41,6 +43,19 @@ static int fail(msk_ctx *ctx, int code, const char *fmt, ...) {
     if (ctx) ctx->last_error = buf;
     return code;
 }
+// The same for code that runs on the helper threads of a render (run_wavefront): the text goes to a slot the thread
+// owns; the calling thread copies the first failure into the context after the join.  ctx->last_error is only ever
+// written by the thread that called into the library.
+static int fail_to(std::string *slot, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    *slot = buf;
+    return code;
+}
+#define HIP_TRY_SLOT(slot, expr)                                                                 \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess)                                          \
+        return fail_to(slot, e_ == hipErrorOutOfMemory ? MSK_ERR_OOM : MSK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                       hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 #define HIP_TRY(ctx, expr)                                                                       \
     do { hipError_t e_ = (expr); if (e_ != hipSuccess)                                          \
         return fail(ctx, e_ == hipErrorOutOfMemory ? MSK_ERR_OOM : MSK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
@@ -148,6 +163,11 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     if (!d->cie1931_xyz || !d->d65) return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: spectral tables missing");
     if ((d->n_faces && (!d->vertices || !d->faces)) || (d->n_meshes && !d->meshes))
         return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: geometry arrays missing");
+    if ((d->n_bsdfs && !d->bsdfs) || (d->n_emitters && !d->emitters))
+        return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: bsdf / emitter arrays missing");
+    // leaf references pack first_tri << 5 | count into 31 bits (msk_bvh.h) and bit 31 of a hit's prim word is the shadow flag
+    if (d->n_faces >= (1u << 26))
+        return fail(ctx, MSK_ERR_UNSUPPORTED, "msk_gpu_scene_create: %u triangles, this back end addresses fewer than 2^26", d->n_faces);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     // ---- validate + gather per-triangle data (operand shapes are checked here, on the host,
@@ -162,8 +182,12 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
             return fail(ctx, MSK_ERR_INVALID_ARG, "mesh %u: vertex/face range exceeds the arrays", m);
         if (md.bsdf_id < 0 || (uint32_t) md.bsdf_id >= d->n_bsdfs)
             return fail(ctx, MSK_ERR_INVALID_ARG, "mesh %u: bsdf_id %d out of range", m, md.bsdf_id);
-        if (md.emitter_id >= (int32_t) d->n_emitters)
+        if (md.emitter_id >= (int32_t) d->n_emitters || md.emitter_id < -1)
             return fail(ctx, MSK_ERR_INVALID_ARG, "mesh %u: emitter_id %d out of range", m, md.emitter_id);
+        // one mesh per area emitter, named from both sides (Shape::m_emitter / Emitter::m_shape, shape.cpp:27-37): a second
+        // mesh pointing at the same emitter would be lit with the first one's area pdf and CDF
+        if (md.emitter_id >= 0 && (!d->emitters || d->emitters[md.emitter_id].mesh_id != (int32_t) m))
+            return fail(ctx, MSK_ERR_INVALID_ARG, "mesh %u: emitter %d does not point back at it", m, md.emitter_id);
         any_normals |= md.has_normals != 0; any_uvs |= md.has_texcoords != 0;
     }
     if (any_normals) tn.assign((size_t) d->n_faces * 12, 0.f);
@@ -189,6 +213,8 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
             for (int k = 0; k < 3; ++k) {
                 if (fi[k] >= md.vertex_count) return fail(ctx, MSK_ERR_INVALID_ARG, "mesh %u face %u: vertex index %u out of range", m, f, fi[k]);
                 v[k] = d->vertices + (size_t) (md.first_vertex + fi[k]) * 8;
+                if (!(std::isfinite(v[k][0]) && std::isfinite(v[k][1]) && std::isfinite(v[k][2])))
+                    return fail(ctx, MSK_ERR_INVALID_ARG, "mesh %u vertex %u: non-finite position", m, fi[k]);
                 for (int c = 0; c < 3; ++c) { pos[(size_t) g * 9 + k * 3 + c] = v[k][c]; tv[(size_t) g * 12 + k * 4 + c] = v[k][c]; }
                 if (any_normals) for (int c = 0; c < 3; ++c) tn[(size_t) g * 12 + k * 4 + c] = v[k][3 + c];
             }
@@ -454,7 +480,8 @@ struct Workspace {
     std::vector<uint64_t> plan_key;          // empty = nothing cached
     uint64_t plan_n_pix = 0;
     DevBuf counts_init; unsigned long long counts_total = 0; uint32_t counts_regions = 0;
-    DevBuf block_buf, blocks, block_of, spiral, pix, rec_a, rec_b, film;
+    DevBuf block_buf, blocks, block_of, spiral, pix, rec_a, rec_b, film, bands;
+    uint32_t n_bands = 0;
     DevBuf aov_rec[MSK_MAX_AOV_GROUPS + 1], aov_block_buf[MSK_MAX_AOV_GROUPS + 1];   // [n_groups] = the nested path's RGB
 };
 
@@ -474,9 +501,15 @@ static uint32_t env_u32(const char *name, uint32_t def) {
 
 struct EventPool {
     msk_ctx *ctx; size_t next = 0; std::vector<hipEvent_t> *pool = nullptr;       // pool: ctx->events unless told otherwise
+    // nullptr when the runtime cannot create another event: the dispatch then simply carries no timestamps
+    // (hipExtLaunchKernelGGL takes null events) and the statistics miss that launch; nothing else depends on events
     hipEvent_t get() {
         std::vector<hipEvent_t> &v = pool ? *pool : ctx->events;
-        while (next >= v.size()) { hipEvent_t e; (void) hipEventCreate(&e); v.push_back(e); }
+        while (next >= v.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess || !e) { (void) hipGetLastError(); return nullptr; }
+            v.push_back(e);
+        }
         return v[next++];
     }
 };
@@ -484,7 +517,7 @@ struct EventPool {
 void free_workspace(msk_scene *scene) { delete scene->ws; scene->ws = nullptr; }
 
 static void sum_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, float *ms) {
-    for (auto &p : v) { float t = 0; if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) *ms += t; }
+    for (auto &p : v) { float t = 0; if (p.first && p.second && hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) *ms += t; }
 }
 
 // t0 / t1: events that take the kernel's own start / end timestamps (hipExtLaunchKernelGGL: no extra packets in the queue,
@@ -519,7 +552,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
                          uint32_t region_size, uint32_t n_regions, msk_stats *stats, EventPool &ev,
                          std::vector<std::pair<hipEvent_t, hipEvent_t>> &ev_trace,
                          std::vector<std::pair<hipEvent_t, hipEvent_t>> &ev_shade,
-                         const AovParams *aov = nullptr, float4 *aov_rgb = nullptr) {
+                         const AovParams *aov = nullptr, float4 *aov_rgb = nullptr, bool packed = false) {
     msk_ctx *ctx = sc->ctx;
     const unsigned long long total = (unsigned long long) n_pix * spp_owned;
     // static, interleaved partition of the pass's samples over the regions (see RegionCtl); the initial records are kept
@@ -554,6 +587,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     pp0.region_first = 0; pp0.region_count = n_regions;
     pp0.trace_split = sc->trace_mode == 0 ? std::max(1u, env_u32("MSK_TRACE_SPLIT", 2)) : 1u;
     pp0.aov_rgb = aov_rgb;
+    pp0.packed = packed ? 1u : 0u;
     pp0.stack_ovf = nullptr;
     const bool diffuse_only = sc->all_diffuse && !aov_rgb;      // the AOV RGB record lives in the general shading variant
     const uint32_t group = env_u32("MSK_SYNC_GROUP", 8);
@@ -563,8 +597,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     // launch is timed.  MSK_TIMING_EVERY=n times the launches of every n-th sync group only (rotating from render to render so
     // that repeated renders cover all groups); msk_stats::ms_trace / ms_shade / n_*_launches then describe that sample.
     const uint32_t every = std::max(1u, env_u32("MSK_TIMING_EVERY", 1));
-    static uint32_t timing_phase = 0;
-    const uint32_t phase = timing_phase++;
+    const uint32_t phase = ctx->timing_phase++;
 
     // The wavefront loop over the regions [first, first + count) on one stream.  The pool's two halves run this at the same
     // time on two streams (two host threads): regions are independent — each owns its slots, its share of the samples and
@@ -572,7 +605,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     // round), which one launch at a time leaves open at its start, its end and wherever its waves wait.  Measured with two
     // concurrent half-size renders before this was built: 49.3 against 55.0 ms for the bench step.
     struct Half { uint32_t first, count; hipStream_t stream; Ctrl *d_ctrl, *h_ctrl; EventPool ev; uint32_t *stack_ovf;
-                  msk_stats st; int rc; unsigned long long expected; };
+                  msk_stats st; int rc; unsigned long long expected; std::string err; };
     auto run_range = [&](Half &hf) -> int {
         (void) hipSetDevice(ctx->device);               // the current device is per host thread
         PassParams pp = pp0;
@@ -599,32 +632,33 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
             for (uint32_t g = 0; g < group; ++g, ++it) {
                 hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
                 if (timed) { a = ev_h.get(); b = ev_h.get(); c = ev_h.get(); d = ev_h.get(); }
+                const bool have_ev = a && b && c && d;
 #define MSK_SHADE(L, D) hipExtLaunchKernelGGL((k_shade_gen<L, D>), dim3(grid), dim3(MSK_BLOCK), sc->shade_lds_bytes + shade_pad_lds, stream_h, a, b, 0, sc->dev, sb.st, pp)
                 if (sc->lds_tables) { if (diffuse_only) MSK_SHADE(true, true); else MSK_SHADE(true, false); }
                 else { if (diffuse_only) MSK_SHADE(false, true); else MSK_SHADE(false, false); }
 #undef MSK_SHADE
                 launch_trace(sc, stream_h, sb.st, pp, c, d);
                 if (aov && aov->n_groups) hipLaunchKernelGGL(k_aov_primary, dim3(grid), dim3(MSK_BLOCK), 0, stream_h, sc->dev, sb.st, pp, *aov);
-                if (timed) { cur_shade.push_back({a, b}); cur_trace.push_back({c, d}); }
+                if (timed && have_ev) { cur_shade.push_back({a, b}); cur_trace.push_back({c, d}); }
             }
             read_pending();                     // the previous group's, while this one runs
-            HIP_TRY(ctx, hipMemsetAsync(hf.d_ctrl, 0, sizeof(Ctrl), stream_h));
+            HIP_TRY_SLOT(&hf.err, hipMemsetAsync(hf.d_ctrl, 0, sizeof(Ctrl), stream_h));
             hipLaunchKernelGGL(k_reduce_ctl, dim3(std::min(64u, (hf.count + MSK_BLOCK - 1) / MSK_BLOCK)), dim3(MSK_BLOCK), 0, stream_h,
                                sb.counts.as<RegionCtl>() + hf.first, hf.count, hf.d_ctrl);
-            HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipMemcpyAsync(hf.h_ctrl, hf.d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream_h));
-            HIP_TRY(ctx, hipStreamSynchronize(stream_h));
+            HIP_TRY_SLOT(&hf.err, hipGetLastError());
+            HIP_TRY_SLOT(&hf.err, hipMemcpyAsync(hf.h_ctrl, hf.d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream_h));
+            HIP_TRY_SLOT(&hf.err, hipStreamSynchronize(stream_h));
             pend_shade.swap(cur_shade); pend_trace.swap(cur_trace); cur_shade.clear(); cur_trace.clear(); parity ^= 1u;
             const Ctrl &h = *hf.h_ctrl;
             if (h.remaining == 0 && h.live == 0) break;
-            if (it > 100000000u) return fail(ctx, MSK_ERR_HIP, "wavefront loop did not terminate");
+            if (it > 100000000u) return fail_to(&hf.err, MSK_ERR_HIP, "wavefront loop did not terminate");
         }
         read_pending();
         ev_h.next = ev_mark;                            // every timestamp has been read: the events are free again
         st->samples = hf.h_ctrl->samples_done; st->segments = hf.h_ctrl->segments; st->shadow_rays = hf.h_ctrl->shadow_rays;
         st->iterations = it;
         if (hf.h_ctrl->samples_done != hf.expected)
-            return fail(ctx, MSK_ERR_HIP, "internal error: %llu of %llu samples finished", hf.h_ctrl->samples_done, hf.expected);
+            return fail_to(&hf.err, MSK_ERR_HIP, "internal error: %llu of %llu samples finished", hf.h_ctrl->samples_done, hf.expected);
         return MSK_OK;
     };
 
@@ -654,7 +688,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
         const uint32_t first = (uint32_t) (n_regions * (cum[k] / cum[n_parts])), last = k + 1 == n_parts ? n_regions : (uint32_t) (n_regions * (cum[k + 1] / cum[n_parts]));
         parts.push_back(Half{first, last - first, k ? ctx->more_streams[k - 1] : stream, sb.ctrl.as<Ctrl>() + k, ctx->h_ctrl + k,
                              k ? EventPool{ctx, 0, &ctx->more_events[k - 1]} : EventPool{ctx, ev.next, ev.pool}, nullptr, msk_stats{}, MSK_OK,
-                             share(first, last - first)});
+                             share(first, last - first), std::string()});
         std::memset(&parts.back().st, 0, sizeof(msk_stats));
         if (ovf_words) {                                // LaneStack overflow: one word per lane per extra entry, per launch
             const size_t lanes = (size_t) (((last - first) * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK) * MSK_BLOCK;
@@ -671,7 +705,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     } else {
         parts[0].rc = run_range(parts[0]);
     }
-    for (auto &hf : parts) if (hf.rc) return hf.rc;
+    for (auto &hf : parts) if (hf.rc) return fail(ctx, hf.rc, "%s", hf.err.c_str());     // first failing part, after the join
     if (stats) {
         for (const Half &hf : parts) {
             stats->samples += hf.st.samples; stats->segments += hf.st.segments; stats->shadow_rays += hf.st.shadow_rays;
@@ -730,7 +764,7 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     if (stats) std::memset(stats, 0, sizeof *stats);
     EventPool ev{ctx, 0};
     hipEvent_t t_begin = ev.get(), t_end = ev.get();
-    (void) hipEventRecord(t_begin, stream);
+    if (t_begin) (void) hipEventRecord(t_begin, stream);
     const int W = sc->dev.width, H = sc->dev.height, bs = prm->block_size;
     int nbx, nby;
     std::vector<HostBlock> all = spiral_blocks(W, H, bs, &nbx, &nby);
@@ -787,8 +821,13 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
         }
         passes.push_back({b0, b1}); b0 = b1;
     }
+    // Default filter (border 2, footprint of five pixels) and blocks whose bordered width fits 12 lane columns: the records carry
+    // their filter weights and the replay is k_resolve_rows.  Anything else: positions + k_resolve_blocks.
+    const uint32_t band_rounds = std::max(5u, env_u32("MSK_RESOLVE_ROUNDS", 10));
+    const bool packed = border == 2 && (int) std::floor(sc->dev.filter_radius + 0.5f) == 2 && bs + 2 * border <= 3 * MSK_RR_COLS &&
+                        !env_u32("MSK_RESOLVE_GENERIC", 0);
     const std::vector<uint64_t> plan_key = {(uint64_t) W, (uint64_t) H, (uint64_t) bs, (uint64_t) border, prm->block_first, bstride,
-                                            spp_owned, passes.size(), owned.size()};
+                                            spp_owned, passes.size(), owned.size(), (uint64_t) packed, band_rounds};
     const bool plan_cached = passes.size() == 1 && ws.plan_key == plan_key;
     if (!plan_cached) {
         ws.plan_key.clear();
@@ -803,16 +842,28 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
         if (!plan_cached) {
             std::vector<uint4> pix;
             for (size_t b = ps.first; b < ps.second; ++b) {
-                const uint32_t npix = (uint32_t) (owned[b].size_x * owned[b].size_y);
                 for (int y = 0; y < owned[b].size_y; ++y)
-                    for (int x = 0; x < owned[b].size_x; ++x) {
-                        const uint64_t rec0 = (uint64_t) owned[b].pixel_base * spp_owned + (uint32_t) (y * owned[b].size_x + x);
-                        pix.push_back(make_uint4((uint32_t) ((owned[b].off_y + y) * W + owned[b].off_x + x), (uint32_t) rec0,
-                                                 (uint32_t) (rec0 >> 32), npix));
-                    }
+                    for (int x = 0; x < owned[b].size_x; ++x)       // PassParams::pix_table; the record of (pixel j, sample) is j * spp + sample
+                        pix.push_back(make_uint4((uint32_t) ((owned[b].off_y + y) * W + owned[b].off_x + x), (uint32_t) x | ((uint32_t) y << 16),
+                                                 (uint32_t) (owned[b].off_x - border), (uint32_t) (owned[b].off_y - border)));
             }
             HIP_TRY(ctx, d_pix.upload(pix));
             n_pix = pix.size();
+            // k_resolve_rows work list: per block, bands of target rows that each cost at most `band_rounds` source rows
+            // (the first band has no rows above it to wait for and the last one none below, so they take more target rows)
+            std::vector<RowBand> bands;
+            for (size_t b = ps.first; packed && b < ps.second; ++b) {
+                const uint32_t rows = (uint32_t) owned[b].size_y + 4u;
+                uint32_t a = 0;
+                while (a < rows) {
+                    const uint32_t rem = rows - a;
+                    const uint32_t h = (a == 0) ? std::min(band_rounds, rem) : (rem <= band_rounds ? rem : band_rounds - 4u);
+                    bands.push_back(RowBand{(uint32_t) (b - ps.first), a, a + h, 0u});
+                    a += h;
+                }
+            }
+            HIP_TRY(ctx, ws.bands.upload(bands));
+            ws.n_bands = (uint32_t) bands.size();
             if (passes.size() == 1) { ws.plan_key = plan_key; ws.plan_n_pix = n_pix; }
         }
         const uint64_t n_rec = n_pix * spp_owned;
@@ -829,7 +880,7 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
             if (aov->rgba) { HIP_TRY(ctx, ws.aov_rec[MSK_MAX_AOV_GROUPS].reserve(n_rec * 16)); aov_rgb = ws.aov_rec[MSK_MAX_AOV_GROUPS].as<float4>(); }
         }
         rc = run_wavefront(sc, stream, prm, spp_owned, d_pix.as<uint4>(), n_pix, d_rec_a.as<float4>(),
-                           d_rec_b.as<float>(), sb, region_size, n_regions, stats, ev, ev_trace, ev_shade, aov ? &ap : nullptr, aov_rgb);
+                           d_rec_b.as<float>(), sb, region_size, n_regions, stats, ev, ev_trace, ev_shade, aov ? &ap : nullptr, aov_rgb, packed);
         if (rc) return rc;
         const uint32_t nb = (uint32_t) (ps.second - ps.first);
         // tile of film pixels per thread: 1 wide (adjacent lanes read adjacent records -> full cache lines),
@@ -838,7 +889,7 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
         const int tiles_x = (bs + 2 * border + tile_x - 1) / tile_x, tiles_y = (bs + 2 * border + tile_y - 1) / tile_y;
         const uint64_t threads = (uint64_t) nb * tiles_x * tiles_y;
         hipEvent_t a = ev.get(), b = ev.get();
-        (void) hipEventRecord(a, stream);
+        if (a) (void) hipEventRecord(a, stream);
         const dim3 rgrid((uint32_t) ((threads + MSK_BLOCK - 1) / MSK_BLOCK));
 #define MSK_RESOLVE(TX, TY) hipLaunchKernelGGL((k_resolve_blocks<TX, TY>), rgrid, dim3(MSK_BLOCK), 0, stream, sc->dev,      \
                            d_blocks.as<BlockInfo>() + ps.first, nb, res_rec, d_rec_b.as<float>(), spp_owned,               \
@@ -848,7 +899,12 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
             const uint32_t slot = g == 0 ? 0 : (g - 1 < (aov ? aov->n_groups : 0u) ? g - 1 : MSK_MAX_AOV_GROUPS);
             const float4 *res_rec = g == 0 ? d_rec_a.as<float4>() : ws.aov_rec[slot].as<float4>();
             float *res_buf = g == 0 ? d_block_buf.as<float>() : ws.aov_block_buf[slot].as<float>();
-            if (tile_x == 2 && tile_y == 2) MSK_RESOLVE(2, 2);
+            if (packed) {
+                if (ws.n_bands)
+                    hipLaunchKernelGGL(k_resolve_rows, dim3(ws.n_bands), dim3(MSK_WAVE), 0, stream, sc->dev, d_blocks.as<BlockInfo>() + ps.first,
+                                       ws.bands.as<RowBand>(), ws.n_bands, res_rec, (const uint32_t *) d_rec_b.as<float>(), spp_owned, res_buf, buf_stride);
+            }
+            else if (tile_x == 2 && tile_y == 2) MSK_RESOLVE(2, 2);
             else if (tile_x == 2 && tile_y == 3) MSK_RESOLVE(2, 3);
             else if (tile_x == 2 && tile_y == 4) MSK_RESOLVE(2, 4);
             else if (tile_x == 1 && tile_y == 1) MSK_RESOLVE(1, 1);
@@ -858,14 +914,14 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
             else MSK_RESOLVE(1, 4);
         }
 #undef MSK_RESOLVE
-        (void) hipEventRecord(b, stream);
+        if (b) (void) hipEventRecord(b, stream);
         ev_resolve.push_back({a, b});
         HIP_TRY(ctx, hipStreamSynchronize(stream));   // d_pix / records are reused by the next pass
         if (stats) stats->passes++;
     }
     {
         hipEvent_t a = ev.get(), b = ev.get();
-        (void) hipEventRecord(a, stream);
+        if (a) (void) hipEventRecord(a, stream);
         for (uint32_t g = 0; g <= n_aov_bufs; ++g) {
             const uint32_t slot = g == 0 ? 0 : (g - 1 < (aov ? aov->n_groups : 0u) ? g - 1 : MSK_MAX_AOV_GROUPS);
             FilmOut fo;
@@ -875,14 +931,14 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
                                sc->dev, d_blocks.as<BlockInfo>(), d_block_of.as<int32_t>(), d_spiral.as<uint32_t>(), nbx, nby, bs,
                                g == 0 ? d_block_buf.as<float>() : ws.aov_block_buf[slot].as<float>(), buf_stride, fo);
         }
-        (void) hipEventRecord(b, stream);
+        if (b) (void) hipEventRecord(b, stream);
         ev_resolve.push_back({a, b});
     }
-    (void) hipEventRecord(t_end, stream);
+    if (t_end) (void) hipEventRecord(t_end, stream);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     if (stats) {
-        (void) hipEventElapsedTime(&stats->ms_total, t_begin, t_end);
+        if (t_begin && t_end) (void) hipEventElapsedTime(&stats->ms_total, t_begin, t_end);
         sum_events(ev_resolve, &stats->ms_resolve);      // trace / shade were summed group by group in run_wavefront
     }
     return MSK_OK;
@@ -976,7 +1032,7 @@ extern "C" int msk_gpu_sample_pixels(msk_scene *scene, const msk_render_params *
     for (uint64_t i = 0; i < n_pixels; ++i) {
         const int x = pixels[2 * i], y = pixels[2 * i + 1];
         if (x < 0 || y < 0 || x >= W || y >= H) return fail(ctx, MSK_ERR_INVALID_ARG, "pixel (%d,%d) outside the %dx%d film", x, y, W, H);
-        pix[i] = make_uint4((uint32_t) (y * W + x), (uint32_t) i, 0u, (uint32_t) n_pixels);   // one pseudo-block
+        pix[i] = make_uint4((uint32_t) (y * W + x), 0u, 0u, 0u);       // unpacked records: only the film index is read
     }
     if (n_pixels == 0) return MSK_OK;
     msk_render_params p = *prm; p.sample_first = 0; p.sample_stride = 1;

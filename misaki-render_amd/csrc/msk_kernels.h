@@ -104,9 +104,11 @@ struct PassParams {
     uint64_t seed;
     uint32_t spp_owned, sample_first, sample_stride;
     int32_t rr_depth, max_depth, hide_emitters;
-    const uint4 *pix_table;       // pass pixel j -> {film index y*W+x, rec0 lo, rec0 hi, pixels in its block}
-    float4 *rec_a;                // per sample {X,Y,Z,pos.x}; record of (j, si) = rec0(j) + si * npix(j):
-    float *rec_b;                 // per sample pos.y           i.e. [block][sample][pixel], pixel fastest
+    const uint4 *pix_table;       // pass pixel j -> {film index y*W+x, x | y << 16 inside its block, block off_x - border, off_y - border (int bits)}
+    float4 *rec_a;                // per sample {X,Y,Z,pos.x}; the record of (j, si) is j * spp_owned + si: [block][pixel][sample], a pixel's
+    float *rec_b;                 // per sample pos.y           samples contiguous (the film replay streams them in that order)
+    uint32_t packed;              // 1: the records carry the sample's filter weights instead of its position (SampleWeights below):
+                                  //    rec_a.w = x word, rec_b = y word
     uint32_t region_size, n_regions;      // n_regions: all regions of the pass (the samples' static partition is over all of them)
     uint32_t region_first, region_count;  // the regions this launch covers (the pool's halves run on two streams)
     uint32_t trace_split;         // waves per region in k_trace (each takes every trace_split-th chunk); shading is one wave per region
@@ -119,7 +121,7 @@ struct PassParams {
 #define MSK_MAX_AOV_GROUPS 8
 struct AovParams {
     uint32_t n_groups;
-    float4 *rec[MSK_MAX_AOV_GROUPS];       // per sample {a, b, c, pos.x}, same indexing as PassParams::rec_a
+    float4 *rec[MSK_MAX_AOV_GROUPS];       // per sample {a, b, c, pos.x or the x weight word}, same indexing as PassParams::rec_a
     uint32_t code[MSK_MAX_AOV_GROUPS];     // three 8-bit selectors: 0 none, 1 t, 2-4 p, 5-6 uv, 7-9 n, 10-12 sh.n
 };
 struct FilmOut { float *film; int32_t stride; int32_t ch[5]; };   // block channel c -> film channel ch[c] (or -1)
@@ -871,6 +873,39 @@ MSK_DEV void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ImageBlock::put's per-sample part (imageblock.cpp:84-96), done once per sample instead of once per (sample, target pixel):
+// a sample of block pixel (lx, ly) can only reach the five target columns lx .. lx + 4 and rows ly .. ly + 4 of the bordered
+// block (border = 2: the default Gaussian, radius 2).  Field i (6 bits) of the x word is the index into the filter's
+// discretisation (rfilter.h:13-16: min(int(|t - pos| * scale), 32)) of target column lx + i, or MSK_W_OUT when that column is
+// outside [ceil(pos - r), floor(pos + r)]; the y word likewise.  Same fp32 expressions as the replay kernels evaluate per target.
+#define MSK_W_OUT 33u                       /* lut[33] = 0 in the replay kernel's copy of the table */
+#define MSK_W_FIELDS 0x3fffffffu
+#define MSK_W_NONFINITE 0x40000000u         /* bit 30 of the x word: a value of this record is inf / nan (see k_resolve_rows) */
+struct SampleWeights { uint32_t x, y; };
+MSK_DEV uint32_t weight_word(float pos, uint32_t l, float radius, float scale) {
+    const float lo = pos - radius, hi = pos + radius;
+    uint32_t w = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const float ft = (float) (l + (uint32_t) i);
+        const int idx = min((int) fabsf((ft - pos) * scale), 32);
+        w |= ((ft >= lo && ft <= hi) ? (uint32_t) idx : MSK_W_OUT) << (6 * i);
+    }
+    return w;
+}
+MSK_DEV SampleWeights sample_weights(const DeviceScene &sc, uint4 pt, float px, float py) {
+    // imageblock.cpp:84-85: pos - 0.5 - (offset - border)
+    const float bx = px - 0.5f - (float) (int) pt.z, by = py - 0.5f - (float) (int) pt.w;
+    SampleWeights r;
+    r.x = weight_word(bx, pt.y & 0xffffu, sc.filter_radius, sc.filter_scale);
+    r.y = weight_word(by, pt.y >> 16, sc.filter_radius, sc.filter_scale);
+    return r;
+}
+MSK_DEV uint32_t nonfinite_flag(float a, float b, float c) {
+    const bool fin = fabsf(a) < MSK_INF_F && fabsf(b) < MSK_INF_F && fabsf(c) < MSK_INF_F;      // false for nan too
+    return fin ? 0u : MSK_W_NONFINITE;
+}
+
 // render_sample's tail for one finished path (integrator.cpp:115-125): ray weight, XYZ, film position -> sample record
 template <bool DIFFUSE_ONLY>
 MSK_DEV void emit_record(const DeviceScene &sc, const SceneTables &tb, const PassParams &pp, spec wl, spec res, uint32_t j,
@@ -884,16 +919,22 @@ MSK_DEV void emit_record(const DeviceScene &sc, const SceneTables &tb, const Pas
     const uint64_t key = counter_key(pp.seed, pix, pp.sample_first + si * pp.sample_stride);
     const f2 jit = counter_pair(key, 0);
     const float px = (float) (pix % (uint32_t) sc.width) + jit.x, py = (float) (pix / (uint32_t) sc.width) + jit.y;
-    const uint4 pt = pp.pix_table[j];
-    const size_t r = (((size_t) pt.z << 32) | pt.y) + (size_t) si * pt.w;
-    pp.rec_a[r] = make_float4(X, Y, Z, px);
-    pp.rec_b[r] = py;
+    const size_t r = (size_t) j * pp.spp_owned + si;
+    float wx = px, wy = py;
+    if (pp.packed) {
+        const uint4 pt = pp.pix_table[j];
+        const SampleWeights sw = sample_weights(sc, pt, px, py);
+        wx = __uint_as_float(sw.x | nonfinite_flag(X, Y, Z)); wy = __uint_as_float(sw.y);
+    }
+    pp.rec_a[r] = make_float4(X, Y, Z, wx);
+    pp.rec_b[r] = wy;
     if (!DIFFUSE_ONLY && pp.aov_rgb) {                             // aov.cpp:124-136: the sample before ray_weight
         float x0, y0, z0;
         spectrum_to_xyz(tb.cie, res, wl, &x0, &y0, &z0);
-        pp.aov_rgb[r] = make_float4(3.240479f * x0 + (-1.537150f * y0 + -0.498535f * z0),
-                                    -0.969256f * x0 + (1.875991f * y0 + 0.041556f * z0),
-                                    0.055648f * x0 + (-0.204043f * y0 + 1.057311f * z0), px);
+        const float R = 3.240479f * x0 + (-1.537150f * y0 + -0.498535f * z0), G = -0.969256f * x0 + (1.875991f * y0 + 0.041556f * z0),
+                    B = 0.055648f * x0 + (-0.204043f * y0 + 1.057311f * z0);
+        if (pp.packed) wx = __uint_as_float((__float_as_uint(wx) & MSK_W_FIELDS) | nonfinite_flag(R, G, B));
+        pp.aov_rgb[r] = make_float4(R, G, B, wx);
     }
 }
 
@@ -1094,7 +1135,17 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
                     const float sample1 = DIFFUSE_ONLY ? 0.f : counter_pair(key, pb + 1).x;
                     const spec bsdf_val = bsdf_sample<DIFFUSE_ONLY>(bs, wi_s, sample1, u2, wl, refl, &wo_l, &bs_pdf, &bs_eta, &ok);
                     if (!ok) {
-                        alive = false;         // failed sample: zero direction, the reference's ray misses (no NEE either)
+                        // failed sample: zero direction, the reference's ray misses and the loop ends (path.cpp:89-97) — but the
+                        // NEE term of this bounce was added before the sample (path.cpp:60-66).  diffuse / roughconductor fail
+                        // only with cos_i <= 0, where that term is 0; roughdielectric can fail (sample_ggx pdf == 0) with a
+                        // non-zero one: the slot then lives one more iteration, dead, for its shadow ray.
+                        if (!has_shadow) alive = false;
+                        else {
+                            thr = splat(0.f);
+                            new_o = make_float4(si.p.x, si.p.y, si.p.z, (1.f + max_abs(si.p)) * MSK_RAY_EPS_F);
+                            new_d = make_float4(0.f, 0.f, 0.f, -0.f);
+                            depth += 1;
+                        }
                     } else {
                         if (flipped) wo_l.z = -wo_l.z;
                         const f3 wo = si.sh.to_world(wo_l);
@@ -1251,9 +1302,11 @@ k_aov_primary(DeviceScene sc, PathState st, PassParams pp, AovParams ap) {
         }
         const uint32_t pix = id.z;
         const uint64_t key = counter_key(pp.seed, pix, pp.sample_first + id.y * pp.sample_stride);
-        const float px = (float) (pix % (uint32_t) sc.width) + counter_pair(key, 0).x;
-        const uint4 pt = pp.pix_table[id.x];
-        const size_t r = (((size_t) pt.z << 32) | pt.y) + (size_t) id.y * pt.w;
+        const f2 jit = counter_pair(key, 0);
+        const float px = (float) (pix % (uint32_t) sc.width) + jit.x;
+        const size_t r = (size_t) id.x * pp.spp_owned + id.y;
+        uint32_t wxw = 0;
+        if (pp.packed) wxw = sample_weights(sc, pp.pix_table[id.x], px, (float) (pix / (uint32_t) sc.width) + jit.y).x;
         for (uint32_t g = 0; g < ap.n_groups; ++g) {
             const uint32_t code = ap.code[g];
             float o[3];
@@ -1265,7 +1318,7 @@ k_aov_primary(DeviceScene sc, PathState st, PassParams pp, AovParams ap) {
                 for (int q = 1; q < 13; ++q) x = sel == (uint32_t) q ? val[q] : x;
                 o[k] = x;
             }
-            ap.rec[g][r] = make_float4(o[0], o[1], o[2], px);
+            ap.rec[g][r] = make_float4(o[0], o[1], o[2], pp.packed ? __uint_as_float(wxw | nonfinite_flag(o[0], o[1], o[2])) : px);
         }
     }
 }
@@ -1337,18 +1390,17 @@ k_resolve_blocks(DeviceScene sc, const BlockInfo *blocks, uint32_t n_blocks, con
     const int y_lo = max(0, ty0 - border - span), y_hi = min(b.size_y - 1, ty0 + TY - 1 - border + span);
     const int x_lo = max(0, tx0 - border - span), x_hi = min(b.size_x - 1, tx0 + TX - 1 - border + span);
     const float offx = (float) (b.off_x - border), offy = (float) (b.off_y - border);
-    const uint32_t npix = (uint32_t) (b.size_x * b.size_y);
     constexpr int U = 8;            // records in flight per lane
     for (int y = y_lo; y <= y_hi; ++y)
         for (int x = x_lo; x <= x_hi; ++x) {
-            const size_t r0 = (size_t) b.pixel_base * spp_owned + (uint32_t) (y * b.size_x + x);
+            const size_t r0 = ((size_t) b.pixel_base + (uint32_t) (y * b.size_x + x)) * spp_owned;
             for (uint32_t s0 = 0; s0 < spp_owned; s0 += U) {
                 float4 ra[U]; float rb[U];
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
                     const uint32_t s = min(s0 + (uint32_t) k, spp_owned - 1);
-                    ra[k] = rec_a[r0 + (size_t) s * npix];
-                    rb[k] = rec_b[r0 + (size_t) s * npix];
+                    ra[k] = rec_a[r0 + s];
+                    rb[k] = rec_b[r0 + s];
                 }
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
@@ -1394,6 +1446,151 @@ k_resolve_blocks(DeviceScene sc, const BlockInfo *blocks, uint32_t n_blocks, con
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_resolve_rows: the same replay for the default filter (border 2, radius 2) from records that carry their weights
+// (SampleWeights), reading each record ~3 times instead of ~12.
+//
+// Order is what makes the film bit-identical to the scalar loop: a target pixel must receive its source pixels in row-major
+// order and each source pixel's samples in sample order (integrator.cpp:89-98 + imageblock.cpp:98-110).  Row-major order means
+// that while source row r is being replayed exactly five target rows are live (r .. r + 4 of the bordered block) and all of them
+// take row r's samples — so one wave sweeps a band of target rows DOWN the block: 12 x 5 lanes, a lane owns three adjacent
+// target columns of one live row (lane row = target row mod 5; a finished row's lanes move on to the row five below).  A round
+// = one source row: for each of the seven source columns a lane's three targets can see (kx, ascending), the wave stages 64
+// samples of that column for all 12 lane columns in LDS — one coalesced kilobyte per column, shared by the five lane rows —
+// and every lane adds them to the targets in reach (a static set per kx) in sample order.  Re-read factor: 7/3 in x (a source
+// column is staged for up to three lane columns at different kx) x (rounds / source rows) in y, against 5 x 7/3 before.
+// A target's additions are exactly ImageBlock::put's: weight = lut[ix] * lut[iy] (imageblock.cpp:103), += weight * value
+// (:106); targets outside the sample's footprint add nothing.
+// ------------------------------------------------------------------------------------------
+struct RowBand { uint32_t block, row_begin, row_end, pad; };      // target rows [row_begin, row_end) of the bordered block
+#define MSK_RR_COLS 12            /* lane columns: 3 target columns each -> bordered width <= 36 (block size <= 32) */
+#define MSK_RR_CHUNK 64           /* samples staged per step */
+#define MSK_RR_STRIDE 65          /* slot stride in records: consecutive slots land on different LDS banks */
+
+template <bool SAFE>
+MSK_DEV void rr_accumulate(const float4 *la, const uint32_t *lb, const float *lut, uint32_t shy, int kx, float (&acc)[3][4]) {
+    // in reach of source column 3 lx - 4 + kx: target j of this lane with field f = j + 4 - kx in 0..4
+#pragma unroll 4
+    for (int s = 0; s < MSK_RR_CHUNK; ++s) {
+        const float4 ra = la[s];
+        const uint32_t wyw = lb[s], wxw = __float_as_uint(ra.w);
+        const uint32_t iy = (wyw >> shy) & 63u;
+        const float wy = lut[iy];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int f = j + 4 - kx;
+            if (f < 0 || f > 4) continue;
+            const uint32_t ix = (wxw >> (6 * f)) & 63u;
+            const float w = lut[ix] * wy;
+            if (SAFE) {
+                // a record with inf / nan values: the scalar loop never multiplies them for targets outside the footprint
+                if (ix == MSK_W_OUT || iy == MSK_W_OUT) continue;
+            }
+            acc[j][0] += w * ra.x; acc[j][1] += w * ra.y; acc[j][2] += w * ra.z; acc[j][3] += w * 1.f;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(MSK_WAVE)
+k_resolve_rows(DeviceScene sc, const BlockInfo *blocks, const RowBand *bands, uint32_t n_bands, const float4 *rec_a,
+               const uint32_t *rec_b, uint32_t spp_owned, float *block_buf, uint32_t buf_stride) {
+    __shared__ float4 lds_a[MSK_RR_COLS * MSK_RR_STRIDE];
+    __shared__ uint32_t lds_b[MSK_RR_COLS * MSK_RR_STRIDE];
+    __shared__ float lut[36];
+    const uint32_t lane = threadIdx.x;
+    if (lane < 36) lut[lane] = lane < 33 ? sc.lut[lane] : 0.f;
+    if (blockIdx.x >= n_bands) return;
+    const RowBand band = bands[blockIdx.x];
+    const BlockInfo b = blocks[band.block];
+    const int lx = (int) (lane % MSK_RR_COLS), lr = (int) (lane / MSK_RR_COLS);      // lanes 60..63 (lr = 5) only help staging
+    const int sx_t = b.size_x + 4;                                                    // bordered width
+    const int r_begin = max(0, (int) band.row_begin - 4), r_end = min(b.size_y - 1, (int) band.row_end - 1);
+    float acc[3][4];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[j][c] = 0.f;
+    const float4 *my_a = lds_a + lx * MSK_RR_STRIDE;
+    const uint32_t *my_b = lds_b + lx * MSK_RR_STRIDE;
+    const uint32_t n_chunks = (spp_owned + MSK_RR_CHUNK - 1) / MSK_RR_CHUNK;
+    // One step = (source row r, source-column offset kx, chunk c of 64 samples), in exactly that nesting order.  The records
+    // of step i + 1 are fetched into registers while step i is accumulated out of LDS (one wave owns its LDS: the only
+    // synchronisation is between the lanes of this wave).
+    float4 pa[MSK_RR_COLS]; uint32_t pb[MSK_RR_COLS];
+    bool p_lane_ok = false; int p_kx = 0;
+    // Unconditional loads from clamped addresses (a conditional load would have to be waited for at the join, one column at a
+    // time); what is not a real record — a column outside the block, a sample index past the last one — is replaced when the
+    // step is stored to LDS.
+    auto fetch = [&](int r, int kx, uint32_t c) {
+        const uint32_t sidx = c * MSK_RR_CHUNK + lane;
+        p_lane_ok = sidx < spp_owned; p_kx = kx;
+        const size_t row_rec = ((size_t) b.pixel_base + (size_t) r * b.size_x) * spp_owned + min(sidx, spp_owned - 1u);
+#pragma unroll
+        for (int q = 0; q < MSK_RR_COLS; ++q) {
+            const int sx = min(max(3 * q - 4 + kx, 0), b.size_x - 1);
+            const size_t rr = row_rec + (size_t) sx * spp_owned;
+            pa[q] = rec_a[rr]; pb[q] = rec_b[rr];
+        }
+    };
+    int r = r_begin, kx = 0; uint32_t c = 0;
+    if (r_begin > r_end) return;
+    fetch(r, kx, c);
+    wave_sync();                                              // lut
+    int m = 0, ty = 0; uint32_t shy = 0; bool mine = false;
+    while (r <= r_end) {
+        if (kx == 0 && c == 0) {                              // a round begins
+            m = ((lr - r) % 5 + 5) % 5;                       // this lane's live target row is r + m; its y field is m
+            ty = r + m;
+            mine = lr < 5 && ty >= (int) band.row_begin && ty < (int) band.row_end;
+            shy = 6u * (uint32_t) m;
+            if (m == 4 || r == r_begin) {                     // a new target row starts here
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) acc[j][ch] = 0.f;
+            }
+        }
+        // ---- this step's records: registers -> LDS; a flagged record anywhere sends the whole step down the exact path
+        uint32_t flags = 0;
+#pragma unroll
+        for (int q = 0; q < MSK_RR_COLS; ++q) {
+            const int sx = 3 * q - 4 + p_kx;
+            float4 va = pa[q]; uint32_t vb = pb[q];
+            if (!(p_lane_ok && sx >= 0 && sx < b.size_x)) {   // no such column / sample: zero weights (five fields of MSK_W_OUT), zero values
+                va = make_float4(0.f, 0.f, 0.f, __uint_as_float(MSK_W_OUT * 0x1041041u));
+                vb = MSK_W_OUT * 0x1041041u;
+            }
+            flags |= __float_as_uint(va.w);
+            lds_a[q * MSK_RR_STRIDE + lane] = va;
+            lds_b[q * MSK_RR_STRIDE + lane] = vb;
+        }
+        const bool safe = __ballot((flags & MSK_W_NONFINITE) != 0u) != 0ull;
+        wave_sync();
+        // ---- the next step's records, in flight while this one is accumulated
+        const int kx_now = kx;
+        const bool round_ends = kx == 6 && c + 1 == n_chunks;
+        const int r_now = r;
+        if (++c == n_chunks) { c = 0; if (++kx == 7) { kx = 0; ++r; } }
+        fetch(min(r, r_end), kx, c);                         // (past the last step: a valid address, never stored)
+        switch (kx_now) {
+#define MSK_RR_CASE(K) case K: if (safe) rr_accumulate<true>(my_a, my_b, lut, shy, K, acc); else rr_accumulate<false>(my_a, my_b, lut, shy, K, acc); break;
+            MSK_RR_CASE(0) MSK_RR_CASE(1) MSK_RR_CASE(2) MSK_RR_CASE(3) MSK_RR_CASE(4) MSK_RR_CASE(5) MSK_RR_CASE(6)
+#undef MSK_RR_CASE
+        }
+        wave_sync();                                          // every lane has read this step before the next one is stored
+        // ---- a target row is complete after its last source row (ty == r), or when the block's source rows end
+        if (round_ends && mine && (m == 0 || r_now == r_end)) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int tx = 3 * lx + j;
+                if (tx >= sx_t) continue;
+                float *o = block_buf + (size_t) b.slot * buf_stride + (size_t) (ty * sx_t + tx) * 5;
+                o[0] = acc[j][0]; o[1] = acc[j][1]; o[2] = acc[j][2]; o[3] = acc[j][3]; o[4] = acc[j][3];
+            }
+        }
+    }
+}
+
 // Film::put for every block in spiral order (imageblock.cpp:36-53,133-173; D6: ascending block id).
 // One thread per film pixel; block_of[by*nbx+bx] = slot of that block's buffer or -1 (not rendered
 // by this rank), spiral_id gives the order.
@@ -1434,12 +1631,12 @@ k_film_put(DeviceScene sc, const BlockInfo *blocks, const int32_t *block_of, con
     for (int c = 0; c < 5; ++c) if (out.ch[c] >= 0) o[out.ch[c]] = acc[c];
 }
 
-// records of listed pixels ([sample][pixel] on device) -> {X,Y,Z} + position, [pixel][sample]
+// records of listed pixels (unpacked: they carry positions) -> {X,Y,Z} + position, [pixel][sample] on both sides
 __global__ void k_export_records(const float4 *rec_a, const float *rec_b, uint64_t n_pix, uint32_t spp, float *out_xyz,
                                  float *out_pos) {
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pix * spp) return;
-    const uint64_t s = i / n_pix, p = i % n_pix, o = p * spp + s;
+    const uint64_t o = i;
     const float4 a = rec_a[i];
     out_xyz[o * 3] = a.x; out_xyz[o * 3 + 1] = a.y; out_xyz[o * 3 + 2] = a.z;
     if (out_pos) { out_pos[o * 2] = a.w; out_pos[o * 2 + 1] = rec_b[i]; }

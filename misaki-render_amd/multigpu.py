@@ -54,9 +54,17 @@ def balanced_shares(spp_total, step_ms):
 
 
 def reduce_film(film, dist=None, dst=0):
-    """Sum the per-rank films onto rank `dst` (in place).  film: torch tensor [H, W, 5] float32."""
+    """Sum the per-rank films onto rank `dst` (in place).  film: torch tensor [H, W, 5] float32.
+
+    Returns when the reduce has finished with `film` on this rank.  The back end renders on its own HIP stream
+    (msk_gpu_render_device with hip_stream = NULL returns when the film is complete), the collective runs on the process
+    group's stream behind torch's current stream: without the wait below the next render could overwrite `film` while
+    the reduce still reads it."""
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
+        if film.is_cuda:
+            import torch
+            torch.cuda.current_stream(film.device).synchronize()
     return film
 
 
