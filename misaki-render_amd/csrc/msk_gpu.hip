@@ -901,7 +901,7 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
             float *res_buf = g == 0 ? d_block_buf.as<float>() : ws.aov_block_buf[slot].as<float>();
             if (packed) {
                 if (ws.n_bands)
-                    hipLaunchKernelGGL(k_resolve_rows, dim3(ws.n_bands), dim3(MSK_WAVE), 0, stream, sc->dev, d_blocks.as<BlockInfo>() + ps.first,
+                    hipLaunchKernelGGL(k_resolve_rows, dim3(ws.n_bands), dim3(MSK_WAVE), (size_t) env_u32("MSK_RESOLVE_PAD_LDS_KB", 0) * 1024, stream, sc->dev, d_blocks.as<BlockInfo>() + ps.first,
                                        ws.bands.as<RowBand>(), ws.n_bands, res_rec, (const uint32_t *) d_rec_b.as<float>(), spp_owned, res_buf, buf_stride);
             }
             else if (tile_x == 2 && tile_y == 2) MSK_RESOLVE(2, 2);

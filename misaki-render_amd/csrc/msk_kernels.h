@@ -1464,30 +1464,55 @@ k_resolve_blocks(DeviceScene sc, const BlockInfo *blocks, uint32_t n_blocks, con
 // ------------------------------------------------------------------------------------------
 struct RowBand { uint32_t block, row_begin, row_end, pad; };      // target rows [row_begin, row_end) of the bordered block
 #define MSK_RR_COLS 12            /* lane columns: 3 target columns each -> bordered width <= 36 (block size <= 32) */
-#define MSK_RR_CHUNK 64           /* samples staged per step */
-#define MSK_RR_STRIDE 65          /* slot stride in records: consecutive slots land on different LDS banks */
+#ifndef MSK_RR_CHUNK
+#define MSK_RR_CHUNK 64           /* samples staged per step (<= 64: one per lane) */
+#endif
+#define MSK_RR_STRIDE (MSK_RR_CHUNK + 1)   /* slot stride in records: consecutive slots land on different LDS banks */
+#ifndef MSK_RR_G
+#define MSK_RR_G 8                 /* samples per accumulate group */
+#endif
 
+typedef float msk_f2 __attribute__((ext_vector_type(2)));      // pairs for v_pk_mul_f32 / v_pk_add_f32: two IEEE operations each
 template <bool SAFE>
-MSK_DEV void rr_accumulate(const float4 *la, const uint32_t *lb, const float *lut, uint32_t shy, int kx, float (&acc)[3][4]) {
-    // in reach of source column 3 lx - 4 + kx: target j of this lane with field f = j + 4 - kx in 0..4
-#pragma unroll 4
-    for (int s = 0; s < MSK_RR_CHUNK; ++s) {
-        const float4 ra = la[s];
-        const uint32_t wyw = lb[s], wxw = __float_as_uint(ra.w);
-        const uint32_t iy = (wyw >> shy) & 63u;
-        const float wy = lut[iy];
+MSK_DEV void rr_accumulate(const float4 *la, const uint2 *lw, const float *lut, uint32_t shy, int kx, msk_f2 (&acc)[3][2]) {
+    // in reach of source column 3 lx - 4 + kx: target j of this lane with field f = j + 4 - kx in 0..4.
+    // Groups of MSK_RR_G samples, the next group's records read from LDS while this one is accumulated (a wave often has its
+    // SIMD to itself here: nothing else would cover the LDS round trips record -> index -> weight).
+    // A staged record is {X, Y, Z, 1} + {x word, y word}: weight * {X, Y} and weight * {Z, 1} are two packed multiplies and the
+    // four channel sums two packed adds — the same four products and four sums as imageblock.cpp:106, channel by channel.
+    constexpr int G = MSK_RR_G;
+    float4 ra[G]; uint2 rw[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) { ra[k] = la[k]; rw[k] = lw[k]; }
+#pragma unroll 1
+    for (int s0 = 0; s0 < MSK_RR_CHUNK; s0 += G) {
+        float4 na[G]; uint2 nw[G];
+        const int s1 = (s0 + G < MSK_RR_CHUNK) ? s0 + G : s0;          // (the last group re-reads itself: no branch in the loop)
+#pragma unroll
+        for (int k = 0; k < G; ++k) { na[k] = la[s1 + k]; nw[k] = lw[s1 + k]; }
+        float wy[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) wy[k] = lut[(rw[k].y >> shy) & 63u];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int f = j + 4 - kx;
             if (f < 0 || f > 4) continue;
-            const uint32_t ix = (wxw >> (6 * f)) & 63u;
-            const float w = lut[ix] * wy;
-            if (SAFE) {
-                // a record with inf / nan values: the scalar loop never multiplies them for targets outside the footprint
-                if (ix == MSK_W_OUT || iy == MSK_W_OUT) continue;
+            float wx[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) wx[k] = lut[(rw[k].x >> (6 * f)) & 63u];
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const float w = wx[k] * wy[k];
+                if (SAFE) {
+                    // a record with inf / nan values: the scalar loop never multiplies them for targets outside the footprint
+                    if (((rw[k].x >> (6 * f)) & 63u) == MSK_W_OUT || ((rw[k].y >> shy) & 63u) == MSK_W_OUT) continue;
+                }
+                const msk_f2 ww = {w, w}, xy = {ra[k].x, ra[k].y}, z1 = {ra[k].z, ra[k].w};
+                acc[j][0] += ww * xy; acc[j][1] += ww * z1;
             }
-            acc[j][0] += w * ra.x; acc[j][1] += w * ra.y; acc[j][2] += w * ra.z; acc[j][3] += w * 1.f;
         }
+#pragma unroll
+        for (int k = 0; k < G; ++k) { ra[k] = na[k]; rw[k] = nw[k]; }
     }
 }
 
@@ -1495,7 +1520,7 @@ __global__ void __launch_bounds__(MSK_WAVE)
 k_resolve_rows(DeviceScene sc, const BlockInfo *blocks, const RowBand *bands, uint32_t n_bands, const float4 *rec_a,
                const uint32_t *rec_b, uint32_t spp_owned, float *block_buf, uint32_t buf_stride) {
     __shared__ float4 lds_a[MSK_RR_COLS * MSK_RR_STRIDE];
-    __shared__ uint32_t lds_b[MSK_RR_COLS * MSK_RR_STRIDE];
+    __shared__ uint2 lds_w[MSK_RR_COLS * MSK_RR_STRIDE];
     __shared__ float lut[36];
     const uint32_t lane = threadIdx.x;
     if (lane < 36) lut[lane] = lane < 33 ? sc.lut[lane] : 0.f;
@@ -1505,13 +1530,11 @@ k_resolve_rows(DeviceScene sc, const BlockInfo *blocks, const RowBand *bands, ui
     const int lx = (int) (lane % MSK_RR_COLS), lr = (int) (lane / MSK_RR_COLS);      // lanes 60..63 (lr = 5) only help staging
     const int sx_t = b.size_x + 4;                                                    // bordered width
     const int r_begin = max(0, (int) band.row_begin - 4), r_end = min(b.size_y - 1, (int) band.row_end - 1);
-    float acc[3][4];
+    msk_f2 acc[3][2];                                         // per target {X, Y} {Z, W}
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[j][c] = 0.f;
+    for (int j = 0; j < 3; ++j) { acc[j][0] = msk_f2{0.f, 0.f}; acc[j][1] = msk_f2{0.f, 0.f}; }
     const float4 *my_a = lds_a + lx * MSK_RR_STRIDE;
-    const uint32_t *my_b = lds_b + lx * MSK_RR_STRIDE;
+    const uint2 *my_w = lds_w + lx * MSK_RR_STRIDE;
     const uint32_t n_chunks = (spp_owned + MSK_RR_CHUNK - 1) / MSK_RR_CHUNK;
     // One step = (source row r, source-column offset kx, chunk c of 64 samples), in exactly that nesting order.  The records
     // of step i + 1 are fetched into registers while step i is accumulated out of LDS (one wave owns its LDS: the only
@@ -1522,8 +1545,8 @@ k_resolve_rows(DeviceScene sc, const BlockInfo *blocks, const RowBand *bands, ui
     // time); what is not a real record — a column outside the block, a sample index past the last one — is replaced when the
     // step is stored to LDS.
     auto fetch = [&](int r, int kx, uint32_t c) {
-        const uint32_t sidx = c * MSK_RR_CHUNK + lane;
-        p_lane_ok = sidx < spp_owned; p_kx = kx;
+        const uint32_t sidx = c * MSK_RR_CHUNK + lane % MSK_RR_CHUNK;      // (lanes past the chunk repeat addresses: no extra traffic)
+        p_lane_ok = sidx < spp_owned && lane < MSK_RR_CHUNK; p_kx = kx;
         const size_t row_rec = ((size_t) b.pixel_base + (size_t) r * b.size_x) * spp_owned + min(sidx, spp_owned - 1u);
 #pragma unroll
         for (int q = 0; q < MSK_RR_COLS; ++q) {
@@ -1545,12 +1568,11 @@ k_resolve_rows(DeviceScene sc, const BlockInfo *blocks, const RowBand *bands, ui
             shy = 6u * (uint32_t) m;
             if (m == 4 || r == r_begin) {                     // a new target row starts here
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-#pragma unroll
-                    for (int ch = 0; ch < 4; ++ch) acc[j][ch] = 0.f;
+                for (int j = 0; j < 3; ++j) { acc[j][0] = msk_f2{0.f, 0.f}; acc[j][1] = msk_f2{0.f, 0.f}; }
             }
         }
-        // ---- this step's records: registers -> LDS; a flagged record anywhere sends the whole step down the exact path
+        // ---- this step's records: registers -> LDS as {X, Y, Z, 1} + {x word, y word}; a flagged record anywhere sends the
+        //      whole step down the exact path
         uint32_t flags = 0;
 #pragma unroll
         for (int q = 0; q < MSK_RR_COLS; ++q) {
@@ -1560,9 +1582,12 @@ k_resolve_rows(DeviceScene sc, const BlockInfo *blocks, const RowBand *bands, ui
                 va = make_float4(0.f, 0.f, 0.f, __uint_as_float(MSK_W_OUT * 0x1041041u));
                 vb = MSK_W_OUT * 0x1041041u;
             }
-            flags |= __float_as_uint(va.w);
-            lds_a[q * MSK_RR_STRIDE + lane] = va;
-            lds_b[q * MSK_RR_STRIDE + lane] = vb;
+            const uint32_t wxw = __float_as_uint(va.w);
+            flags |= wxw;
+            if (MSK_RR_CHUNK == MSK_WAVE || lane < MSK_RR_CHUNK) {
+                lds_a[q * MSK_RR_STRIDE + lane] = make_float4(va.x, va.y, va.z, 1.f);
+                lds_w[q * MSK_RR_STRIDE + lane] = make_uint2(wxw, vb);
+            }
         }
         const bool safe = __ballot((flags & MSK_W_NONFINITE) != 0u) != 0ull;
         wave_sync();
@@ -1573,7 +1598,7 @@ k_resolve_rows(DeviceScene sc, const BlockInfo *blocks, const RowBand *bands, ui
         if (++c == n_chunks) { c = 0; if (++kx == 7) { kx = 0; ++r; } }
         fetch(min(r, r_end), kx, c);                         // (past the last step: a valid address, never stored)
         switch (kx_now) {
-#define MSK_RR_CASE(K) case K: if (safe) rr_accumulate<true>(my_a, my_b, lut, shy, K, acc); else rr_accumulate<false>(my_a, my_b, lut, shy, K, acc); break;
+#define MSK_RR_CASE(K) case K: if (safe) rr_accumulate<true>(my_a, my_w, lut, shy, K, acc); else rr_accumulate<false>(my_a, my_w, lut, shy, K, acc); break;
             MSK_RR_CASE(0) MSK_RR_CASE(1) MSK_RR_CASE(2) MSK_RR_CASE(3) MSK_RR_CASE(4) MSK_RR_CASE(5) MSK_RR_CASE(6)
 #undef MSK_RR_CASE
         }
@@ -1585,7 +1610,7 @@ k_resolve_rows(DeviceScene sc, const BlockInfo *blocks, const RowBand *bands, ui
                 const int tx = 3 * lx + j;
                 if (tx >= sx_t) continue;
                 float *o = block_buf + (size_t) b.slot * buf_stride + (size_t) (ty * sx_t + tx) * 5;
-                o[0] = acc[j][0]; o[1] = acc[j][1]; o[2] = acc[j][2]; o[3] = acc[j][3]; o[4] = acc[j][3];
+                o[0] = acc[j][0].x; o[1] = acc[j][0].y; o[2] = acc[j][1].x; o[3] = acc[j][1].y; o[4] = acc[j][1].y;
             }
         }
     }
