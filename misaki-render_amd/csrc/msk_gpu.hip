@@ -739,11 +739,14 @@ static uint32_t owned_spp(const msk_render_params *p) {
     return p->sample_first < p->spp ? (p->spp - p->sample_first + ss - 1) / ss : 0;
 }
 
-// 8 M path slots either way.  Short rays (LDS-resident scene): many small regions, one chunk loop per wave.  Long rays
-// (k_trace_r): few large regions, so that lane replacement has a long list of rays to keep the lanes busy with.
+// Short rays (LDS-resident scene): many small regions, one chunk loop per wave: 8192 x 512 = 4 M path slots (0.6 GB of state;
+// measured 16384 / 12288 / 8192 / 6144 regions: 42.7 / 41.7 / 41.2 / 41.6 ms for the bench step — the shading kernel streams the
+// whole pool's state every iteration and a smaller pool keeps more of it in the 256 MB Infinity Cache, the traversal kernel
+// wants many waves per launch).  Long rays (k_trace_r): 4096 regions of 2048 slots = 8 M, so that lane replacement has a long
+// list of rays to keep the lanes busy with.
 static void pool_shape(const msk_scene *sc, uint64_t total_samples, uint32_t *region_size, uint32_t *n_regions) {
     const bool big = sc->trace_mode == 1 || sc->trace_mode == 2;
-    uint32_t rs = env_u32("MSK_REGION_SIZE", big ? 2048 : 512), nr = env_u32("MSK_REGIONS", big ? 4096 : 16384);
+    uint32_t rs = env_u32("MSK_REGION_SIZE", big ? 2048 : 512), nr = env_u32("MSK_REGIONS", big ? 4096 : 8192);
     rs = std::max(64u, (rs + 63u) & ~63u);
     while (rs > 256 && total_samples / rs < nr) rs = std::max(256u, rs / 2);       // small jobs: keep the GPU full first
     const uint64_t need = (total_samples + rs - 1) / rs;

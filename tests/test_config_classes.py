@@ -1,0 +1,96 @@
+"""BASELINE configs 3 and 5 at the sizes their numbers are quoted on: the 70 k-triangle rough-conductor and the
+146 k-triangle rough-dielectric stand-ins (hostmirror.bunny_class_scene / teapot_class_scene — the reference ships no
+meshes) at 1024 x 1024.  Ray level against the oracle's BRUTE FORCE (no tree on the checking side), sample
+level against the oracle's path tracer, and the full-size renders through size-independent properties."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {"config3_bunny_class": ("bunny_class_scene", 65000, 256), "config5_teapot_class": ("teapot_class_scene", 140000, 128)}
+
+
+@pytest.fixture(scope="module", params=sorted(CONFIGS))
+def big(request, gpu_ctx, abi, hostmirror, oracle):
+    maker, min_tris, spp = CONFIGS[request.param]
+    flat = getattr(hostmirror, maker)(1024)
+    assert flat.desc.n_faces > min_tris
+    g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+    yield g, o, flat, spp
+    g.close()
+    o.close()
+
+
+def _rays(flat, o, n, seed):
+    rng = np.random.RandomState(seed)
+    v = flat.vertices[:, :3]
+    lo, hi = v.min(0), v.max(0)
+    a = np.zeros((n, 8), np.float32)
+    a[:, :3] = rng.uniform(lo - 20, hi + 20, (n, 3))
+    # half of the rays aim at the mesh in the middle of the room (the tree's deep part), the rest anywhere
+    tgt = rng.uniform(lo, hi, (n, 3))
+    tgt[: n // 2] = np.array([278, 200, 280]) + rng.normal(size=(n // 2, 3)) * 90
+    d = tgt - a[:, :3]
+    a[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    a[:, 3], a[:, 7] = 1e-3, np.inf
+    a[::3, 7] = rng.uniform(50, 900, len(a[::3]))
+    cam = np.stack([o.camera_ray(0.5, *p)[0] for p in rng.uniform(0, 1024, (2000, 2)).astype(np.float32)])
+    return np.concatenate([a, cam]).astype(np.float32)
+
+
+def test_rays_bit_exact_against_brute_force(big):
+    g, o, flat, _ = big
+    rays = _rays(flat, o, 150_000, 21)
+    o.set_bvh(1)
+    first = o.trace_closest(rays)
+    ok = np.isfinite(first[:, 0])
+    # secondary rays leave the surfaces the first batch hit (ray epsilon as Interaction::spawn_ray sets it)
+    p = rays[ok, :3] + rays[ok, 4:7] * first[ok, 0:1]
+    sec = _rays(flat, o, 50_000, 22)[: min(50_000, int(ok.sum()))]
+    sec[:, :3] = p[: len(sec)]
+    sec[:, 3] = (1 + np.abs(sec[:, :3]).max(1)) * np.float32(8.940697e-05)
+    rays = np.concatenate([rays, sec])
+    assert len(rays) >= 200_000
+    got = g.trace_closest(rays)
+    occ = g.trace_any(rays)
+    # the checker: every triangle against every ray, no tree (oracle.cpp closest_hit / any_hit with set_bvh(0))
+    o.set_bvh(0)
+    want = o.trace_closest(rays)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    sub = slice(0, None, 4)
+    assert np.array_equal(occ[sub], o.trace_any(rays[sub]))
+    o.set_bvh(1)
+    assert np.array_equal(occ, o.trace_any(rays))
+    mesh_hits = (want[:, 3].view(np.uint32) >= 12) & np.isfinite(want[:, 0])        # the room is triangles 0..11
+    assert mesh_hits.sum() > 40_000 and 0.5 < np.isfinite(want[:, 0]).mean() <= 1.0
+
+
+def test_per_sample_radiance_bit_exact(big, abi):
+    g, o, _, _ = big
+    rng = np.random.RandomState(9)
+    on_mesh = np.stack([rng.randint(380, 650, 40), rng.randint(420, 760, 40)], 1)    # the mesh covers the middle of the film
+    pixels = np.concatenate([on_mesh, rng.randint(0, 1024, (22, 2)), [[0, 0], [1023, 1023]]]).astype(np.int32)
+    assert len(pixels) == 64
+    prm = abi.render_params(spp=8, seed=4)
+    gx, gp = g.sample_pixels(prm, pixels)
+    ox, op = o.sample_pixels(prm, pixels)
+    assert np.array_equal(gp, op)
+    assert np.array_equal(gx.view(np.uint32), ox.view(np.uint32))
+    assert np.isfinite(gx).all() and gx.max() > 0
+
+
+def test_full_size_properties(big, abi):
+    """The whole config (268 M / 134 M samples: far beyond the scalar oracle).  (i) sample count, finite, non-negative;
+    (ii) the weight channels depend on the film positions only: bit-equal to those of a depth-0 render; (iii) the film is
+    linear in the sample set: two sample-index shards sum to the whole within the cross-shard tolerance; (iv) a second
+    run is bit-identical."""
+    g, _, _, spp = big
+    full, st = g.render(abi.render_params(spp=spp, seed=5))
+    assert st.samples == 1024 * 1024 * spp and np.isfinite(full).all() and full[..., :3].min() >= 0
+    assert st.segments > 2 * st.samples
+    flat0, _ = g.render(abi.render_params(spp=spp, seed=5, max_depth=0))
+    assert np.array_equal(full[..., 3:].view(np.uint32), flat0[..., 3:].view(np.uint32)) and not flat0[..., :3].any()
+    halves = [g.render(abi.render_params(spp=spp, seed=5, sample_first=r, sample_stride=2))[0] for r in range(2)]
+    assert np.allclose(halves[0] + halves[1], full, rtol=1e-4, atol=1e-4)
+    again, _ = g.render(abi.render_params(spp=spp, seed=5))
+    assert np.array_equal(again.view(np.uint32), full.view(np.uint32))
