@@ -598,6 +598,16 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     // that repeated renders cover all groups); msk_stats::ms_trace / ms_shade / n_*_launches then describe that sample.
     const uint32_t every = std::max(1u, env_u32("MSK_TIMING_EVERY", 1));
     const uint32_t phase = ctx->timing_phase++;
+    // k_wavefront (iterations on the device): possible when tables and tree are LDS-resident and everything fits one block's LDS
+    // next to each other, and there is no per-iteration AOV kernel.  MSK_FUSED=1: the whole pass; MSK_FUSED_TAIL_PCT=p: from
+    // the point where every sample has been started and fewer than p % of the slots are live.
+    const uint32_t fused_queue_f4 = sc->lds_tables ? (uint32_t) ((sc->shade_lds_bytes - (size_t) (MSK_BLOCK / MSK_WAVE) * 3 * MSK_DONE_Q * 16) / 16) : 0u;
+    const uint32_t fused_trace_f4 = (uint32_t) (sc->shade_lds_bytes / 16);
+    const size_t fused_lds = sc->shade_lds_bytes + sc->trace_lds_bytes;
+    const bool fused_ok = sc->trace_mode == 0 && sc->lds_tables && fused_lds <= 64 * 1024 && !(aov && aov->n_groups);
+    const bool fused_all = fused_ok && env_u32("MSK_FUSED", 0) != 0;
+    const uint32_t fused_iters = std::max(1u, env_u32("MSK_FUSED_ITERS", 16));
+    const uint32_t fused_tail_pct = fused_ok ? env_u32("MSK_FUSED_TAIL_PCT", 10) : 0u;
 
     // The wavefront loop over the regions [first, first + count) on one stream.  The pool's two halves run this at the same
     // time on two streams (two host threads): regions are independent — each owns its slots, its share of the samples and
@@ -626,9 +636,18 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
             pend_shade.clear(); pend_trace.clear();
         };
         uint32_t parity = 0;
+        bool fused_now = fused_all;
         for (uint32_t gi = 0;; ++gi) {
             ev_h.next = ev_mark + (size_t) parity * 4 * group;
             const bool timed = timing && (gi + phase) % every == 0;
+            if (fused_now) {
+                // the iteration loop on the device (k_wavefront): one bounded launch = up to fused_iters sweeps of every region
+                // (not timed: msk_stats::ms_shade / ms_trace stay the sums of k_shade_gen / k_trace launches)
+                hipEvent_t a = nullptr, b = nullptr;
+                if (diffuse_only) hipExtLaunchKernelGGL((k_wavefront<true>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
+                else hipExtLaunchKernelGGL((k_wavefront<false>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
+                it += fused_iters;
+            } else
             for (uint32_t g = 0; g < group; ++g, ++it) {
                 hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
                 if (timed) { a = ev_h.get(); b = ev_h.get(); c = ev_h.get(); d = ev_h.get(); }
@@ -651,6 +670,8 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
             pend_shade.swap(cur_shade); pend_trace.swap(cur_trace); cur_shade.clear(); cur_trace.clear(); parity ^= 1u;
             const Ctrl &h = *hf.h_ctrl;
             if (h.remaining == 0 && h.live == 0) break;
+            if (fused_ok && !fused_now && h.remaining == 0 && h.live * 100ull < (unsigned long long) fused_tail_pct * hf.count * region_size)
+                fused_now = true;                       // the thinning end of the pass: no more launches and host round trips per sweep
             if (it > 100000000u) return fail_to(&hf.err, MSK_ERR_HIP, "wavefront loop did not terminate");
         }
         read_pending();

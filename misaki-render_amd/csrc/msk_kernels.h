@@ -944,22 +944,11 @@ MSK_DEV void emit_record(const DeviceScene &sc, const SceneTables &tb, const Pas
 #define MSK_DONE_Q 128                     /* entries per wave: up to 63 parked + 64 new */
 struct DoneQueue { float4 *wl, *res; uint4 *id; };
 
-template <bool LDS_TABLES, bool DIFFUSE_ONLY>
-__global__ void __launch_bounds__(MSK_BLOCK)
-k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
-    extern __shared__ float4 lds_dyn[];
-    const SceneTables tb = stage_tables<LDS_TABLES>(sc, lds_dyn);
-    const uint32_t lwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
-    const uint32_t wave = pp.region_first + lwave;
-    const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
-    // this wave's done-queue: after the staged tables, 3 x MSK_DONE_Q float4 per wave
-    DoneQueue dq;
-    {
-        float4 *qbase = lds_dyn + (LDS_TABLES ? tables_lds_float4s(sc) : 0u) + (threadIdx.x / MSK_WAVE) * (3 * MSK_DONE_Q);
-        dq.wl = qbase; dq.res = qbase + MSK_DONE_Q; dq.id = (uint4 *) (qbase + 2 * MSK_DONE_Q);
-    }
+// One shading sweep of region `wave` by its owner wave (see the file header); returns the region's live count afterwards.
+template <bool DIFFUSE_ONLY>
+MSK_DEV uint32_t shade_region(const DeviceScene &sc, const SceneTables &tb, const DoneQueue &dq, const PathState &st, const PassParams &pp,
+                              uint32_t wave, uint32_t lane) {
     uint32_t n_queued = 0;
-    if (lwave >= pp.region_count) return;
     RegionCtl rc = pp.regions[wave];
     const uint32_t n_in = rc.count;
     const size_t base = (size_t) wave * pp.region_size;
@@ -1252,11 +1241,83 @@ k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
         // sh / contrib stay as they are: nothing reads them for a slot without a shadow ray (ray_o.w >= 0, no MSK_FLAG_SHADOW)
         if (!DIFFUSE_ONLY) st.aux[o] = make_float2(1.f, 0.f);
     }
+    const uint32_t n_out = cursor + got;
     if (lane == 0) {
-        const uint32_t n_out = cursor + got;
         rc.count = n_out; rc.next_sample = first + got;
         rc.segments += n_out; rc.shadow_rays += n_shadow; rc.samples_done += n_done;
         pp.regions[wave] = rc;
+    }
+    return n_out;
+}
+
+// this wave's done-queue: `base` + 3 x MSK_DONE_Q float4 per wave of the block
+MSK_DEV DoneQueue done_queue(float4 *base) {
+    DoneQueue dq;
+    float4 *qbase = base + (threadIdx.x / MSK_WAVE) * (3 * MSK_DONE_Q);
+    dq.wl = qbase; dq.res = qbase + MSK_DONE_Q; dq.id = (uint4 *) (qbase + 2 * MSK_DONE_Q);
+    return dq;
+}
+
+template <bool LDS_TABLES, bool DIFFUSE_ONLY>
+__global__ void __launch_bounds__(MSK_BLOCK)
+k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
+    extern __shared__ float4 lds_dyn[];
+    const SceneTables tb = stage_tables<LDS_TABLES>(sc, lds_dyn);
+    const uint32_t lwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
+    const DoneQueue dq = done_queue(lds_dyn + (LDS_TABLES ? tables_lds_float4s(sc) : 0u));      // after the staged tables
+    if (lwave >= pp.region_count) return;
+    shade_region<DIFFUSE_ONLY>(sc, tb, dq, st, pp, pp.region_first + lwave, threadIdx.x & (MSK_WAVE - 1));
+}
+
+// ------------------------------------------------------------------------------------------
+// k_wavefront: the iteration loop itself on the device, for scenes whose tree is staged in LDS.  A region is private to
+// its wave — its slots, its share of the samples, its counters — so nothing orders one region's iterations against
+// another's: every wave runs  shade -> trace -> shade -> ...  on its own region until the region has no path and no sample
+// left (or `max_iters` sweeps have run: a bounded launch, the host relaunches while work remains).  Tables, tree and
+// triangles are staged once per block instead of once per launch.  Same arithmetic as k_shade_gen / k_trace<0>: same records.
+// ------------------------------------------------------------------------------------------
+template <bool DIFFUSE_ONLY>
+__global__ void __launch_bounds__(MSK_BLOCK)
+k_wavefront(DeviceScene sc, PathState st, PassParams pp, uint32_t max_iters, uint32_t queue_f4, uint32_t trace_f4) {
+    extern __shared__ float4 lds_dyn[];
+    // LDS: [tables][done queues][traversal stacks][tree + triangles]; offsets in float4 from the host's plan
+    const SceneTables tb = stage_tables<true>(sc, lds_dyn);
+    const DoneQueue dq = done_queue(lds_dyn + queue_f4);
+    uint32_t *stack_base = (uint32_t *) (lds_dyn + trace_f4);
+    float4 *scene_lds = lds_dyn + trace_f4 + (sc.stack_entries * MSK_BLOCK) / 4;
+    const TraceLds g = stage_scene(sc, scene_lds, true, false);
+    const LaneStack<false> stack{stack_base + threadIdx.x, nullptr, (int) sc.stack_entries, 0};
+    const uint32_t lwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
+    const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
+    if (lwave >= pp.region_count) return;
+    const uint32_t wave = pp.region_first + lwave;
+    const size_t base = (size_t) wave * pp.region_size;
+    for (uint32_t it = 0; it < max_iters; ++it) {
+        const uint32_t n = shade_region<DIFFUSE_ONLY>(sc, tb, dq, st, pp, wave, lane);
+        // the rays this wave has just written are read back by the same wave (other lanes): program order through the
+        // CU's own L1 after the stores have drained
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (n == 0) break;                                     // no live path, and regeneration found no sample to start
+        for (uint32_t c = lane; c < n; c += MSK_WAVE) {
+            const size_t i = base + c;
+            float4 ro = st.ray_o[i];
+            float4 rd = st.ray_d[i];
+            const bool has_shadow = __float_as_int(ro.w) < 0;
+            ro.w = fabsf(ro.w);
+            rd.w = slot_tmax(rd.w);
+            const f3 o = mk3(ro.x, ro.y, ro.z);
+            float bt, bu, bv; uint32_t bp;
+            uint32_t unocc = 0;
+            if (has_shadow) {
+                const float4 s = st.sh[i];
+                const bool occ = traverse_scene<0, true>(sc, g, o, mk3(s.x, s.y, s.z), ro.w, s.w, stack, &bt, &bu, &bv, &bp);
+                unocc = occ ? 0u : MSK_HIT_UNOCCLUDED;
+            }
+            traverse_scene<0, false>(sc, g, o, mk3(rd.x, rd.y, rd.z), ro.w, rd.w, stack, &bt, &bu, &bv, &bp);
+            const bool valid = (bp != MSK_NO_PRIM) && (bt != rd.w);           // scene.cpp:234 tfar != maxt
+            st.hit[i] = make_float4(valid ? bt : MSK_INF_F, bu, bv, __uint_as_float((valid ? bp : MSK_PRIM_MASK) | unocc));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
 }
 
