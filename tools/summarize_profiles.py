@@ -19,6 +19,13 @@ os.makedirs(out, exist_ok=True)
 ks = glob.glob(os.path.join(root, "gpurun_out", "prof_kt", "**", "*_kernel_stats.csv"), recursive=True)
 if ks:
     shutil.copy(max(ks, key=os.path.getmtime), os.path.join(out, f"{tag}_kernel_stats.csv"))
+ks1 = glob.glob(os.path.join(root, "gpurun_out", "prof_kt1", "**", "*_kernel_stats.csv"), recursive=True)
+if ks1:   # the same command under MSK_STREAMS=1: per-kernel durations without overlapping launches
+    shutil.copy(max(ks1, key=os.path.getmtime), os.path.join(out, f"{tag}_kernel_stats_1stream.csv"))
+for name in ("prof_kt.json", "prof_kt1.json"):      # the bench line printed inside each profiled run
+    src = os.path.join(root, "gpurun_out", name)
+    if os.path.exists(src) and os.path.getsize(src):
+        shutil.copy(src, os.path.join(out, f"{tag}_bench_under_{name.replace('prof_', 'rocprof_')}"))
 
 
 def short(name):
@@ -56,10 +63,12 @@ print(json.dumps(summary, indent=1))
 
 # SQ pass (one run, 8 counters): per-wave fractions of SQ_WAVE_CYCLES (all in quad-cycles, MI355X_MICROARCH.md)
 sq_files = glob.glob(os.path.join(root, "gpurun_out", "prof_sq", "**", "*_counter_collection.csv"), recursive=True)
+sq2_files = glob.glob(os.path.join(root, "gpurun_out", "prof_sq2", "**", "*_counter_collection.csv"), recursive=True)
 if sq_files:
     tot = collections.defaultdict(lambda: collections.defaultdict(float))
-    for r in csv.DictReader(open(max(sq_files, key=os.path.getmtime))):
-        tot[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    for f in [max(sq_files, key=os.path.getmtime)] + ([max(sq2_files, key=os.path.getmtime)] if sq2_files else []):
+        for r in csv.DictReader(open(f)):
+            tot[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
     sq = {}
     for k, v in sorted(tot.items()):
         if not k.startswith("k_"):
