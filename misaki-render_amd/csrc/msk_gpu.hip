@@ -1056,7 +1056,8 @@ extern "C" int msk_gpu_sample_pixels(msk_scene *scene, const msk_render_params *
     for (uint64_t i = 0; i < n_pixels; ++i) {
         const int x = pixels[2 * i], y = pixels[2 * i + 1];
         if (x < 0 || y < 0 || x >= W || y >= H) return fail(ctx, MSK_ERR_INVALID_ARG, "pixel (%d,%d) outside the %dx%d film", x, y, W, H);
-        pix[i] = make_uint4((uint32_t) (y * W + x), 0u, 0u, 0u);       // unpacked records: only the film index is read
+        // a "block" of one pixel at (x, y): the kernels take the film coordinates from the block offset (pixel_x / pixel_y)
+        pix[i] = make_uint4((uint32_t) (y * W + x), 0u, (uint32_t) (x - scene->dev.filter_border), (uint32_t) (y - scene->dev.filter_border));
     }
     if (n_pixels == 0) return MSK_OK;
     msk_render_params p = *prm; p.sample_first = 0; p.sample_stride = 1;

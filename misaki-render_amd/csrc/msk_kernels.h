@@ -901,6 +901,10 @@ MSK_DEV SampleWeights sample_weights(const DeviceScene &sc, uint4 pt, float px, 
     r.y = weight_word(by, pt.y >> 16, sc.filter_radius, sc.filter_scale);
     return r;
 }
+// film coordinates of a pass pixel from its table entry {film index, x | y << 16 inside its block, block offset - border}
+// (= film index % width, film index / width, without the integer divisions)
+MSK_DEV uint32_t pixel_x(const DeviceScene &sc, uint4 pt) { return (uint32_t) ((int) pt.z + sc.filter_border) + (pt.y & 0xffffu); }
+MSK_DEV uint32_t pixel_y(const DeviceScene &sc, uint4 pt) { return (uint32_t) ((int) pt.w + sc.filter_border) + (pt.y >> 16); }
 MSK_DEV uint32_t nonfinite_flag(float a, float b, float c) {
     const bool fin = fabsf(a) < MSK_INF_F && fabsf(b) < MSK_INF_F && fabsf(c) < MSK_INF_F;      // false for nan too
     return fin ? 0u : MSK_W_NONFINITE;
@@ -918,11 +922,11 @@ MSK_DEV void emit_record(const DeviceScene &sc, const SceneTables &tb, const Pas
     spectrum_to_xyz(tb.cie, result, wl, &X, &Y, &Z);
     const uint64_t key = counter_key(pp.seed, pix, pp.sample_first + si * pp.sample_stride);
     const f2 jit = counter_pair(key, 0);
-    const float px = (float) (pix % (uint32_t) sc.width) + jit.x, py = (float) (pix / (uint32_t) sc.width) + jit.y;
+    const uint4 pt = pp.pix_table[j];
+    const float px = (float) pixel_x(sc, pt) + jit.x, py = (float) pixel_y(sc, pt) + jit.y;
     const size_t r = (size_t) j * pp.spp_owned + si;
     float wx = px, wy = py;
     if (pp.packed) {
-        const uint4 pt = pp.pix_table[j];
         const SampleWeights sw = sample_weights(sc, pt, px, py);
         wx = __uint_as_float(sw.x | nonfinite_flag(X, Y, Z)); wy = __uint_as_float(sw.y);
     }
@@ -953,6 +957,7 @@ MSK_DEV uint32_t shade_region(const DeviceScene &sc, const SceneTables &tb, cons
     const uint32_t n_in = rc.count;
     const size_t base = (size_t) wave * pp.region_size;
     const uint32_t n_em = sc.n_emitters;
+    const bool one_emitter = n_em == 1 && (DIFFUSE_ONLY || sc.env_emitter < 0);      // one AREA emitter
     uint32_t cursor = 0, n_shadow = 0, n_done = 0;
 
     for (uint32_t c0 = 0; c0 < n_in; c0 += MSK_WAVE) {
@@ -964,6 +969,9 @@ MSK_DEV uint32_t shade_region(const DeviceScene &sc, const SceneTables &tb, cons
         spec wl = from4(st.wl[i]), thr = from4(st.thr[i]), res = from4(st.res[i]);
         const float4 rd4 = st.ray_d[i];
         float4 hit = st.hit[i];
+#ifdef MSK_WHATIF_EXTRAR       /* timing experiment (same results): 16 B more read per segment */
+        { const float4 x_ = st.sh[i]; if (x_.x == 12345.678f && x_.y == -3.25f) hit.x = 0.f; }
+#endif
         // the previous bounce's NEE term (path.cpp:60-66), now that the shadow ray has been traced
         if (active && (id.w & MSK_FLAG_SHADOW) && (__float_as_uint(hit.w) & MSK_HIT_UNOCCLUDED))
             res = res + from4(st.contrib[i]);
@@ -1005,8 +1013,14 @@ MSK_DEV uint32_t shade_region(const DeviceScene &sc, const SceneTables &tb, cons
             }
             // AreaLight::eval at this hit (area.cpp:51-54): used by the MIS term of the previous bounce or by the directly
             // visible emitter, never both
+            // With a single emitter, its radiance at the path's wavelengths is what both this hit (area.cpp:51-54) and the
+            // bounce's NEE sample (area.cpp:39-44) evaluate — same function, same arguments, same bits: once per chunk for
+            // every lane instead of once for the few lanes on the emitter plus once for the NEE samples.
+            spec le_one = splat(0.f);
+            if (one_emitter) le_one = emitter_radiance(tb, 0, wl);
             spec le_hit = splat(0.f);
-            if (si.emitter_id >= 0 && si.wi.z > 0.f) le_hit = emitter_radiance(tb, si.emitter_id, wl);
+            if (one_emitter) { if (si.emitter_id >= 0 && si.wi.z > 0.f) le_hit = le_one; }
+            else if (si.emitter_id >= 0 && si.wi.z > 0.f) le_hit = emitter_radiance(tb, si.emitter_id, wl);
             if (depth > 1) {
                 // ---- tail of the previous bounce: emitter hit by the BSDF sample (path.cpp:82-88,103-108)
                 if (si.emitter_id >= 0) {
@@ -1098,7 +1112,7 @@ MSK_DEV uint32_t shade_region(const DeviceScene &sc, const SceneTables &tb, cons
                     pdf *= (dp != 0.f) ? dist2 / dp : 0.f;
                     if (!DIFFUSE_ONLY) nee_pdf = e0.w * ((dp != 0.f) ? (dist * dist) / dp : 0.f);   // shape.cpp:80-86
                     if (dot(d, ln) < 0.f && pdf != 0.f) {                  // area.cpp:39-44
-                        emitter_val = emitter_radiance(tb, (int) e, wl) / pdf;
+                        emitter_val = (one_emitter ? le_one : emitter_radiance(tb, (int) e, wl)) / pdf;
                     } else {
                         pdf = 0.f; emitter_val = splat(0.f);
                     }
@@ -1190,6 +1204,9 @@ MSK_DEV uint32_t shade_region(const DeviceScene &sc, const SceneTables &tb, cons
             if (has_shadow) new_o.w = __int_as_float(__float_as_int(new_o.w) | (int) 0x80000000);       // PathState::ray_o
             st.ray_o[o] = new_o; st.ray_d[o] = new_d; st.sh[o] = new_sh; st.contrib[o] = to4(contrib);
             if (!DIFFUSE_ONLY) st.aux[o] = make_float2(eta, nee_pdf);
+#ifdef MSK_WHATIF_EXTRAW       /* timing experiment (same results): 16 B more written per survivor (k_trace overwrites hit) */
+            st.hit[o] = new_sh;
+#endif
         }
         cursor += __popcll(m);
     }
@@ -1204,15 +1221,21 @@ MSK_DEV uint32_t shade_region(const DeviceScene &sc, const SceneTables &tb, cons
     const uint32_t n_free = pp.region_size - cursor;
     const unsigned long long first = rc.next_sample, left = rc.end_sample - rc.next_sample;
     const uint32_t got = (uint32_t) (left < n_free ? left : n_free);
+    // the linear sample index -> (pass pixel, sample) split is a 32-bit division whenever this sweep's indices fit (a pass
+    // of < 2^32 samples: every configuration but the largest single-GPU ones), the 64-bit one otherwise
+    const bool idx32 = got > 0 && (((((first + got - 1) >> 6) * pp.n_regions + wave) << 6) | 63ull) < (1ull << 32);
     for (uint32_t k = lane; k < got; k += MSK_WAVE) {
         const unsigned long long q = first + k;
         const unsigned long long sidx_lin = (((q >> 6) * pp.n_regions + wave) << 6) | (q & 63ull);
-        const uint32_t j = (uint32_t) (sidx_lin / pp.spp_owned), si = (uint32_t) (sidx_lin % pp.spp_owned);
-        const uint32_t pix = pp.pix_table[j].x;
+        uint32_t j, si;
+        if (idx32) { j = (uint32_t) sidx_lin / pp.spp_owned; si = (uint32_t) sidx_lin - j * pp.spp_owned; }
+        else { j = (uint32_t) (sidx_lin / pp.spp_owned); si = (uint32_t) (sidx_lin % pp.spp_owned); }
+        const uint4 pt = pp.pix_table[j];
+        const uint32_t pix = pt.x;
         const uint64_t key = counter_key(pp.seed, pix, pp.sample_first + si * pp.sample_stride);
         const f2 jit = counter_pair(key, 0);
         const float wsample = counter_pair(key, 1).x;
-        const float px = (float) (pix % (uint32_t) sc.width) + jit.x, py = (float) (pix / (uint32_t) sc.width) + jit.y;
+        const float px = (float) pixel_x(sc, pt) + jit.x, py = (float) pixel_y(sc, pt) + jit.y;
         spec wl;
 #pragma unroll
         for (int q = 0; q < 4; ++q) wl.v[q] = wavelength_of(wsample, q);
