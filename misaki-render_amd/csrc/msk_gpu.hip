@@ -458,9 +458,9 @@ static std::vector<HostBlock> spiral_blocks(int w, int h, int bs, int *nbx, int 
 struct StateBufs {
     DevBuf id, wl, thr, res, ray_o, ray_d, sh, contrib, hit, aux, counts, ctrl, stack_ovf[MSK_MAX_STREAMS];
     PathState st;
-    hipError_t alloc(size_t n, uint32_t n_regions) {
+    hipError_t alloc(size_t n, uint32_t n_regions) {      // n = slots a sweep can hold live; every region has two halves of them
         hipError_t e;
-#define A_(b, sz) if ((e = b.reserve(n * (sz))) != hipSuccess) return e;
+#define A_(b, sz) if ((e = b.reserve(2 * n * (sz))) != hipSuccess) return e;
         A_(id, 16) A_(wl, 16) A_(thr, 16) A_(res, 16) A_(ray_o, 16) A_(ray_d, 16) A_(sh, 16) A_(contrib, 16) A_(hit, 16)
         A_(aux, 8)
 #undef A_
@@ -825,8 +825,8 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     for (auto &b : owned) all_samples += (uint64_t) b.size_x * b.size_y * spp_owned;
     pool_shape(sc, all_samples, &region_size, &n_regions);
     const size_t n_slots = (size_t) region_size * n_regions;
-    const size_t state_bytes = n_slots * 144 + 4096;
-    const size_t held = ws.rec_a.bytes + ws.rec_b.bytes + ws.sb.id.bytes * 144 / 16;    // reusable: counts as free
+    const size_t state_bytes = 2 * n_slots * 152 + 4096;                              // two halves per region (StateBufs::alloc)
+    const size_t held = ws.rec_a.bytes + ws.rec_b.bytes + ws.sb.id.bytes * 152 / 16;    // reusable: counts as free
     free_b += held;
     size_t budget = getenv("MSK_RECORD_BUDGET_MB") ? (size_t) atoll(getenv("MSK_RECORD_BUDGET_MB")) << 20
                                                    : (free_b > state_bytes ? (size_t) ((free_b - state_bytes) * 0.8) : 0);

@@ -7,10 +7,11 @@
 //                every path (emitter hit + MIS, Russian roulette), runs the next bounce's
 //                NEE + BSDF sampling (PathTracer::sample body, path.cpp:33-123), parks finished
 //                paths in a wave-local LDS queue and writes their sample records 64 at a time,
-//                compacts the survivors to the front of the region IN PLACE with a wave ballot +
-//                prefix popcount (no block barrier, no global queue, no atomic), then refills the
-//                free tail of the region with new camera samples (render_sample,
-//                integrator.cpp:103-116) from the region's own static share of the pass (RegionCtl).
+//                compacts the survivors into the region's other half with a wave ballot + prefix
+//                popcount (no block barrier, no global queue, no atomic) — those with a pending shadow
+//                ray from the front, the others from the end (RegionView) — then fills what is free
+//                with new camera samples (render_sample, integrator.cpp:103-116) from the region's own
+//                static share of the pass (RegionCtl).
 //   k_trace      per live slot: the pending shadow ray (Scene::ray_test, scene.cpp:255-273) and
 //                the extension ray (Scene::ray_intersect, scene.cpp:216-253) against the
 //                flattened BVH: k_trace<0> with nodes + triangles staged in LDS when the scene is
@@ -30,7 +31,6 @@ namespace msk {
 #define MSK_BLOCK 256
 #define MSK_LEAF_BIT 0x80000000u  /* child ref: leaf = BIT | first_tri << 5 | count ; inner = node index */
 #define MSK_NO_PRIM 0xffffffffu
-#define MSK_FLAG_SHADOW 0x10000u
 #define MSK_DEPTH_MASK 0xffffu
 
 struct DeviceScene {
@@ -71,15 +71,14 @@ struct DeviceScene {
 };
 
 struct PathState {
-    uint4 *id;          // {pass pixel j, owned-sample index si, film pixel y*W+x, depth | MSK_FLAG_SHADOW}
+    uint4 *id;          // {pass pixel j, owned-sample index si, film pixel y*W+x, depth}
     float4 *wl, *thr, *res;
-    float4 *ray_o;      // o.xyz, tmin (>= 0) with the sign bit set when the slot also carries a shadow ray (so that the trace
-                        // kernels need no other word of the state to know)
+    float4 *ray_o;      // o.xyz, tmin
     float4 *ray_d;      // d.xyz, then: camera ray: tmax (> 0); bounce ray (tmax = inf): minus the pdf of the BSDF sample that made
                         // it (BSDFSample::pdf > 0, needed by the MIS weight at the next hit).  d = 0 marks a path whose
                         // throughput is zero and which only waits for its shadow ray: such a ray hits nothing
-    float4 *sh;         // shadow d.xyz, tmax
-    float4 *contrib;    // NEE contribution added when the shadow ray is unoccluded
+    float4 *sh;         // shadow d.xyz, tmax                                        } written / read only for the slots
+    float4 *contrib;    // NEE contribution added when the shadow ray is unoccluded  } c < ns of a region (RegionView)
     float4 *hit;        // t,u,v,prim
     float2 *aux;        // {eta (path.cpp:29), pdf_emitter_direct of the last NEE record (path.cpp:103-106 on an environment hit)}
 };
@@ -94,8 +93,26 @@ struct RegionCtl {
     // than contiguous slices) keeps every region's mix of cheap and expensive pixels the same.
     unsigned long long next_sample, end_sample;
     unsigned long long segments, shadow_rays, samples_done;
-    uint32_t count, pad;                          // live slots
+    uint32_t count;                               // live slots
+    uint32_t half_ns;                             // bit 0: which half of the region holds them; bits 1..: how many of them carry a shadow ray
 };
+// A region is two halves of region_size slots.  A shading sweep reads the live paths from one half and writes the survivors
+// (and the new camera samples) to the other, so nothing it writes can land on a slot it has not read yet, in whatever order
+// it reads and wherever it writes.  That freedom is used to GROUP the survivors: those with a pending shadow ray are packed
+// upwards from the front of the half, the others (and the new samples) downwards from its end.  Live slot c (0 <= c < count)
+// is slot c for c < ns and slot region_size - 1 - (c - ns) otherwise: "has a shadow ray" is c < ns — no flag to carry, the
+// shadow direction / contribution arrays are only written and read for the slots that need them, and k_trace's chunks are
+// shadow-and-extension or extension-only as a whole instead of every chunk walking the tree twice with half of its lanes.
+// (Slot indices are 32-bit: a pool of 2^32 slots would be 650 GB of state.)
+struct RegionView {
+    uint32_t base, n, ns, last;                   // last = region_size - 1
+    MSK_DEV uint32_t slot(uint32_t c) const { return base + (c < ns ? c : last - (c - ns)); }
+};
+MSK_DEV RegionView region_view(uint32_t region, uint32_t region_size, uint32_t count, uint32_t half_ns) {
+    RegionView v;
+    v.base = (region * 2u + (half_ns & 1u)) * region_size; v.n = count; v.ns = half_ns >> 1; v.last = region_size - 1u;
+    return v;
+}
 struct Ctrl {                                     // written by k_reduce_ctl, read by the host
     unsigned long long live, remaining, segments, shadow_rays, samples_done;
 };
@@ -383,14 +400,12 @@ MSK_DEV void trace_chunks(const DeviceScene &sc, const PathState &st, const Pass
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
     if (lwave >= pp.region_count) return;
     const uint32_t wave = pp.region_first + lwave;
-    const uint32_t n = pp.regions[wave].count;
-    const size_t base = (size_t) wave * pp.region_size;
-    for (uint32_t c = sub * MSK_WAVE + lane; c < n; c += MSK_WAVE * pp.trace_split) {
-        const size_t i = base + c;
-        float4 ro = st.ray_o[i];
+    const RegionView rv = region_view(wave, pp.region_size, pp.regions[wave].count, pp.regions[wave].half_ns);
+    for (uint32_t c = sub * MSK_WAVE + lane; c < rv.n; c += MSK_WAVE * pp.trace_split) {
+        const uint32_t i = rv.slot(c);
+        const float4 ro = st.ray_o[i];
         float4 rd = st.ray_d[i];
-        const bool has_shadow = __float_as_int(ro.w) < 0;
-        ro.w = fabsf(ro.w);
+        const bool has_shadow = c < rv.ns;
         rd.w = slot_tmax(rd.w);
         const f3 o = mk3(ro.x, ro.y, ro.z);
         float bt, bu, bv; uint32_t bp;
@@ -510,11 +525,11 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
     if (lwave >= pp.region_count) return;
     const uint32_t wave = pp.region_first + lwave;
-    const uint32_t n = pp.regions[wave].count;
-    const size_t base = (size_t) wave * pp.region_size;
+    const RegionView rv = region_view(wave, pp.region_size, pp.regions[wave].count, pp.regions[wave].half_ns);
+    const uint32_t n = rv.n;
     uint32_t next = 0;                       // wave-uniform: first slot nobody has taken yet
     bool active = false, shadow_phase = false;
-    size_t slot = 0;
+    uint32_t slot = 0;
     float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 0, 0);      // rd.w = the extension ray's tmax (slot_tmax)
     uint32_t unocc = 0;
     TravState t;
@@ -525,10 +540,9 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
             if (!active) {
                 const uint32_t c = next + (uint32_t) __popcll(idle & ((1ull << lane) - 1ull));
                 if (c < n) {
-                    slot = base + c;
+                    slot = rv.slot(c);
                     ro = st.ray_o[slot]; rd = st.ray_d[slot];
-                    shadow_phase = __float_as_int(ro.w) < 0;
-                    ro.w = fabsf(ro.w);
+                    shadow_phase = c < rv.ns;
                     rd.w = slot_tmax(rd.w);
                     unocc = 0; active = true;
                     if (shadow_phase) {
@@ -950,35 +964,49 @@ struct DoneQueue { float4 *wl, *res; uint4 *id; };
 
 // One shading sweep of region `wave` by its owner wave (see the file header); returns the region's live count afterwards.
 template <bool DIFFUSE_ONLY>
-MSK_DEV uint32_t shade_region(const DeviceScene &sc, const SceneTables &tb, const DoneQueue &dq, const PathState &st, const PassParams &pp,
-                              uint32_t wave, uint32_t lane) {
+MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, const DoneQueue &dq, const PathState &st, const PassParams &pp,
+                                uint32_t wave, uint32_t lane) {
     uint32_t n_queued = 0;
     RegionCtl rc = pp.regions[wave];
     const uint32_t n_in = rc.count;
-    const size_t base = (size_t) wave * pp.region_size;
+    const RegionView in = region_view(wave, pp.region_size, rc.count, rc.half_ns);
+    const uint32_t base_out = (wave * 2u + ((rc.half_ns & 1u) ^ 1u)) * pp.region_size;      // the other half
+    const uint32_t last = pp.region_size - 1u;
+    uint32_t cur_s = 0, cur_n = 0;                // survivors written so far: with a shadow ray (upwards from slot 0), without (downwards from `last`)
     const uint32_t n_em = sc.n_emitters;
     const bool one_emitter = n_em == 1 && (DIFFUSE_ONLY || sc.env_emitter < 0);      // one AREA emitter
-    uint32_t cursor = 0, n_shadow = 0, n_done = 0;
+    uint32_t n_done = 0;
 
+    // A chunk's state as it is loaded.  (Measured and rejected: issuing the NEXT chunk's loads before this one is shaded — legal
+    // with two-half regions — costs 30 VGPRs = one wave per SIMD and is slower, 21.6 vs 20.7 ms of shading per bench step.)
+    struct ChunkIn { uint4 id; float4 wl, thr, res, rd4, hit, contrib; float2 aux; };
+    auto load_chunk = [&](uint32_t c0) {
+        const uint32_t c = c0 + lane;
+        const uint32_t i = in.slot(c < n_in ? c : 0u);
+        ChunkIn k;
+        k.id = st.id[i]; k.wl = st.wl[i]; k.thr = st.thr[i]; k.res = st.res[i]; k.rd4 = st.ray_d[i]; k.hit = st.hit[i];
+        k.contrib = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < in.ns) k.contrib = st.contrib[i];                          // (whole chunks, but for the one the boundary falls in)
+        k.aux = make_float2(1.f, 0.f);
+        if (!DIFFUSE_ONLY) k.aux = st.aux[i];
+        return k;
+    };
     for (uint32_t c0 = 0; c0 < n_in; c0 += MSK_WAVE) {
         const uint32_t c = c0 + lane;
         const bool active = c < n_in;
-        const size_t i = base + (active ? c : 0);
+        const bool shadow_in = c < in.ns;          // this path's last bounce sent a shadow ray (ns <= n_in)
         // ---- load
-        const uint4 id = st.id[i];
-        spec wl = from4(st.wl[i]), thr = from4(st.thr[i]), res = from4(st.res[i]);
-        const float4 rd4 = st.ray_d[i];
-        float4 hit = st.hit[i];
-#ifdef MSK_WHATIF_EXTRAR       /* timing experiment (same results): 16 B more read per segment */
-        { const float4 x_ = st.sh[i]; if (x_.x == 12345.678f && x_.y == -3.25f) hit.x = 0.f; }
-#endif
+        const ChunkIn cur = load_chunk(c0);
+        const uint4 id = cur.id;
+        spec wl = from4(cur.wl), thr = from4(cur.thr), res = from4(cur.res);
+        const float4 rd4 = cur.rd4;
+        float4 hit = cur.hit;
         // the previous bounce's NEE term (path.cpp:60-66), now that the shadow ray has been traced
-        if (active && (id.w & MSK_FLAG_SHADOW) && (__float_as_uint(hit.w) & MSK_HIT_UNOCCLUDED))
-            res = res + from4(st.contrib[i]);
+        if (shadow_in && (__float_as_uint(hit.w) & MSK_HIT_UNOCCLUDED))
+            res = res + from4(cur.contrib);
         hit.w = __uint_as_float(__float_as_uint(hit.w) & MSK_PRIM_MASK);
         float bs_pdf = -rd4.w;                                             // meaningful for depth > 1 (PathState::ray_d)
-        float eta = 1.f, nee_pdf = 0.f;                                    // carried only by the general variant
-        if (!DIFFUSE_ONLY) { const float2 a = st.aux[i]; eta = a.x; nee_pdf = a.y; }
+        float eta = cur.aux.x, nee_pdf = cur.aux.y;                        // carried only by the general variant
         uint32_t depth = id.w & MSK_DEPTH_MASK;
         const f3 rd = mk3(rd4.x, rd4.y, rd4.z);
         const uint32_t pix = id.z;
@@ -1191,24 +1219,19 @@ MSK_DEV uint32_t shade_region(const DeviceScene &sc, const SceneTables &tb, cons
                 }
             }
         }
-        // ---- in-place compaction of the survivors (wave ballot + prefix popcount)
-        const unsigned long long m = __ballot(alive);
-        const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
-        n_shadow += __popcll(__ballot(alive && has_shadow));
+        // ---- compaction of the survivors into the other half, grouped (wave ballot + prefix popcount)
+        const unsigned long long m_s = __ballot(alive && has_shadow), m_n = __ballot(alive && !has_shadow);
         n_done += __popcll(__ballot(active && !alive));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every load of this chunk has landed before slots are overwritten
         if (alive) {
-            const size_t o = base + cursor + off;
-            st.id[o] = make_uint4(id.x, id.y, id.z, depth | (has_shadow ? MSK_FLAG_SHADOW : 0u));
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const uint32_t o = base_out + (has_shadow ? cur_s + (uint32_t) __popcll(m_s & below) : last - (cur_n + (uint32_t) __popcll(m_n & below)));
+            st.id[o] = make_uint4(id.x, id.y, id.z, depth);
             st.wl[o] = to4(wl); st.thr[o] = to4(thr); st.res[o] = to4(res);
-            if (has_shadow) new_o.w = __int_as_float(__float_as_int(new_o.w) | (int) 0x80000000);       // PathState::ray_o
-            st.ray_o[o] = new_o; st.ray_d[o] = new_d; st.sh[o] = new_sh; st.contrib[o] = to4(contrib);
+            st.ray_o[o] = new_o; st.ray_d[o] = new_d;
+            if (has_shadow) { st.sh[o] = new_sh; st.contrib[o] = to4(contrib); }
             if (!DIFFUSE_ONLY) st.aux[o] = make_float2(eta, nee_pdf);
-#ifdef MSK_WHATIF_EXTRAW       /* timing experiment (same results): 16 B more written per survivor (k_trace overwrites hit) */
-            st.hit[o] = new_sh;
-#endif
         }
-        cursor += __popcll(m);
+        cur_s += (uint32_t) __popcll(m_s); cur_n += (uint32_t) __popcll(m_n);
     }
 
     // ---- the paths still parked (< 64)
@@ -1218,7 +1241,7 @@ MSK_DEV uint32_t shade_region(const DeviceScene &sc, const SceneTables &tb, cons
         emit_record<DIFFUSE_ONLY>(sc, tb, pp, qwl, qres, qid.x, qid.y, qid.z);
     }
     // ---- regeneration: fill the free tail with new camera samples (integrator.cpp:103-116)
-    const uint32_t n_free = pp.region_size - cursor;
+    const uint32_t n_free = pp.region_size - (cur_s + cur_n);
     const unsigned long long first = rc.next_sample, left = rc.end_sample - rc.next_sample;
     const uint32_t got = (uint32_t) (left < n_free ? left : n_free);
     // the linear sample index -> (pass pixel, sample) split is a 32-bit division whenever this sweep's indices fit (a pass
@@ -1256,21 +1279,21 @@ MSK_DEV uint32_t shade_region(const DeviceScene &sc, const SceneTables &tb, cons
         const float *m = sc.to_world;
         const f3 dw = mk3(m[0] * dl.x + (m[1] * dl.y + m[2] * dl.z), m[4] * dl.x + (m[5] * dl.y + m[6] * dl.z),
                           m[8] * dl.x + (m[9] * dl.y + m[10] * dl.z));
-        const size_t o = base + cursor + k;
+        const uint32_t o = base_out + (last - (cur_n + k));         // the new samples carry no shadow ray: they continue that group
         st.id[o] = make_uint4(j, si, pix, 1u);
         st.wl[o] = to4(wl); st.thr[o] = make_float4(1.f, 1.f, 1.f, 1.f); st.res[o] = make_float4(0.f, 0.f, 0.f, 0.f);
         st.ray_o[o] = make_float4(ow.x, ow.y, ow.z, sc.near_clip * inv_z);
         st.ray_d[o] = make_float4(dw.x, dw.y, dw.z, sc.far_clip * inv_z);
-        // sh / contrib stay as they are: nothing reads them for a slot without a shadow ray (ray_o.w >= 0, no MSK_FLAG_SHADOW)
         if (!DIFFUSE_ONLY) st.aux[o] = make_float2(1.f, 0.f);
     }
-    const uint32_t n_out = cursor + got;
+    const uint32_t n_out = cur_s + cur_n + got;
+    rc.count = n_out; rc.half_ns = (cur_s << 1) | ((rc.half_ns & 1u) ^ 1u);
     if (lane == 0) {
-        rc.count = n_out; rc.next_sample = first + got;
-        rc.segments += n_out; rc.shadow_rays += n_shadow; rc.samples_done += n_done;
+        rc.next_sample = first + got;
+        rc.segments += n_out; rc.shadow_rays += cur_s; rc.samples_done += n_done;
         pp.regions[wave] = rc;
     }
-    return n_out;
+    return region_view(wave, pp.region_size, rc.count, rc.half_ns);
 }
 
 // this wave's done-queue: `base` + 3 x MSK_DONE_Q float4 per wave of the block
@@ -1314,19 +1337,17 @@ k_wavefront(DeviceScene sc, PathState st, PassParams pp, uint32_t max_iters, uin
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
     if (lwave >= pp.region_count) return;
     const uint32_t wave = pp.region_first + lwave;
-    const size_t base = (size_t) wave * pp.region_size;
     for (uint32_t it = 0; it < max_iters; ++it) {
-        const uint32_t n = shade_region<DIFFUSE_ONLY>(sc, tb, dq, st, pp, wave, lane);
+        const RegionView rv = shade_region<DIFFUSE_ONLY>(sc, tb, dq, st, pp, wave, lane);
         // the rays this wave has just written are read back by the same wave (other lanes): program order through the
         // CU's own L1 after the stores have drained
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        if (n == 0) break;                                     // no live path, and regeneration found no sample to start
-        for (uint32_t c = lane; c < n; c += MSK_WAVE) {
-            const size_t i = base + c;
-            float4 ro = st.ray_o[i];
+        if (rv.n == 0) break;                                  // no live path, and regeneration found no sample to start
+        for (uint32_t c = lane; c < rv.n; c += MSK_WAVE) {
+            const uint32_t i = rv.slot(c);
+            const float4 ro = st.ray_o[i];
             float4 rd = st.ray_d[i];
-            const bool has_shadow = __float_as_int(ro.w) < 0;
-            ro.w = fabsf(ro.w);
+            const bool has_shadow = c < rv.ns;
             rd.w = slot_tmax(rd.w);
             const f3 o = mk3(ro.x, ro.y, ro.z);
             float bt, bu, bv; uint32_t bp;
@@ -1352,10 +1373,9 @@ k_aov_primary(DeviceScene sc, PathState st, PassParams pp, AovParams ap) {
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
     if (lwave >= pp.region_count) return;
     const uint32_t wave = pp.region_first + lwave;
-    const uint32_t n_in = pp.regions[wave].count;
-    const size_t base = (size_t) wave * pp.region_size;
-    for (uint32_t c = lane; c < n_in; c += MSK_WAVE) {
-        const size_t i = base + c;
+    const RegionView rv = region_view(wave, pp.region_size, pp.regions[wave].count, pp.regions[wave].half_ns);
+    for (uint32_t c = lane; c < rv.n; c += MSK_WAVE) {
+        const uint32_t i = rv.slot(c);
         const uint4 id = st.id[i];
         if ((id.w & MSK_DEPTH_MASK) != 1u) continue;
         const float4 hit = st.hit[i];
