@@ -315,6 +315,18 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         tri_pad = 0.5e-4f * diag;
     }
     mskbvh::Built bvh = mskbvh::build(pos.data(), d->n_faces, tri_pad);
+    // material class of every triangle into its leaf record's prim word (MSK_CLASS_SHIFT): the traversal hands it to the
+    // shading kernel with the hit, which sorts its paths by it
+    if (!all_diffuse)
+        for (size_t k = 0; k < d->n_faces; ++k) {
+            uint32_t w, mesh;
+            std::memcpy(&w, &bvh.tris[k * 16 + 3], 4);
+            std::memcpy(&mesh, &tv[(size_t) w * 12 + 3], 4);
+            const int32_t b = mesh_info[(size_t) mesh * 4];
+            const uint32_t cls = (b >= 0 && (uint32_t) b < d->n_bsdfs) ? (uint32_t) d->bsdfs[b].type : 0u;      // MSK_BSDF_* = 0, 1, 2
+            w |= (cls & (MSK_N_CLASSES - 1u)) << MSK_CLASS_SHIFT;
+            std::memcpy(&bvh.tris[k * 16 + 3], &w, 4);
+        }
 
     msk_scene *s = new msk_scene();
     s->ctx = ctx; s->n_tris = d->n_faces; s->bvh_depth = bvh.max_depth; s->all_diffuse = all_diffuse;
@@ -590,6 +602,12 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     pp0.packed = packed ? 1u : 0u;
     pp0.stack_ovf = nullptr;
     const bool diffuse_only = sc->all_diffuse && !aov_rgb;      // the AOV RGB record lives in the general shading variant
+    // material-sorted shading (general variant): LDS for the permutation, 3 bytes per slot of a region and wave (MSK_SORT=0: off)
+    const size_t sort_lds = (size_t) (MSK_BLOCK / MSK_WAVE) * 3 * region_size;
+    const bool sort_on = !diffuse_only && !sc->all_diffuse && region_size <= 4096 && env_u32("MSK_SORT", 1) &&
+                         sc->shade_lds_bytes + sort_lds <= 64 * 1024;
+    pp0.sort_scratch = sort_on ? 1u : 0u;
+    const size_t shade_lds = sc->shade_lds_bytes + (sort_on ? sort_lds : 0);
     const uint32_t group = env_u32("MSK_SYNC_GROUP", 8);
     static const size_t shade_pad_lds = (size_t) env_u32("MSK_SHADE_PAD_LDS_KB", 0) * 1024;   // occupancy experiments only
     const bool timing = stats != nullptr;
@@ -652,7 +670,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
                 hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
                 if (timed) { a = ev_h.get(); b = ev_h.get(); c = ev_h.get(); d = ev_h.get(); }
                 const bool have_ev = a && b && c && d;
-#define MSK_SHADE(L, D) hipExtLaunchKernelGGL((k_shade_gen<L, D>), dim3(grid), dim3(MSK_BLOCK), sc->shade_lds_bytes + shade_pad_lds, stream_h, a, b, 0, sc->dev, sb.st, pp)
+#define MSK_SHADE(L, D) hipExtLaunchKernelGGL((k_shade_gen<L, D>), dim3(grid), dim3(MSK_BLOCK), shade_lds + shade_pad_lds, stream_h, a, b, 0, sc->dev, sb.st, pp)
                 if (sc->lds_tables) { if (diffuse_only) MSK_SHADE(true, true); else MSK_SHADE(true, false); }
                 else { if (diffuse_only) MSK_SHADE(false, true); else MSK_SHADE(false, false); }
 #undef MSK_SHADE

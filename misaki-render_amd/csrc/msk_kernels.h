@@ -31,6 +31,13 @@ namespace msk {
 #define MSK_BLOCK 256
 #define MSK_LEAF_BIT 0x80000000u  /* child ref: leaf = BIT | first_tri << 5 | count ; inner = node index */
 #define MSK_NO_PRIM 0xffffffffu
+// The prim word of a triangle record / hit record: bits 0..25 the scene-global triangle index (msk_gpu_scene_create rejects
+// scenes of 2^26 triangles and more), bits 27..28 the MATERIAL CLASS of the triangle's BSDF (0 diffuse, 1 rough conductor,
+// 2 rough dielectric; a miss reads 3), written into the leaf records at scene creation so that the traversal kernels deliver
+// it with the hit for free.  k_shade_gen sorts a region's paths by it (material-sorted shading, shade_region).
+#define MSK_PRIM_ID 0x03ffffffu
+#define MSK_CLASS_SHIFT 27
+#define MSK_N_CLASSES 4
 #define MSK_DEPTH_MASK 0xffffu
 
 struct DeviceScene {
@@ -128,6 +135,7 @@ struct PassParams {
                                   //    rec_a.w = x word, rec_b = y word
     uint32_t region_size, n_regions;      // n_regions: all regions of the pass (the samples' static partition is over all of them)
     uint32_t region_first, region_count;  // the regions this launch covers (the pool's halves run on two streams)
+    uint32_t sort_scratch;        // 1: the shading launch has LDS for the material sort (3 bytes per slot of a region and wave)
     uint32_t trace_split;         // waves per region in k_trace (each takes every trace_split-th chunk); shading is one wave per region
     RegionCtl *regions;
     uint32_t *stack_ovf;          // traversal-stack overflow (LaneStack), (stack_total - stack_entries) x lanes words, or nullptr
@@ -270,7 +278,7 @@ MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict
             if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v, OVF ? nullptr : q + 4, tri_pad)) {
                 if (ANY) return true;
                 const uint32_t prim = __float_as_uint(q0.w);
-                if (bp == MSK_NO_PRIM || t < bt || (t == bt && prim < bp)) { bt = t; bu = u; bv = v; bp = prim; }
+                if (bp == MSK_NO_PRIM || t < bt || (t == bt && (prim & MSK_PRIM_ID) < (bp & MSK_PRIM_ID))) { bt = t; bu = u; bv = v; bp = prim; }
             }
         }
         if (sp > 0) { cur = stack.pop(sp); } else cur = DONE;
@@ -331,7 +339,7 @@ MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restric
             if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v, OVF ? nullptr : q + 4, tri_pad)) {
                 if (ANY) return true;
                 const uint32_t prim = __float_as_uint(q0.w);
-                if (bp == MSK_NO_PRIM || t < bt || (t == bt && prim < bp)) { bt = t; bu = u; bv = v; bp = prim; }
+                if (bp == MSK_NO_PRIM || t < bt || (t == bt && (prim & MSK_PRIM_ID) < (bp & MSK_PRIM_ID))) { bt = t; bu = u; bv = v; bp = prim; }
             }
         }
         if (sp > 0) { cur = stack.pop(sp); } else cur = DONE;
@@ -503,7 +511,7 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
             if (tri_test(q0, q1, q2, q3, t.o, t.d, t.tmin, t.tmax, &tt, &u, &v, MSK_OVF(MODE) ? nullptr : q + 4, sc.tri_pad)) {
                 if (any) { found = true; break; }
                 const uint32_t prim = __float_as_uint(q0.w);
-                if (t.bp == MSK_NO_PRIM || tt < t.bt || (tt == t.bt && prim < t.bp)) { t.bt = tt; t.bu = u; t.bv = v; t.bp = prim; }
+                if (t.bp == MSK_NO_PRIM || tt < t.bt || (tt == t.bt && (prim & MSK_PRIM_ID) < (t.bp & MSK_PRIM_ID))) { t.bt = tt; t.bu = u; t.bv = v; t.bp = prim; }
             }
         }
         if (t.sp > 0 && !found) { t.cur = stack.pop(t.sp); } else t.cur = DONE;
@@ -594,7 +602,7 @@ k_trace_batch(DeviceScene sc, const float4 *rays, uint64_t n, float4 *out_hit, u
             traverse_scene<MODE, false>(sc, g, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, stack, &bt, &bu, &bv, &bp);
             const bool valid = (bp != MSK_NO_PRIM) && (bt != rd.w);
             out_hit[i] = make_float4(valid ? bt : MSK_INF_F, valid ? bu : 0.f, valid ? bv : 0.f,
-                                     __uint_as_float(valid ? bp : MSK_NO_PRIM));
+                                     __uint_as_float(valid ? (bp & MSK_PRIM_ID) : MSK_NO_PRIM));
         }
     }
 }
@@ -962,10 +970,55 @@ MSK_DEV void emit_record(const DeviceScene &sc, const SceneTables &tb, const Pas
 #define MSK_DONE_Q 128                     /* entries per wave: up to 63 parked + 64 new */
 struct DoneQueue { float4 *wl, *res; uint4 *id; };
 
-// One shading sweep of region `wave` by its owner wave (see the file header); returns the region's live count afterwards.
+// Material-sorted shading (general variant).  Before a region is shaded its live paths are ordered by the material class of
+// the surface their ray has just hit (bits 27..28 of the hit record's prim word, delivered by the traversal): a counting
+// sort over the four classes with wave ballots and prefix popcounts, the permutation kept in LDS (two bytes per slot).
+// The sweep then reads the region through that permutation, so a chunk's 64 lanes run ONE BSDF's code — diffuse chunks
+// skip the microfacet branches altogether (no lane enters them), conductor chunks do not wait for the dielectric lobe
+// selection — instead of every chunk paying for every BSDF some lane of it needs.  Results do not depend on the order:
+// a path's arithmetic is its own and its record is addressed by (pixel, sample).  What makes reading in any order legal
+// is the two-half region (RegionView): nothing this sweep writes is something it still has to read.
+struct SortScratch { uint16_t *perm; uint8_t *cls; };        // per wave: region_size entries each, or {nullptr, nullptr}
+MSK_DEV bool sort_by_class(const PathState &st, const RegionView &in, const SortScratch &ss, uint32_t lane) {
+    uint32_t cnt[MSK_N_CLASSES] = {0u, 0u, 0u, 0u};
+    for (uint32_t c0 = 0; c0 < in.n; c0 += MSK_WAVE) {
+        const uint32_t c = c0 + lane;
+        uint32_t k = MSK_N_CLASSES;                           // no lane
+        if (c < in.n) {
+            k = (((const uint32_t *) &st.hit[in.slot(c)])[3] >> MSK_CLASS_SHIFT) & (MSK_N_CLASSES - 1u);
+            ss.cls[c] = (uint8_t) k;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < MSK_N_CLASSES; ++q) cnt[q] += (uint32_t) __popcll(__ballot(k == q));
+    }
+    uint32_t n_present = 0;
+#pragma unroll
+    for (uint32_t q = 0; q + 1 < MSK_N_CLASSES; ++q) n_present += cnt[q] ? 1u : 0u;
+    if (n_present <= 1u) return false;                        // one material (misses aside): the region is read in slot order
+    uint32_t start[MSK_N_CLASSES];
+    start[0] = 0;
+#pragma unroll
+    for (uint32_t q = 1; q < MSK_N_CLASSES; ++q) start[q] = start[q - 1] + cnt[q - 1];
+    wave_sync();
+    for (uint32_t c0 = 0; c0 < in.n; c0 += MSK_WAVE) {
+        const uint32_t c = c0 + lane;
+        const uint32_t k = c < in.n ? (uint32_t) ss.cls[c] : MSK_N_CLASSES;
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (uint32_t q = 0; q < MSK_N_CLASSES; ++q) {
+            const unsigned long long m = __ballot(k == q);
+            if (k == q) ss.perm[start[q] + (uint32_t) __popcll(m & below)] = (uint16_t) c;
+            start[q] += (uint32_t) __popcll(m);
+        }
+    }
+    wave_sync();
+    return true;
+}
+
+// One shading sweep of region `wave` by its owner wave (see the file header); returns the region as the sweep leaves it.
 template <bool DIFFUSE_ONLY>
-MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, const DoneQueue &dq, const PathState &st, const PassParams &pp,
-                                uint32_t wave, uint32_t lane) {
+MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, const DoneQueue &dq, const SortScratch &ss, const PathState &st,
+                                const PassParams &pp, uint32_t wave, uint32_t lane) {
     uint32_t n_queued = 0;
     RegionCtl rc = pp.regions[wave];
     const uint32_t n_in = rc.count;
@@ -980,8 +1033,15 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
     // A chunk's state as it is loaded.  (Measured and rejected: issuing the NEXT chunk's loads before this one is shaded — legal
     // with two-half regions — costs 30 VGPRs = one wave per SIMD and is slower, 21.6 vs 20.7 ms of shading per bench step.)
     struct ChunkIn { uint4 id; float4 wl, thr, res, rd4, hit, contrib; float2 aux; };
+    bool sorted = false;
+    if (!DIFFUSE_ONLY && ss.perm) sorted = sort_by_class(st, in, ss, lane);
+    // live index of this lane in the chunk that starts at c0 (the slot order, or the material order)
+    auto live_index = [&](uint32_t c0) {
+        const uint32_t p = c0 + lane;
+        return (!DIFFUSE_ONLY && sorted && p < n_in) ? (uint32_t) ss.perm[p] : p;
+    };
     auto load_chunk = [&](uint32_t c0) {
-        const uint32_t c = c0 + lane;
+        const uint32_t c = live_index(c0);
         const uint32_t i = in.slot(c < n_in ? c : 0u);
         ChunkIn k;
         k.id = st.id[i]; k.wl = st.wl[i]; k.thr = st.thr[i]; k.res = st.res[i]; k.rd4 = st.ray_d[i]; k.hit = st.hit[i];
@@ -992,7 +1052,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
         return k;
     };
     for (uint32_t c0 = 0; c0 < n_in; c0 += MSK_WAVE) {
-        const uint32_t c = c0 + lane;
+        const uint32_t c = live_index(c0);
         const bool active = c < n_in;
         const bool shadow_in = c < in.ns;          // this path's last bounce sent a shadow ray (ns <= n_in)
         // ---- load
@@ -1004,7 +1064,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
         // the previous bounce's NEE term (path.cpp:60-66), now that the shadow ray has been traced
         if (shadow_in && (__float_as_uint(hit.w) & MSK_HIT_UNOCCLUDED))
             res = res + from4(cur.contrib);
-        hit.w = __uint_as_float(__float_as_uint(hit.w) & MSK_PRIM_MASK);
+        hit.w = __uint_as_float(__float_as_uint(hit.w) & MSK_PRIM_ID);
         float bs_pdf = -rd4.w;                                             // meaningful for depth > 1 (PathState::ray_d)
         float eta = cur.aux.x, nee_pdf = cur.aux.y;                        // carried only by the general variant
         uint32_t depth = id.w & MSK_DEPTH_MASK;
@@ -1305,15 +1365,28 @@ MSK_DEV DoneQueue done_queue(float4 *base) {
 }
 
 template <bool LDS_TABLES, bool DIFFUSE_ONLY>
-__global__ void __launch_bounds__(MSK_BLOCK)
-k_shade_gen(DeviceScene sc, PathState st, PassParams pp) {
+MSK_DEV void shade_gen_body(const DeviceScene &sc, const PathState &st, const PassParams &pp) {
     extern __shared__ float4 lds_dyn[];
     const SceneTables tb = stage_tables<LDS_TABLES>(sc, lds_dyn);
     const uint32_t lwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
-    const DoneQueue dq = done_queue(lds_dyn + (LDS_TABLES ? tables_lds_float4s(sc) : 0u));      // after the staged tables
+    const uint32_t queue_f4 = LDS_TABLES ? tables_lds_float4s(sc) : 0u;                         // after the staged tables
+    const DoneQueue dq = done_queue(lds_dyn + queue_f4);
+    SortScratch ss{nullptr, nullptr};
+    if (!DIFFUSE_ONLY && pp.sort_scratch) {         // after the queues: per wave, 3 bytes per slot of a region (host: shade LDS plan)
+        uint8_t *p = (uint8_t *) (lds_dyn + queue_f4 + (MSK_BLOCK / MSK_WAVE) * 3 * MSK_DONE_Q) + (size_t) (threadIdx.x / MSK_WAVE) * 3u * pp.region_size;
+        ss.perm = (uint16_t *) p; ss.cls = p + 2u * pp.region_size;
+    }
     if (lwave >= pp.region_count) return;
-    shade_region<DIFFUSE_ONLY>(sc, tb, dq, st, pp, pp.region_first + lwave, threadIdx.x & (MSK_WAVE - 1));
+    shade_region<DIFFUSE_ONLY>(sc, tb, dq, ss, st, pp, pp.region_first + lwave, threadIdx.x & (MSK_WAVE - 1));
 }
+template <bool LDS_TABLES, bool DIFFUSE_ONLY>
+__global__ void __launch_bounds__(MSK_BLOCK)
+k_shade_gen(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<LDS_TABLES, DIFFUSE_ONLY>(sc, st, pp); }
+// The general variant with its tables in HBM sits a few registers above the 168 that three waves per SIMD allow (two cost
+// 20 % of the shading time on the mesh scenes): the allocator is told to stay at three.
+template <>
+__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_shade_gen<false, false>(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<false, false>(sc, st, pp); }
 
 // ------------------------------------------------------------------------------------------
 // k_wavefront: the iteration loop itself on the device, for scenes whose tree is staged in LDS.  A region is private to
@@ -1338,7 +1411,7 @@ k_wavefront(DeviceScene sc, PathState st, PassParams pp, uint32_t max_iters, uin
     if (lwave >= pp.region_count) return;
     const uint32_t wave = pp.region_first + lwave;
     for (uint32_t it = 0; it < max_iters; ++it) {
-        const RegionView rv = shade_region<DIFFUSE_ONLY>(sc, tb, dq, st, pp, wave, lane);
+        const RegionView rv = shade_region<DIFFUSE_ONLY>(sc, tb, dq, SortScratch{nullptr, nullptr}, st, pp, wave, lane);   // (the thin end of a pass: no sort)
         // the rays this wave has just written are read back by the same wave (other lanes): program order through the
         // CU's own L1 after the stores have drained
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1383,7 +1456,7 @@ k_aov_primary(DeviceScene sc, PathState st, PassParams pp, AovParams ap) {
 #pragma unroll
         for (int k = 0; k < 13; ++k) val[k] = 0.f;
         if (hit.x != MSK_INF_F) {
-            const uint32_t prim = __float_as_uint(hit.w) & MSK_PRIM_MASK;
+            const uint32_t prim = __float_as_uint(hit.w) & MSK_PRIM_ID;
             const float4 a = sc.tri_verts[(size_t) prim * 3], b = sc.tri_verts[(size_t) prim * 3 + 1], cc = sc.tri_verts[(size_t) prim * 3 + 2];
             const int4 mi = sc.mesh_info[__float_as_uint(a.w)];
             const f3 p0 = mk3(a.x, a.y, a.z), p1 = mk3(b.x, b.y, b.z), p2 = mk3(cc.x, cc.y, cc.z);

@@ -143,3 +143,31 @@ def test_gpu_matches_oracle_on_conductors(gpu_ctx, oracle, hostmirror, golden_lo
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     g.close()
     o.close()
+
+
+@pytest.mark.gpu
+def test_material_sorted_shading_changes_no_bit(gpu_ctx, oracle, hostmirror, golden_lookup, abi, monkeypatch):
+    """k_shade_gen reads a region through its material-class permutation (MSK_SORT=1, the default) or in slot order
+    (MSK_SORT=0): a path's arithmetic is its own and its record is addressed by (pixel, sample), so both give the
+    oracle's film bit for bit — on a scene where conductors, diffuse walls and misses share every region, at a spp
+    that runs the multi-stream loop with full regions."""
+    flat = conductor_scene(hostmirror, golden_lookup, 96, 96, blob_res=40)
+    g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+    prm = abi.render_params(spp=16, seed=3)
+    ref, rst = o.render(prm, threads=8)
+    films = {}
+    for sort in ("1", "0"):
+        monkeypatch.setenv("MSK_SORT", sort)
+        films[sort], st = g.render(prm)
+        assert st.samples == rst.samples
+        assert np.array_equal(films[sort].view(np.uint32), ref.view(np.uint32)), sort
+    # many more samples than slots: every region full, sorted every sweep (the film of the unsorted run is the reference)
+    big = abi.render_params(spp=700, seed=8)
+    monkeypatch.setenv("MSK_SORT", "0")
+    a, sa = g.render(big)
+    monkeypatch.setenv("MSK_SORT", "1")
+    b, sb = g.render(big)
+    assert sa.segments == sb.segments and sa.shadow_rays == sb.shadow_rays
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    g.close()
+    o.close()

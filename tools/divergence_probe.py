@@ -17,9 +17,12 @@ def scene(kind):
 for kind in ("all_diffuse", "all_conductor", "mixed", "mixed_half"):
     sc = abi.Scene(ctx, scene(kind))
     sc.render(abi.render_params(spp=16))
-    best = None
-    for _ in range(3):
-        _, st = sc.render(abi.render_params(spp=128))
-        if best is None or st.ms_shade < best.ms_shade: best = st
-    print("%-14s shade %.2f ms, %.1f M segments -> %.4f ns/segment; trace %.2f ms" % (kind, best.ms_shade, best.segments / 1e6, best.ms_shade * 1e6 / best.segments, best.ms_trace))
+    for sort in ("1", "0"):                       # material-sorted shading on / off (read per render)
+        os.environ["MSK_SORT"] = sort
+        best = None
+        for _ in range(3):
+            _, st = sc.render(abi.render_params(spp=128))
+            if best is None or st.ms_shade < best.ms_shade: best = st
+        print("%-14s MSK_SORT=%s shade %.2f ms, %.1f M segments -> %.4f ns/segment; trace %.2f ms; total %.2f ms" % (
+            kind, sort, best.ms_shade, best.segments / 1e6, best.ms_shade * 1e6 / best.segments, best.ms_trace, best.ms_total))
     sc.close()
