@@ -51,6 +51,17 @@ struct Built {
     std::vector<float> nodes4;
     uint32_t root_ref4 = 0;
     int max_depth4 = 0;
+    // 8-wide form with QUANTISED child boxes (collapse8): 32 dwords (128 B = one L2 line) per node,
+    //   dw 0-2  origin (the low corner of the node's box)      dw 3  meta: bits 0-1 ordering axis, bits 8-15 mask of used slots
+    //   dw 4-6  scale (a power of two per axis)                dw 7  -
+    //   dw 8-19 child boxes as bytes, slot s = byte s of a dword pair: lo.x[8] lo.y[8] lo.z[8] hi.x[8] hi.y[8] hi.z[8]
+    //           child box = [origin + lo * scale, origin + hi * scale], rounded OUTWARDS (it contains the padded box above)
+    //   dw 20-27 child refs (as above), kEmpty4 for an unused slot (whose box is inverted: lo = 255, hi = 0)
+    // Slots are ordered by the children's centres along the ordering axis, so a ray visits them front to back by walking the
+    // slots up or down according to the sign of its direction on that axis — no sorting of eight distances per visit.
+    std::vector<float> nodes8;
+    uint32_t root_ref8 = 0;
+    int max_depth8 = 0;
 };
 static constexpr uint32_t kEmpty4 = 0xfffffffeu;
 
@@ -239,6 +250,83 @@ static inline void collapse4(Built &b) {
     b.root_ref4 = c.collapse(b.root_ref, 1);
     b.nodes4 = std::move(c.out);
     b.max_depth4 = c.max_depth;
+}
+
+// Collapses the binary tree into 8-wide nodes with quantised child boxes (layout: Built::nodes8).
+struct Collapser8 {
+    const std::vector<float> &n2;
+    std::vector<float> out;
+    int max_depth = 0;
+    typedef Collapser::Slot Slot;
+    void children(uint32_t node, Slot *a, Slot *b) const { Collapser c{n2, {}, 0}; c.children(node, a, b); }
+    uint32_t collapse(uint32_t node, int depth) {
+        max_depth = std::max(max_depth, depth);
+        Slot s[8]; int ns = 2;
+        children(node, &s[0], &s[1]);
+        while (ns < 8) {                 // open the inner child with the largest surface area
+            int best = -1; float best_area = -1.f;
+            for (int i = 0; i < ns; ++i)
+                if (!(s[i].ref & 0x80000000u) && Collapser::area(s[i]) > best_area) { best = i; best_area = Collapser::area(s[i]); }
+            if (best < 0) break;
+            Slot a, b; children(s[best].ref, &a, &b);
+            s[best] = a; s[ns++] = b;
+        }
+        // ordering axis: the one along which the children's centres spread most; slots ascending along it
+        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = 0; i < ns; ++i)
+            for (int a = 0; a < 3; ++a) {
+                const float c = 0.5f * (s[i].lo[a] + s[i].hi[a]);
+                clo[a] = std::min(clo[a], c); chi[a] = std::max(chi[a], c);
+                lo[a] = std::min(lo[a], (double) s[i].lo[a]); hi[a] = std::max(hi[a], (double) s[i].hi[a]);
+            }
+        int axis = 0;
+        for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+        std::stable_sort(s, s + ns, [&](const Slot &x, const Slot &y) { return x.lo[axis] + x.hi[axis] < y.lo[axis] + y.hi[axis]; });
+        const uint32_t me = (uint32_t) (out.size() / 32);
+        out.resize(out.size() + 32, 0.f);
+        uint32_t refs[8];
+        for (int i = 0; i < 8; ++i) {
+            if (i >= ns) refs[i] = kEmpty4;
+            else if (s[i].ref & 0x80000000u) refs[i] = s[i].ref;
+            else refs[i] = collapse(s[i].ref, depth + 1);
+        }
+        // quantisation frame: origin = low corner (a float), scale = the power of two with 255 * scale >= extent
+        float origin[3], scale[3];
+        uint8_t q[6][8];
+        for (int a = 0; a < 3; ++a) {
+            origin[a] = (float) lo[a];
+            const double ext = hi[a] - (double) origin[a];
+            int e = ext > 0 ? (int) std::ceil(std::log2(ext / 255.0)) : -60;
+            e = std::max(-100, std::min(100, e));
+            while (255.0 * std::ldexp(1.0, e) < ext) ++e;              // (log2 rounding)
+            scale[a] = (float) std::ldexp(1.0, e);
+            const double sc = std::ldexp(1.0, e);
+            for (int i = 0; i < 8; ++i) {
+                if (i >= ns) { q[a][i] = 255; q[3 + a][i] = 0; continue; }
+                double ql = std::floor(((double) s[i].lo[a] - (double) origin[a]) / sc), qh = std::ceil(((double) s[i].hi[a] - (double) origin[a]) / sc);
+                ql = std::max(0.0, std::min(255.0, ql)); qh = std::max(0.0, std::min(255.0, qh));
+                // exact in double: origin + q * 2^e; the decoded box must contain the child's
+                if ((double) origin[a] + ql * sc > (double) s[i].lo[a] || (double) origin[a] + qh * sc < (double) s[i].hi[a]) std::abort();
+                q[a][i] = (uint8_t) ql; q[3 + a][i] = (uint8_t) qh;
+            }
+        }
+        float *o = &out[(size_t) me * 32];
+        const uint32_t meta = (uint32_t) axis | (((1u << ns) - 1u) << 8);
+        std::memcpy(&o[0], origin, 12); std::memcpy(&o[3], &meta, 4);
+        std::memcpy(&o[4], scale, 12);
+        std::memcpy(&o[8], q, 48);
+        std::memcpy(&o[20], refs, 32);
+        return me;
+    }
+};
+static inline void collapse8(Built &b) {
+    b.nodes8.clear(); b.root_ref8 = b.root_ref; b.max_depth8 = 0;
+    if (b.root_ref & 0x80000000u) return;
+    Collapser8 c{b.nodes, {}, 0};
+    b.root_ref8 = c.collapse(b.root_ref, 1);
+    b.nodes8 = std::move(c.out);
+    b.max_depth8 = c.max_depth;
 }
 
 }  // namespace mskbvh

@@ -75,17 +75,22 @@ struct DevBuf {
 };
 
 static uint32_t env_u32(const char *name, uint32_t def);
+// width of the tree for scenes that do not fit LDS: 4 (full-precision boxes) or 8 (quantised boxes); MSK_WIDE_BVH overrides, 0 = binary
+#ifndef MSK_WIDE_BVH_DEFAULT
+#define MSK_WIDE_BVH_DEFAULT 4
+#endif
 struct Workspace;
 struct msk_scene {
     msk_ctx *ctx = nullptr;
     Workspace *ws = nullptr;           // render buffers, kept between calls (hipMalloc/hipFree of GBs costs milliseconds)
     DeviceScene dev;
-    DevBuf nodes, nodes4, tris, tri_bounds, tri_verts, tri_frames, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
+    DevBuf nodes, nodes4, nodes8, tris, tri_bounds, tri_verts, tri_frames, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
     bool lds_scene = false, lds_tables = false, all_diffuse = true;
-    int trace_mode = 0;                // 0 binary tree in LDS, 1 binary tree in HBM/L2, 2 4-wide tree in HBM/L2
+    int trace_mode = 0;                // 0 binary tree in LDS, 1 binary tree in HBM/L2, 2 4-wide tree in HBM/L2, 4 8-wide quantised tree in HBM/L2
     size_t trace_lds_bytes = 0, shade_lds_bytes = 0;
     int bvh_depth = 0;
     uint32_t n_tris = 0;
+    size_t tree_bytes = 0;             // node array the traversal walks
 };
 
 // ------------------------------------------------------------------------------------------
@@ -375,7 +380,17 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     s->lds_scene = scene_bytes <= lds_cap && stack_bytes + scene_bytes <= 64 * 1024;
     s->trace_lds_bytes = stack_bytes + (s->lds_scene ? scene_bytes : 0);
     s->trace_mode = s->lds_scene ? 0 : 1;
-    if (!s->lds_scene && env_u32("MSK_WIDE_BVH", 1) && !(bvh.root_ref & MSK_LEAF_BIT)) {
+    s->tree_bytes = bvh.nodes.size() * 4;
+    if (!s->lds_scene && env_u32("MSK_WIDE_BVH", MSK_WIDE_BVH_DEFAULT) == 8 && !(bvh.root_ref & MSK_LEAF_BIT)) {
+        // the tree stays in HBM/L2: eight quantised child boxes per 128-byte line (msk_bvh.h: collapse8)
+        mskbvh::collapse8(bvh);
+        hipError_t e8 = s->nodes8.upload(bvh.nodes8);
+        if (e8 != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(e8)); }
+        ds.nodes8 = s->nodes8.as<float4>(); ds.root_ref8 = bvh.root_ref8; ds.n_nodes8 = (uint32_t) (bvh.nodes8.size() / 32);
+        ds.stack_entries = (uint32_t) ((7 * bvh.max_depth8 + 2 + 3) & ~3);     // up to seven pushes per level
+        s->trace_mode = 4;
+        s->tree_bytes = bvh.nodes8.size() * 4;
+    } else if (!s->lds_scene && env_u32("MSK_WIDE_BVH", MSK_WIDE_BVH_DEFAULT) && !(bvh.root_ref & MSK_LEAF_BIT)) {
         // the tree stays in HBM/L2: walk it four children at a time, one 128-byte line per visit
         mskbvh::collapse4(bvh);
         hipError_t e4 = s->nodes4.upload(bvh.nodes4);
@@ -383,6 +398,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         ds.nodes4 = s->nodes4.as<float4>(); ds.root_ref4 = bvh.root_ref4; ds.n_nodes4 = (uint32_t) (bvh.nodes4.size() / 32);
         ds.stack_entries = (uint32_t) ((3 * bvh.max_depth4 + 2 + 3) & ~3);     // up to three pushes per level
         s->trace_mode = 2;
+        s->tree_bytes = bvh.nodes4.size() * 4;
     } else if (s->lds_scene && env_u32("MSK_WIDE_LDS", 0) && !(bvh.root_ref & MSK_LEAF_BIT)) {
         // experiment knob, off by default: the 4-wide tree staged in LDS (half the dependent LDS round trips per ray).
         // Measured on cbox: trace 12.45 vs 12.34 ms for the binary tree — no gain.
@@ -395,7 +411,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         s->trace_mode = 3;
     }
     ds.stack_total = ds.stack_entries;
-    if (s->trace_mode == 1 || s->trace_mode == 2) {
+    if (s->trace_mode == 1 || s->trace_mode == 2 || s->trace_mode == 4) {
         // trees in HBM: only the first MSK_STACK_CAP entries of a lane's stack live in LDS, the rest in an HBM overflow
         // array (LaneStack) — any tree depth works within a fixed 24 KB of LDS per block.  (Measured: the cap does not
         // change the trace time between 8 and 40 entries; the traversal needs >= 4 waves per SIMD and has them.)
@@ -543,7 +559,8 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
     const int refill = (sc->trace_mode == 3) ? 0 : refill_env >= 0 ? refill_env : (sc->trace_mode == 0 ? 0 : 16);
     const size_t lds = sc->trace_lds_bytes + (size_t) env_u32("MSK_TRACE_PAD_LDS_KB", 0) * 1024;      // occupancy experiments only
     if (refill > 0) {        // k_trace_r
-        if (sc->trace_mode == 0) hipExtLaunchKernelGGL(k_trace_r<0>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
+        if (sc->trace_mode == 4) hipExtLaunchKernelGGL(k_trace_r<4>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
+        else if (sc->trace_mode == 0) hipExtLaunchKernelGGL(k_trace_r<0>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         else if (sc->trace_mode == 1) hipExtLaunchKernelGGL(k_trace_r<1>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         else hipExtLaunchKernelGGL(k_trace_r<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         return;
@@ -555,6 +572,7 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
     }
     else if (sc->trace_mode == 1) hipExtLaunchKernelGGL(k_trace<1>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
     else if (sc->trace_mode == 2) hipExtLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
+    else if (sc->trace_mode == 4) hipExtLaunchKernelGGL(k_trace<4>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
     else hipExtLaunchKernelGGL(k_trace<3>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
 }
 
@@ -784,7 +802,7 @@ static uint32_t owned_spp(const msk_render_params *p) {
 // wants many waves per launch).  Long rays (k_trace_r): 4096 regions of 2048 slots = 8 M, so that lane replacement has a long
 // list of rays to keep the lanes busy with.
 static void pool_shape(const msk_scene *sc, uint64_t total_samples, uint32_t *region_size, uint32_t *n_regions) {
-    const bool big = sc->trace_mode == 1 || sc->trace_mode == 2;
+    const bool big = sc->trace_mode == 1 || sc->trace_mode == 2 || sc->trace_mode == 4;
     uint32_t rs = env_u32("MSK_REGION_SIZE", big ? 2048 : 512), nr = env_u32("MSK_REGIONS", big ? 4096 : 8192);
     rs = std::max(64u, (rs + 63u) & ~63u);
     while (rs > 256 && total_samples / rs < nr) rs = std::max(256u, rs / 2);       // small jobs: keep the GPU full first
@@ -1120,6 +1138,9 @@ static int trace_batch(msk_scene *scene, uint64_t n, const float *rays, float *o
                            d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
     else if (scene->trace_mode == 2)
         hipLaunchKernelGGL(k_trace_batch<2>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
+                           d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
+    else if (scene->trace_mode == 4)
+        hipLaunchKernelGGL(k_trace_batch<4>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
                            d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
     else
         hipLaunchKernelGGL(k_trace_batch<3>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,

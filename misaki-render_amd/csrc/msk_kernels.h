@@ -44,6 +44,8 @@ struct DeviceScene {
     const float4 *nodes;        // 4 x float4 per node (msk_bvh.h)
     const float4 *nodes4;       // 8 x float4 per 4-wide node, or nullptr (scenes whose BVH is staged in LDS use `nodes`)
     uint32_t root_ref4, n_nodes4;
+    const float4 *nodes8;       // 8 x float4 per 8-wide node with quantised child boxes (msk_bvh.h: collapse8), or nullptr
+    uint32_t root_ref8, n_nodes8;
     const float4 *tris;         // 4 x float4 per triangle, leaf order (msk_bvh.h)
     const float4 *tri_bounds;   // 2 x float4 per triangle, leaf order: padded bounds of the D10 predicate (staged next to the
                                 // triangles for LDS-resident scenes; trees in HBM recompute them from the record instead)
@@ -348,6 +350,96 @@ MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restric
     return false;
 }
 
+// ------------------------------------------------------------------------------------------
+// 8-wide nodes with quantised child boxes (msk_bvh.h: Built::nodes8), for trees that live in HBM/L2: one 128-byte line and
+// one dependent round trip per eight boxes, a tree a quarter of the binary one's size.  A visit moves the ray into the
+// node's frame — t = q * (scale * idir) + (origin - o) * idir for a box plane stored as the byte q — picks each axis's near
+// and far planes by the sign of the direction, tests the eight boxes and hands back the nearest hit child IN SLOT ORDER
+// (the builder sorted the slots along the node's ordering axis; the ray walks them up or down by the sign of its direction
+// there), the others go on the stack farthest first.  The boxes are conservative (rounded outwards around boxes that are
+// already padded by 1e-4 of the scene diagonal), so this, too, can only cull what no triangle test would accept: the hit is
+// the binary tree's, bit for bit.
+// ------------------------------------------------------------------------------------------
+#define MSK_NONE_REF 0xffffffffu
+template <bool OVF>
+MSK_DEV uint32_t node8_step(const float4 *__restrict__ nodes8, uint32_t node, f3 o, f3 d, f3 idir, float tmin, float tcur,
+                            const LaneStack<OVF> &stack, int &sp) {
+    const uint4 *n = (const uint4 *) (nodes8 + (size_t) node * 8);
+    const uint4 h0 = n[0], h1 = n[1], q0 = n[2], q1 = n[3], q2 = n[4], r0 = n[5], r1 = n[6];
+    const float ax = __uint_as_float(h1.x) * idir.x, ay = __uint_as_float(h1.y) * idir.y, az = __uint_as_float(h1.z) * idir.z;
+    const float bx = (__uint_as_float(h0.x) - o.x) * idir.x, by = (__uint_as_float(h0.y) - o.y) * idir.y, bz = (__uint_as_float(h0.z) - o.z) * idir.z;
+    // q0 = lo.x[0..7] lo.y[0..7]; q1 = lo.z, hi.x; q2 = hi.y, hi.z (two dwords of four bytes each)
+    const bool nx = idir.x < 0.f, ny = idir.y < 0.f, nz = idir.z < 0.f;
+    const uint32_t nxa = nx ? q1.z : q0.x, nxb = nx ? q1.w : q0.y, fxa = nx ? q0.x : q1.z, fxb = nx ? q0.y : q1.w;
+    const uint32_t nya = ny ? q2.x : q0.z, nyb = ny ? q2.y : q0.w, fya = ny ? q0.z : q2.x, fyb = ny ? q0.w : q2.y;
+    const uint32_t nza = nz ? q2.z : q1.x, nzb = nz ? q2.w : q1.y, fza = nz ? q1.x : q2.z, fzb = nz ? q1.y : q2.w;
+    uint32_t mask = 0;
+#define MSK_BYTE(w, k) ((float) (((w) >> (8 * (k))) & 0xffu))
+#define MSK_BOX8(S, NXW, NYW, NZW, FXW, FYW, FZW, K) {                                                                     \
+        const float t0 = fmaxf(fmaxf(__fmaf_rn(MSK_BYTE(NXW, K), ax, bx), __fmaf_rn(MSK_BYTE(NYW, K), ay, by)),            \
+                               fmaxf(__fmaf_rn(MSK_BYTE(NZW, K), az, bz), tmin));                                          \
+        const float t1 = fminf(fminf(__fmaf_rn(MSK_BYTE(FXW, K), ax, bx), __fmaf_rn(MSK_BYTE(FYW, K), ay, by)),            \
+                               fminf(__fmaf_rn(MSK_BYTE(FZW, K), az, bz), tcur));                                          \
+        mask |= (t0 <= t1 * 1.0000004f) ? (1u << (S)) : 0u; }
+    MSK_BOX8(0, nxa, nya, nza, fxa, fya, fza, 0) MSK_BOX8(1, nxa, nya, nza, fxa, fya, fza, 1)
+    MSK_BOX8(2, nxa, nya, nza, fxa, fya, fza, 2) MSK_BOX8(3, nxa, nya, nza, fxa, fya, fza, 3)
+    MSK_BOX8(4, nxb, nyb, nzb, fxb, fyb, fzb, 0) MSK_BOX8(5, nxb, nyb, nzb, fxb, fyb, fzb, 1)
+    MSK_BOX8(6, nxb, nyb, nzb, fxb, fyb, fzb, 2) MSK_BOX8(7, nxb, nyb, nzb, fxb, fyb, fzb, 3)
+#undef MSK_BOX8
+#undef MSK_BYTE
+    mask &= (h0.w >> 8) & 0xffu;                       // used slots only (an unused one holds no ref)
+    if (mask == 0u) return MSK_NONE_REF;
+    const uint32_t axis = h0.w & 3u;
+    const float da = axis == 0u ? d.x : axis == 1u ? d.y : d.z;
+    // the nearest hit child in slot order is returned, the others are pushed farthest first; `pend` delays every push by one
+    // so that the nearest never goes through the stack
+    uint32_t pend = MSK_NONE_REF;
+#define MSK_VISIT(S, R) if (mask & (1u << (S))) { if (pend != MSK_NONE_REF) stack.push(sp, pend); pend = (R); }
+    if (da >= 0.f) {
+        MSK_VISIT(7, r1.w) MSK_VISIT(6, r1.z) MSK_VISIT(5, r1.y) MSK_VISIT(4, r1.x) MSK_VISIT(3, r0.w) MSK_VISIT(2, r0.z) MSK_VISIT(1, r0.y) MSK_VISIT(0, r0.x)
+    } else {
+        MSK_VISIT(0, r0.x) MSK_VISIT(1, r0.y) MSK_VISIT(2, r0.z) MSK_VISIT(3, r0.w) MSK_VISIT(4, r1.x) MSK_VISIT(5, r1.y) MSK_VISIT(6, r1.z) MSK_VISIT(7, r1.w)
+    }
+#undef MSK_VISIT
+    return pend;
+}
+
+// The traversal over those nodes; leaves and triangles as in traverse4.
+template <bool ANY, bool OVF>
+MSK_DEV bool traverse8(const float4 *__restrict__ nodes8, const float4 *__restrict__ tris, float tri_pad, uint32_t root_ref,
+                       uint32_t n_tris, f3 o, f3 d, float tmin, float tmax, const LaneStack<OVF> &stack, float *best_t, float *best_u,
+                       float *best_v, uint32_t *best_prim) {
+    float bt = tmax, bu = 0.f, bv = 0.f;
+    uint32_t bp = MSK_NO_PRIM;
+    *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
+    if (n_tris == 0) return false;
+    const f3 idir = slab_idir(d);
+    int sp = 0;
+    uint32_t cur = root_ref;
+    const uint32_t DONE = 0xffffffffu;
+    while (cur != DONE) {
+        while (!(cur & MSK_LEAF_BIT)) {
+            cur = node8_step<OVF>(nodes8, cur, o, d, idir, tmin, bt, stack, sp);
+            if (cur == MSK_NONE_REF) { if (sp > 0) cur = stack.pop(sp); else break; }      // MSK_NONE_REF == DONE
+        }
+        if (cur == DONE) break;
+        const uint32_t first = (cur & 0x7fffffffu) >> 5, cnt = cur & 31u;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const float4 *q = tris + (size_t) (first + i) * 4;
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            float t, u, v;
+            if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v, nullptr, tri_pad)) {
+                if (ANY) return true;
+                const uint32_t prim = __float_as_uint(q0.w);
+                if (bp == MSK_NO_PRIM || t < bt || (t == bt && (prim & MSK_PRIM_ID) < (bp & MSK_PRIM_ID))) { bt = t; bu = u; bv = v; bp = prim; }
+            }
+        }
+        if (sp > 0) { cur = stack.pop(sp); } else cur = DONE;
+    }
+    *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
+    return false;
+}
+
 struct TraceLds {
     const float4 *nodes, *tris;        // staged triangles are 6 float4 each (record + bounds), global ones 4
 };
@@ -385,12 +477,14 @@ MSK_DEV float slot_tmax(float rd_w) {
 }
 #define MSK_HIT_UNOCCLUDED 0x80000000u
 #define MSK_PRIM_MASK 0x7fffffffu
-// MODE 0: binary tree staged in LDS; 1: binary tree in HBM/L2; 2: 4-wide tree in HBM/L2; 3: 4-wide tree staged in LDS
-#define MSK_OVF(MODE) ((MODE) == 1 || (MODE) == 2)      /* the stack can overflow to HBM only when the tree lives there */
+// MODE 0: binary tree staged in LDS; 1: binary tree in HBM/L2; 2: 4-wide tree in HBM/L2; 3: 4-wide tree staged in LDS;
+// 4: 8-wide tree with quantised boxes in HBM/L2
+#define MSK_OVF(MODE) ((MODE) == 1 || (MODE) == 2 || (MODE) == 4)      /* the stack can overflow to HBM only when the tree lives there */
 template <int MODE, bool ANY>
 MSK_DEV bool traverse_scene(const DeviceScene &sc, const TraceLds &g, f3 o, f3 d, float tmin, float tmax, const LaneStack<MSK_OVF(MODE)> &stack,
                             float *bt, float *bu, float *bv, uint32_t *bp) {
-    if (MODE == 2 || MODE == 3) return traverse4<ANY, MSK_OVF(MODE)>(MODE == 3 ? g.nodes : sc.nodes4, g.tris, sc.tri_pad, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+    if constexpr (MODE == 4) return traverse8<ANY, true>(sc.nodes8, g.tris, sc.tri_pad, sc.root_ref8, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+    else if (MODE == 2 || MODE == 3) return traverse4<ANY, MSK_OVF(MODE)>(MODE == 3 ? g.nodes : sc.nodes4, g.tris, sc.tri_pad, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
     return traverse<ANY, MSK_OVF(MODE)>(g.nodes, g.tris, sc.tri_pad, sc.root_ref, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
 }
 
@@ -463,7 +557,10 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
     bool found = false;
     while (!(t.cur & MSK_LEAF_BIT) && steps < max_inner) {
         ++steps;
-        if (MODE == 2) {
+        if constexpr (MODE == 4) {
+            t.cur = node8_step<true>(sc.nodes8, t.cur, t.o, t.d, t.idir, t.tmin, t.bt, stack, t.sp);
+            if (t.cur == MSK_NONE_REF && t.sp > 0) t.cur = stack.pop(t.sp);
+        } else if (MODE == 2) {
             const float4 *n = sc.nodes4 + (size_t) t.cur * 8;
             const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], rf = n[6];
             float t0, t1, t2, t3;
@@ -555,9 +652,9 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
                     unocc = 0; active = true;
                     if (shadow_phase) {
                         const float4 s = st.sh[slot];
-                        trav_begin(t, MODE == 2 ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(s.x, s.y, s.z), ro.w, s.w);
+                        trav_begin(t, MODE == 4 ? sc.root_ref8 : MODE == 2 ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(s.x, s.y, s.z), ro.w, s.w);
                     } else {
-                        trav_begin(t, MODE == 2 ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+                        trav_begin(t, MODE == 4 ? sc.root_ref8 : MODE == 2 ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
                     }
                 }
             }
@@ -570,7 +667,7 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
                 if (shadow_phase) {
                     unocc = occ ? 0u : MSK_HIT_UNOCCLUDED;
                     shadow_phase = false;
-                    trav_begin(t, MODE == 2 ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+                    trav_begin(t, MODE == 4 ? sc.root_ref8 : MODE == 2 ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
                 } else {
                     const bool valid = (t.bp != MSK_NO_PRIM) && (t.bt != rd.w);
                     st.hit[slot] = make_float4(valid ? t.bt : MSK_INF_F, t.bu, t.bv, __uint_as_float((valid ? t.bp : MSK_PRIM_MASK) | unocc));
