@@ -6,6 +6,7 @@
 // resolve.  Everything per-sample runs in the kernels of msk_kernels.h.
 #include "msk_kernels.h"
 #include "msk_bvh.h"
+#include "msk_lbvh.h"
 #include "../../include/msk_gpu.h"
 #include <hip/hip_ext.h>
 
@@ -309,20 +310,26 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     if (cdf_all.empty()) cdf_all.push_back(0.f);
 
     // oracle D10: the triangle-bounds predicate's padding, computed exactly as the oracle does (0.5e-4 * |hi - lo|)
-    float tri_pad;
+    float tri_pad, scene_lo[3] = {INFINITY, INFINITY, INFINITY}, scene_hi[3] = {-INFINITY, -INFINITY, -INFINITY}, scene_diag;
     {
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        float *lo = scene_lo, *hi = scene_hi;
         for (uint32_t t = 0; t < d->n_faces; ++t)
             for (int v = 0; v < 3; ++v)
                 for (int k = 0; k < 3; ++k) { const float q = pos[(size_t) t * 9 + v * 3 + k]; lo[k] = std::min(lo[k], q); hi[k] = std::max(hi[k], q); }
         const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
         const float diag = d->n_faces ? std::sqrt(ex * ex + (ey * ey + ez * ez)) : 1.f;
         tri_pad = 0.5e-4f * diag;
+        scene_diag = diag;
     }
-    mskbvh::Built bvh = mskbvh::build(pos.data(), d->n_faces, tri_pad);
+    // MSK_BVH_BUILD=gpu: the tree is built on the device (msk_lbvh.hip, a linear BVH) once the vertices are uploaded — the
+    // option for scenes that change between renders; default: the host's binned-SAH builder (msk_bvh.h), the better tree
+    const char *build_env = getenv("MSK_BVH_BUILD");
+    const bool gpu_build = build_env && !strcmp(build_env, "gpu") && d->n_faces > 0;
+    mskbvh::Built bvh;
+    if (!gpu_build) bvh = mskbvh::build(pos.data(), d->n_faces, tri_pad);
     // material class of every triangle into its leaf record's prim word (MSK_CLASS_SHIFT): the traversal hands it to the
     // shading kernel with the hit, which sorts its paths by it
-    if (!all_diffuse)
+    if (!all_diffuse && !gpu_build)
         for (size_t k = 0; k < d->n_faces; ++k) {
             uint32_t w, mesh;
             std::memcpy(&w, &bvh.tris[k * 16 + 3], 4);
@@ -338,10 +345,37 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     std::vector<float> cie(d->cie1931_xyz, d->cie1931_xyz + 3 * MSK_CIE_SAMPLES);
     hipError_t e = hipSuccess;
     auto up = [&](DevBuf &b, const std::vector<float> &v) { if (e == hipSuccess) e = b.upload(v); };
-    up(s->nodes, bvh.nodes); up(s->tris, bvh.tris); up(s->tri_bounds, bvh.bounds); up(s->tri_verts, tv); up(s->tri_normals, tn); up(s->tri_uvs, tuv);
+    if (!gpu_build) { up(s->nodes, bvh.nodes); up(s->tris, bvh.tris); up(s->tri_bounds, bvh.bounds); }
+    up(s->tri_verts, tv); up(s->tri_normals, tn); up(s->tri_uvs, tuv);
     up(s->bsdfs, bsdfs); up(s->emitters, emitters); up(s->emitter_d65, d65); up(s->cdf, cdf_all); up(s->cie, cie);
     if (e == hipSuccess) e = s->mesh_info.upload(mesh_info);
+    if (e == hipSuccess && gpu_build) {
+        const size_t nf = d->n_faces;
+        if ((e = s->nodes.alloc(nf * 64)) == hipSuccess && (e = s->tris.alloc(nf * 64)) == hipSuccess) e = s->tri_bounds.alloc(nf * 32);
+    }
     if (e != hipSuccess) { delete s; return fail(ctx, e == hipErrorOutOfMemory ? MSK_ERR_OOM : MSK_ERR_HIP, "scene upload: %s", hipGetErrorString(e)); }
+    if (gpu_build) {
+        msklbvh::Input in;
+        in.tri_verts = s->tri_verts.as<float4>(); in.n_tris = d->n_faces;
+        for (int k = 0; k < 3; ++k) { in.lo[k] = scene_lo[k]; in.hi[k] = scene_hi[k]; }
+        in.box_pad = 1e-4f * scene_diag; in.tri_pad = tri_pad;
+        in.leaf_size = getenv("MSK_BVH_LEAF") ? (uint32_t) std::max(1, std::min(8, atoi(getenv("MSK_BVH_LEAF")))) : 2u;
+        in.mesh_info = s->mesh_info.as<int4>(); in.bsdfs = s->bsdfs.as<float4>(); in.n_bsdfs = d->n_bsdfs; in.bsdf_f4 = MSK_BSDF_F4;
+        in.class_shift = all_diffuse ? 0u : (uint32_t) MSK_CLASS_SHIFT;
+        msklbvh::Result res;
+        char msg[256] = "";
+        if (msklbvh::build(ctx->stream, in, s->nodes.as<float4>(), s->tris.as<float4>(), s->tri_bounds.as<float4>(), &res, msg, sizeof msg)) {
+            delete s;
+            return fail(ctx, MSK_ERR_HIP, "device BVH build: %s", msg);
+        }
+        // the node records back on the host: the size / depth bookkeeping below and the wide collapse read them
+        bvh.root_ref = res.root_ref; bvh.max_depth = res.depth;
+        bvh.nodes.resize((size_t) res.n_nodes * 16);
+        if (res.n_nodes) {
+            hipError_t ec = hipMemcpy(bvh.nodes.data(), s->nodes.p, (size_t) res.n_nodes * 64, hipMemcpyDeviceToHost);
+            if (ec != hipSuccess) { delete s; return fail(ctx, MSK_ERR_HIP, "device BVH build: %s", hipGetErrorString(ec)); }
+        }
+    }
 
     DeviceScene &ds = s->dev;
     std::memset(&ds, 0, sizeof ds);

@@ -94,3 +94,30 @@ def test_full_size_properties(big, abi):
     assert np.allclose(halves[0] + halves[1], full, rtol=1e-4, atol=1e-4)
     again, _ = g.render(abi.render_params(spp=spp, seed=5))
     assert np.array_equal(again.view(np.uint32), full.view(np.uint32))
+
+
+def test_device_built_tree_gives_the_same_hits_and_samples(gpu_ctx, abi, hostmirror, oracle, monkeypatch):
+    """MSK_BVH_BUILD=gpu (msk_lbvh.hip: Morton sort + Karras hierarchy + bottom-up refit on the device) on the 146 k-triangle
+    scene: another tree, the same hits — ray level against the host-built tree's answers (themselves checked against the
+    oracle's brute force above), sample level against the oracle."""
+    flat = hostmirror.teapot_class_scene(1024)
+    host = abi.Scene(gpu_ctx, flat)
+    o = oracle.scene(flat)
+    rays = _rays(flat, o, 100_000, 31)
+    want, want_any = host.trace_closest(rays), host.trace_any(rays)
+    pixels = np.stack([np.random.RandomState(3).randint(380, 650, 24), np.random.RandomState(4).randint(420, 760, 24)], 1).astype(np.int32)
+    prm = abi.render_params(spp=4, seed=2)
+    ox, _ = o.sample_pixels(prm, pixels)
+    for env in (dict(MSK_BVH_BUILD="gpu"), dict(MSK_BVH_BUILD="gpu", MSK_WIDE_BVH="0"), dict(MSK_BVH_BUILD="gpu", MSK_WIDE_BVH="8")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dev = abi.Scene(gpu_ctx, flat)
+        assert np.array_equal(dev.trace_closest(rays).view(np.uint32), want.view(np.uint32)), env
+        assert np.array_equal(dev.trace_any(rays), want_any), env
+        gx, _ = dev.sample_pixels(prm, pixels)
+        assert np.array_equal(gx.view(np.uint32), ox.view(np.uint32)), env
+        dev.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    host.close()
+    o.close()

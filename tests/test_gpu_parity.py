@@ -193,10 +193,13 @@ def test_large_mesh_uses_hbm_bvh(gpu_ctx, abi, hostmirror, oracle, golden_lookup
                                  dict(MSK_STACK_CAP="4"), dict(MSK_STACK_CAP="4", MSK_TRACE_REFILL="0", MSK_WIDE_BVH="0"),
                                  dict(MSK_WIDE_LDS="1", MSK_TRACE_REFILL="0"),
                                  dict(MSK_WIDE_BVH="8"), dict(MSK_WIDE_BVH="8", MSK_TRACE_REFILL="0"),
-                                 dict(MSK_WIDE_BVH="8", MSK_STACK_CAP="4", MSK_TRACE_QUANTUM="2")])
+                                 dict(MSK_WIDE_BVH="8", MSK_STACK_CAP="4", MSK_TRACE_QUANTUM="2"),
+                                 dict(MSK_BVH_BUILD="gpu"), dict(MSK_BVH_BUILD="gpu", MSK_WIDE_BVH="0", MSK_STACK_CAP="4"),
+                                 dict(MSK_BVH_BUILD="gpu", MSK_WIDE_BVH="8"), dict(MSK_BVH_BUILD="gpu", MSK_BVH_LEAF="1", MSK_TRACE_REFILL="0")])
 def test_every_traversal_kernel_gives_the_same_film(gpu_ctx, abi, hostmirror, oracle, golden_lookup, monkeypatch, env):
-    """k_trace<0|1|2|4> (chunk loop) and k_trace_r<0|1|2|4> (lane replacement), binary, 4-wide and 8-wide quantised trees: hit
-    selection is by (t, prim), so every one of them must reproduce the oracle's film bit for bit."""
+    """k_trace<0|1|2|4> (chunk loop) and k_trace_r<0|1|2|4> (lane replacement), binary, 4-wide and 8-wide quantised trees, built
+    by the host's binned-SAH builder or on the device (MSK_BVH_BUILD=gpu, msk_lbvh.hip): hit selection is by (t, prim), so
+    every one of them must reproduce the oracle's film bit for bit."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     blob = hostmirror.blob_mesh("blob", (370, 420, 250), 70, 40, 40, hostmirror.WHITE, seed=2)
