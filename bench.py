@@ -257,11 +257,13 @@ def main():
         ms_shade = sum(s.ms_shade for s in stats)
         n_trace = sum(s.n_trace_launches for s in stats)
         n_shade = sum(s.n_shade_launches for s in stats)
-        # algorithmic bytes of the SoA path state each kernel must move:
+        # algorithmic bytes of the SoA path state each kernel must move; a "segment" is a slot that is live
+        # after a shading sweep (written by it, traced, read by the next sweep), a "shadow ray" one that carries a shadow ray:
         #   k_trace      48 B/segment (ray_o, ray_d in; hit out) + 16 B/shadow ray (sh in)
-        #   k_shade_gen  224 B/segment (96 in, 128 out) + 16 B/shadow ray (contrib in) + 20 B/sample (record out)
+        #   k_shade_gen  192 B/segment (id, wl, thr, res, ray_d, hit in; id, wl, thr, res, ray_o, ray_d out)
+        #                + 48 B/shadow ray (contrib in; sh, contrib out) + 20 B/sample (record out)
         bytes_trace = seg * 48 + shd * 16
-        bytes_shade = seg * 224 + shd * 16 + smp * 20
+        bytes_shade = seg * 192 + shd * 48 + smp * 20
         # the two kernels take nearly the same time on this workload and which one is ahead depends on the box; the shading
         # kernel (five times the bytes) is reported unless the traversal kernel is clearly the longer one
         if ms_trace > 1.03 * ms_shade:
@@ -293,7 +295,8 @@ def main():
             bytes_per_launch = (bytes_trace + bytes_shade) / per_iter
             avg_launch_ms = ms_wavefront / per_iter
             ts, tt = prof("k_shade_gen", "hbm_bytes_per_launch"), prof("k_trace", "hbm_bytes_per_launch")
-            traffic = round((ts + tt) * n_streams) if ts is not None and tt is not None else None   # PMC run = the same 4-stream launches
+            # the PMC passes run single-stream (tools/profile_all.sh): one launch of each kernel there IS one whole-pool iteration
+            traffic = round(ts + tt) if ts is not None and tt is not None else None
         else:
             t = prof(name, "hbm_bytes_per_launch")
             traffic = round(t) if t is not None else None

@@ -57,6 +57,29 @@ for k in sorted(set(fetch) | set(write)):
     summary[k] = {"launches": n, "fetch_size_kib": fetch.get(k, 0.0), "write_size_kib": write.get(k, 0.0),
                   "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes_per_launch": (rd + wr) / n,
                   "note": "read bytes = 2*1024*FETCH_SIZE (gfx950 half-count correction), write bytes = 1024*WRITE_SIZE"}
+# wave-level VALU instructions per path segment (bench.py's roofline.valu): SQ_INSTS_VALU of the SQ pass over the segments
+# that run traced (tools/prof_run.py prints its statistics)
+import re
+try:
+    seg_sq = int(re.findall(r"'segments': (\d+)", open(os.path.join(root, "gpurun_out", "prof_sq.log")).read())[-1])
+except Exception:
+    seg_sq = 0
+sq_files0 = glob.glob(os.path.join(root, "gpurun_out", "prof_sq", "**", "*_counter_collection.csv"), recursive=True)
+if seg_sq and sq_files0:
+    insts = collections.defaultdict(float)
+    for r in csv.DictReader(open(max(sq_files0, key=os.path.getmtime))):
+        if r["Counter_Name"] == "SQ_INSTS_VALU":
+            insts[short(r["Kernel_Name"])] += float(r["Counter_Value"])
+    for k, v in insts.items():
+        if k in summary:
+            summary[k]["valu_insts_per_segment"] = round(v / seg_sq, 3)
+            summary[k]["valu_note"] = "SQ_INSTS_VALU (wave64 instructions, all launches of the SQ pass) / %d path segments of that run" % seg_sq
+try:
+    import subprocess
+    head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+except Exception:
+    head = "?"
+summary["_source"] = f"profiles/{tag}_pmc.json (rocprofv3 PMC passes of tools/prof_run.py, single stream; tree at or after commit {head})"
 json.dump(summary, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
