@@ -917,7 +917,9 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     }
     // Default filter (border 2, footprint of five pixels) and blocks whose bordered width fits 12 lane columns: the records carry
     // their filter weights and the replay is k_resolve_rows.  Anything else: positions + k_resolve_blocks.
-    const uint32_t band_rounds = std::max(5u, env_u32("MSK_RESOLVE_ROUNDS", 10));
+    // source rows per band of k_resolve_rows: 8 cuts a 32-pixel block's 36 target rows into 8 + 7 x 4, eight equal chains per block
+    // (and 2048 waves for the 512^2 bench = two per SIMD, what the kernel's registers allow): 3.03 vs 3.35 ms with 10
+    const uint32_t band_rounds = std::max(5u, env_u32("MSK_RESOLVE_ROUNDS", 8));
     const bool packed = border == 2 && (int) std::floor(sc->dev.filter_radius + 0.5f) == 2 && bs + 2 * border <= 3 * MSK_RR_COLS &&
                         !env_u32("MSK_RESOLVE_GENERIC", 0);
     const std::vector<uint64_t> plan_key = {(uint64_t) W, (uint64_t) H, (uint64_t) bs, (uint64_t) border, prm->block_first, bstride,
