@@ -104,6 +104,8 @@ struct RegionCtl {
     unsigned long long segments, shadow_rays, samples_done;
     uint32_t count;                               // live slots
     uint32_t half_ns;                             // bit 0: which half of the region holds them; bits 1..: how many of them carry a shadow ray
+    uint32_t n_new, pad;                          // the last n_new live slots are camera samples the last sweep started: their throughput is 1
+                                                  // and their radiance 0 by definition — neither written nor read
 };
 // A region is two halves of region_size slots.  A shading sweep reads the live paths from one half and writes the survivors
 // (and the new camera samples) to the other, so nothing it writes can land on a slot it has not read yet, in whatever order
@@ -1130,6 +1132,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
     // A chunk's state as it is loaded.  (Measured and rejected: issuing the NEXT chunk's loads before this one is shaded — legal
     // with two-half regions — costs 30 VGPRs = one wave per SIMD and is slower, 21.6 vs 20.7 ms of shading per bench step.)
     struct ChunkIn { uint4 id; float4 wl, thr, res, rd4, hit, contrib; float2 aux; };
+    const uint32_t first_new = n_in - rc.n_new;      // live index of the first camera sample the last sweep started
     bool sorted = false;
     if (!DIFFUSE_ONLY && ss.perm) sorted = sort_by_class(st, in, ss, lane);
     // live index of this lane in the chunk that starts at c0 (the slot order, or the material order)
@@ -1141,7 +1144,9 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
         const uint32_t c = live_index(c0);
         const uint32_t i = in.slot(c < n_in ? c : 0u);
         ChunkIn k;
-        k.id = st.id[i]; k.wl = st.wl[i]; k.thr = st.thr[i]; k.res = st.res[i]; k.rd4 = st.ray_d[i]; k.hit = st.hit[i];
+        k.id = st.id[i]; k.wl = st.wl[i]; k.rd4 = st.ray_d[i]; k.hit = st.hit[i];
+        k.thr = make_float4(1.f, 1.f, 1.f, 1.f); k.res = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < first_new) { k.thr = st.thr[i]; k.res = st.res[i]; }      // (integrator.cpp:104 / path.cpp:24-25 for the rest)
         k.contrib = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < in.ns) k.contrib = st.contrib[i];                          // (whole chunks, but for the one the boundary falls in)
         k.aux = make_float2(1.f, 0.f);
@@ -1438,13 +1443,13 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
                           m[8] * dl.x + (m[9] * dl.y + m[10] * dl.z));
         const uint32_t o = base_out + (last - (cur_n + k));         // the new samples carry no shadow ray: they continue that group
         st.id[o] = make_uint4(j, si, pix, 1u);
-        st.wl[o] = to4(wl); st.thr[o] = make_float4(1.f, 1.f, 1.f, 1.f); st.res[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.wl[o] = to4(wl);                                        // thr = 1, res = 0: RegionCtl::n_new
         st.ray_o[o] = make_float4(ow.x, ow.y, ow.z, sc.near_clip * inv_z);
         st.ray_d[o] = make_float4(dw.x, dw.y, dw.z, sc.far_clip * inv_z);
         if (!DIFFUSE_ONLY) st.aux[o] = make_float2(1.f, 0.f);
     }
     const uint32_t n_out = cur_s + cur_n + got;
-    rc.count = n_out; rc.half_ns = (cur_s << 1) | ((rc.half_ns & 1u) ^ 1u);
+    rc.count = n_out; rc.half_ns = (cur_s << 1) | ((rc.half_ns & 1u) ^ 1u); rc.n_new = got;
     if (lane == 0) {
         rc.next_sample = first + got;
         rc.segments += n_out; rc.shadow_rays += cur_s; rc.samples_done += n_done;
@@ -1479,11 +1484,14 @@ MSK_DEV void shade_gen_body(const DeviceScene &sc, const PathState &st, const Pa
 template <bool LDS_TABLES, bool DIFFUSE_ONLY>
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_shade_gen(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<LDS_TABLES, DIFFUSE_ONLY>(sc, st, pp); }
-// The general variant with its tables in HBM sits a few registers above the 168 that three waves per SIMD allow (two cost
-// 20 % of the shading time on the mesh scenes): the allocator is told to stay at three.
+// The general variants sit a few registers above the 168 that three waves per SIMD allow (two cost 20 % of the shading time
+// on the mesh scenes): the allocator is told to stay at three.
 template <>
 __global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_shade_gen<false, false>(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<false, false>(sc, st, pp); }
+template <>
+__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_shade_gen<true, false>(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<true, false>(sc, st, pp); }
 
 // ------------------------------------------------------------------------------------------
 // k_wavefront: the iteration loop itself on the device, for scenes whose tree is staged in LDS.  A region is private to
