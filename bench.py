@@ -52,6 +52,10 @@ def parse_args():
     ap.add_argument("--no-balance", action="store_true",
                     help="N > 1: keep the equal interleaved sample split even when the GPUs differ in speed")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: launch, rendezvous (gloo), reduce and timing only")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks that ALL render on cuda:0 and reduce over gloo through host copies of the film: the whole "
+                         "multi-process path but the RCCL call, on a one-GPU box (tests/test_bench_launch.py); its line says "
+                         "\"rehearsal\": true and is not a measurement")
     return ap.parse_args()
 
 
@@ -168,6 +172,9 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the launcher's world size wins", file=sys.stderr)
     dev = "cpu" if args.dry_run else "cuda"
+    rehearsal = bool(args.rehearse_on_one_gpu) and not args.dry_run
+    if rehearsal:
+        local_rank = 0                                   # every rank on the one GPU there is
     if not args.dry_run:
         torch.cuda.set_device(local_rank)
     dist = None
@@ -175,7 +182,7 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dry_run:
+        if args.dry_run or rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -202,7 +209,12 @@ def main():
             # render_device returns when the film is complete on the library's stream; reduce_film returns when the
             # reduce has finished reading it (multigpu.reduce_film synchronises): the next render may overwrite it
             st = scene.render_device(prm, film.data_ptr())
-            mg.reduce_film(film, dist)
+            if rehearsal and dist is not None:           # gloo has no device reduce: through the host (rehearsal only)
+                host = film.cpu()
+                mg.reduce_film(host, dist)
+                film.copy_(host)
+            else:
+                mg.reduce_film(film, dist)
             return st
 
     def fence():
@@ -221,7 +233,8 @@ def main():
         # warm-up step decides speed-proportional contiguous sample ranges; the per-GPU average stays args.spp.
         # (kernel time of the wavefront launches that carried events — the same sync groups on every rank — not the step's
         # wall or device total, which on a first step also holds the one-off uploads of the render plan)
-        shares, times = mg.speed_proportional_shares(dist, warm[-1].ms_trace + warm[-1].ms_shade, spp_total, device="cuda")
+        shares, times = mg.speed_proportional_shares(dist, warm[-1].ms_trace + warm[-1].ms_shade, spp_total,
+                                                     device="cpu" if rehearsal else "cuda")
         if shares is not None:
             prm = mg.shard_params(abi, spp_total, rank, world, mode="range", shares=shares, seed=0)
             step()                       # untimed: the new shares' plan and record buffers are set up here
@@ -234,7 +247,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -316,6 +329,7 @@ def main():
             "metric": "Msamples/s (paths x spp) on cbox@512spp", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            **({"rehearsal": True, "film_finite": bool(torch.isfinite(film).all()), "film_weight_sum": float(film[..., 4].double().sum())} if rehearsal else {}),
             "config": {"workload": f"cbox {WIDTH}x{HEIGHT} @ {args.spp} spp per GPU ({spp_total} spp total), diffuse BSDFs, "
                                    f"path integrator (NEE+MIS, RR from depth 4), counter RNG, Gaussian filter, "
                                    f"ordered film resolve included",

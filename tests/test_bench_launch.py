@@ -48,3 +48,26 @@ def test_single_rank_dry_run():
                        env=_env(), cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     assert _last_json(r.stdout)["n_gpus"] == 1
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_ranks_rehearsed_on_one_gpu():
+    """The N = 2 path with real renders: two rank processes spawned from a bare shell, both on cuda:0, sample shards
+    (each rank every tile, its half of the sample indices), the warm-up's speed-proportional re-split, the film summed onto
+    rank 0 (gloo through host copies here, RCCL on a real node) — checked against one rank rendering all the samples."""
+    common = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs"]
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--spp", "8"] + common,
+                        capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    d2 = _last_json(r2.stdout)
+    assert d2["n_gpus"] == 2 and d2["rehearsal"] and d2["film_finite"] and d2["value"] > 0
+    assert d2["config"]["samples_per_step"] == 512 * 512 * 16
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rehearse-on-one-gpu", "--spp", "16"] + common,
+                        capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = _last_json(r1.stdout)
+    # the same 16 samples per pixel either way: the filter-weight sums agree up to the re-association of two partial sums
+    assert abs(d2["film_weight_sum"] - d1["film_weight_sum"]) <= 1e-5 * abs(d1["film_weight_sum"])
