@@ -839,7 +839,9 @@ static void pool_shape(const msk_scene *sc, uint64_t total_samples, uint32_t *re
     const bool big = sc->trace_mode == 1 || sc->trace_mode == 2 || sc->trace_mode == 4;
     // trees in HBM: one traversal wave per region at 5 waves per SIMD = 5120 resident waves; with 4096 regions the four loops'
     // launches never filled the GPU (8192 regions: config-5-class render 173 vs 191 ms, config-3-class 205 vs 227 ms)
-    uint32_t rs = env_u32("MSK_REGION_SIZE", big ? 2048 : 512), nr = env_u32("MSK_REGIONS", 8192);
+    // LDS-resident scenes: 6144 x 1024 (with the state's cache policy in place — msk_kernels.h, MSK_NT — fewer, longer regions
+    // win over round 1's 8192 x 512: 36.2 vs 37.0 ms per bench step; 5120 … 8192 x 896 … 1280 are within 1 % of each other)
+    uint32_t rs = env_u32("MSK_REGION_SIZE", big ? 2048 : 1024), nr = env_u32("MSK_REGIONS", big ? 8192 : 6144);
     rs = std::max(64u, (rs + 63u) & ~63u);
     while (rs > 256 && total_samples / rs < nr) rs = std::max(256u, rs / 2);       // small jobs: keep the GPU full first
     const uint64_t need = (total_samples + rs - 1) / rs;
