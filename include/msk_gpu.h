@@ -198,7 +198,7 @@ typedef struct msk_scene_desc {
  * rr_depth 5, max_depth -1, hide_emitters 0, block_size 32.
  */
 typedef struct msk_render_params {
-    uint32_t spp;            /* sampler sample_count                           */
+    uint32_t spp;            /* sampler sample_count (<= 2^20 per call: shard more with sample_first / sample_stride) */
     uint64_t seed;           /* sampler base_seed                              */
     int32_t  rng_mode;       /* MSK_RNG_*                                      */
     int32_t  rr_depth;

@@ -523,12 +523,12 @@ struct StateBufs {
     hipError_t alloc(size_t n, uint32_t n_regions) {      // n = slots a sweep can hold live; every region has two halves of them
         hipError_t e;
 #define A_(b, sz) if ((e = b.reserve(2 * n * (sz))) != hipSuccess) return e;
-        A_(id, 16) A_(wl, 16) A_(thr, 16) A_(res, 16) A_(ray_o, 16) A_(ray_d, 16) A_(sh, 16) A_(contrib, 16) A_(hit, 16)
+        A_(id, 8) A_(wl, 16) A_(thr, 16) A_(res, 16) A_(ray_o, 16) A_(ray_d, 16) A_(sh, 16) A_(contrib, 16) A_(hit, 16)
         A_(aux, 8)
 #undef A_
         if ((e = counts.reserve((size_t) n_regions * sizeof(RegionCtl))) != hipSuccess) return e;
         if ((e = ctrl.reserve(MSK_MAX_STREAMS * sizeof(Ctrl))) != hipSuccess) return e;
-        st.id = id.as<uint4>(); st.wl = wl.as<float4>(); st.thr = thr.as<float4>(); st.res = res.as<float4>();
+        st.id = id.as<uint2>(); st.wl = wl.as<float4>(); st.thr = thr.as<float4>(); st.res = res.as<float4>();
         st.ray_o = ray_o.as<float4>(); st.ray_d = ray_d.as<float4>(); st.sh = sh.as<float4>();
         st.contrib = contrib.as<float4>(); st.hit = hit.as<float4>(); st.aux = aux.as<float2>();
         return hipSuccess;
@@ -542,7 +542,7 @@ struct Workspace {
     std::vector<uint64_t> plan_key;          // empty = nothing cached
     uint64_t plan_n_pix = 0;
     DevBuf counts_init; unsigned long long counts_total = 0; uint32_t counts_regions = 0;
-    DevBuf block_buf, blocks, block_of, spiral, pix, rec_a, rec_b, film, bands;
+    DevBuf block_buf, blocks, block_of, spiral, pix, pix_inv, rec_a, rec_b, film, bands;
     uint32_t n_bands = 0;
     DevBuf aov_rec[MSK_MAX_AOV_GROUPS + 1], aov_block_buf[MSK_MAX_AOV_GROUPS + 1];   // [n_groups] = the nested path's RGB
 };
@@ -612,7 +612,7 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
 
 // Renders the samples of `pix` (pass pixel table, host) into records; leaves records on device.
 static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_params *prm, uint32_t spp_owned,
-                         const uint4 *d_pix, uint64_t n_pix, float4 *rec_a, float *rec_b, StateBufs &sb,
+                         const uint4 *d_pix, const uint32_t *d_pix_to_j, uint64_t n_pix, float4 *rec_a, float *rec_b, StateBufs &sb,
                          uint32_t region_size, uint32_t n_regions, msk_stats *stats, EventPool &ev,
                          std::vector<std::pair<hipEvent_t, hipEvent_t>> &ev_trace,
                          std::vector<std::pair<hipEvent_t, hipEvent_t>> &ev_shade,
@@ -646,7 +646,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     pp0.seed = prm->seed; pp0.spp_owned = spp_owned; pp0.sample_first = prm->sample_first;
     pp0.sample_stride = prm->sample_stride ? prm->sample_stride : 1;
     pp0.rr_depth = prm->rr_depth; pp0.max_depth = prm->max_depth; pp0.hide_emitters = prm->hide_emitters;
-    pp0.pix_table = d_pix; pp0.rec_a = rec_a; pp0.rec_b = rec_b;
+    pp0.pix_table = d_pix; pp0.pix_to_j = d_pix_to_j; pp0.rec_a = rec_a; pp0.rec_b = rec_b;
     pp0.region_size = region_size; pp0.n_regions = n_regions; pp0.regions = sb.counts.as<RegionCtl>();
     pp0.region_first = 0; pp0.region_count = n_regions;
     pp0.trace_split = sc->trace_mode == 0 ? std::max(1u, env_u32("MSK_TRACE_SPLIT", 2)) : 1u;
@@ -815,6 +815,9 @@ static int check_params(msk_ctx *ctx, const msk_render_params *p, int block_min)
         return fail(ctx, MSK_ERR_UNSUPPORTED, "rng_mode %d: the GPU back end implements MSK_RNG_COUNTER only "
                     "(a per-block PCG32 stream is sequential by construction)", p->rng_mode);
     if (p->spp == 0) return fail(ctx, MSK_ERR_INVALID_ARG, "spp must be > 0");
+    if (p->spp > (1u << MSK_DEPTH_SHIFT))
+        return fail(ctx, MSK_ERR_UNSUPPORTED, "spp %u: at most %u samples per pixel and call (the path state holds 20 bits of sample index); "
+                    "shard the samples with sample_first / sample_stride", p->spp, 1u << MSK_DEPTH_SHIFT);
     if (p->rr_depth <= 0) return fail(ctx, MSK_ERR_INVALID_ARG, "\"rr_depth\" must be set to a value greater than zero!");
     if (p->max_depth < 0 && p->max_depth != -1)
         return fail(ctx, MSK_ERR_INVALID_ARG, "\"max_depth\" must be set to -1 (infinite) or a value >= 0");
@@ -899,8 +902,8 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     for (auto &b : owned) all_samples += (uint64_t) b.size_x * b.size_y * spp_owned;
     pool_shape(sc, all_samples, &region_size, &n_regions);
     const size_t n_slots = (size_t) region_size * n_regions;
-    const size_t state_bytes = 2 * n_slots * 152 + 4096;                              // two halves per region (StateBufs::alloc)
-    const size_t held = ws.rec_a.bytes + ws.rec_b.bytes + ws.sb.id.bytes * 152 / 16;    // reusable: counts as free
+    const size_t state_bytes = 2 * n_slots * 144 + 4096;                              // two halves per region (StateBufs::alloc)
+    const size_t held = ws.rec_a.bytes + ws.rec_b.bytes + ws.sb.id.bytes * 144 / 8;     // reusable: counts as free
     free_b += held;
     size_t budget = getenv("MSK_RECORD_BUDGET_MB") ? (size_t) atoll(getenv("MSK_RECORD_BUDGET_MB")) << 20
                                                    : (free_b > state_bytes ? (size_t) ((free_b - state_bytes) * 0.8) : 0);
@@ -948,6 +951,9 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
                                                  (uint32_t) (owned[b].off_x - border), (uint32_t) (owned[b].off_y - border)));
             }
             HIP_TRY(ctx, d_pix.upload(pix));
+            std::vector<uint32_t> inv((size_t) W * H, 0xffffffffu);       // film index -> pass pixel (PassParams::pix_to_j)
+            for (size_t j = 0; j < pix.size(); ++j) inv[pix[j].x] = (uint32_t) j;
+            HIP_TRY(ctx, ws.pix_inv.upload(inv));
             n_pix = pix.size();
             // k_resolve_rows work list: per block, bands of target rows that each cost at most `band_rounds` source rows
             // (the first band has no rows above it to wait for and the last one none below, so they take more target rows)
@@ -979,7 +985,7 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
             }
             if (aov->rgba) { HIP_TRY(ctx, ws.aov_rec[MSK_MAX_AOV_GROUPS].reserve(n_rec * 16)); aov_rgb = ws.aov_rec[MSK_MAX_AOV_GROUPS].as<float4>(); }
         }
-        rc = run_wavefront(sc, stream, prm, spp_owned, d_pix.as<uint4>(), n_pix, d_rec_a.as<float4>(),
+        rc = run_wavefront(sc, stream, prm, spp_owned, d_pix.as<uint4>(), ws.pix_inv.as<uint32_t>(), n_pix, d_rec_a.as<float4>(),
                            d_rec_b.as<float>(), sb, region_size, n_regions, stats, ev, ev_trace, ev_shade, aov ? &ap : nullptr, aov_rgb, packed);
         if (rc) return rc;
         const uint32_t nb = (uint32_t) (ps.second - ps.first);
@@ -1127,33 +1133,48 @@ extern "C" int msk_gpu_sample_pixels(msk_scene *scene, const msk_render_params *
     int rc = check_params(ctx, prm, 1);
     if (rc) return rc;
     const int W = scene->dev.width, H = scene->dev.height;
-    std::vector<uint4> pix(n_pixels);
     if (n_pixels >> 32) return fail(ctx, MSK_ERR_INVALID_ARG, "too many pixels");
+    // The path state names a sample by its FILM pixel (PathState::id), so a pixel listed twice is rendered once and its
+    // samples are copied to every place it is listed at.
+    std::vector<uint4> pix;
+    std::vector<uint32_t> inv((size_t) W * H, 0xffffffffu), place(n_pixels);
     for (uint64_t i = 0; i < n_pixels; ++i) {
         const int x = pixels[2 * i], y = pixels[2 * i + 1];
         if (x < 0 || y < 0 || x >= W || y >= H) return fail(ctx, MSK_ERR_INVALID_ARG, "pixel (%d,%d) outside the %dx%d film", x, y, W, H);
-        // a "block" of one pixel at (x, y): the kernels take the film coordinates from the block offset (pixel_x / pixel_y)
-        pix[i] = make_uint4((uint32_t) (y * W + x), 0u, (uint32_t) (x - scene->dev.filter_border), (uint32_t) (y - scene->dev.filter_border));
+        const uint32_t f = (uint32_t) (y * W + x);
+        if (inv[f] == 0xffffffffu) {
+            inv[f] = (uint32_t) pix.size();
+            // a "block" of one pixel at (x, y): the kernels take the film coordinates from the block offset (pixel_x / pixel_y)
+            pix.push_back(make_uint4(f, 0u, (uint32_t) (x - scene->dev.filter_border), (uint32_t) (y - scene->dev.filter_border)));
+        }
+        place[i] = inv[f];
     }
     if (n_pixels == 0) return MSK_OK;
+    const uint64_t n_listed = n_pixels;
+    n_pixels = pix.size();
     msk_render_params p = *prm; p.sample_first = 0; p.sample_stride = 1;
     const uint64_t n_rec = n_pixels * p.spp;
     uint32_t region_size, n_regions;
     pool_shape(scene, n_rec, &region_size, &n_regions);
-    StateBufs sb; DevBuf d_pix, ra, rb, ox, op;
+    StateBufs sb; DevBuf d_pix, d_inv, ra, rb, ox, op;
     HIP_TRY(ctx, sb.alloc((size_t) region_size * n_regions, n_regions));
-    HIP_TRY(ctx, d_pix.upload(pix)); HIP_TRY(ctx, ra.alloc(n_rec * 16)); HIP_TRY(ctx, rb.alloc(n_rec * 4));
+    HIP_TRY(ctx, d_pix.upload(pix)); HIP_TRY(ctx, d_inv.upload(inv)); HIP_TRY(ctx, ra.alloc(n_rec * 16)); HIP_TRY(ctx, rb.alloc(n_rec * 4));
     HIP_TRY(ctx, ox.alloc(n_rec * 12)); HIP_TRY(ctx, op.alloc(n_rec * 8));
     EventPool ev{ctx, 0};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> e1, e2;
-    rc = run_wavefront(scene, ctx->stream, &p, p.spp, d_pix.as<uint4>(), n_pixels, ra.as<float4>(), rb.as<float>(), sb,
+    rc = run_wavefront(scene, ctx->stream, &p, p.spp, d_pix.as<uint4>(), d_inv.as<uint32_t>(), n_pixels, ra.as<float4>(), rb.as<float>(), sb,
                        region_size, n_regions, nullptr, ev, e1, e2);
     if (rc) return rc;
     hipLaunchKernelGGL(k_export_records, dim3((uint32_t) ((n_rec + 255) / 256)), dim3(256), 0, ctx->stream, ra.as<float4>(),
                        rb.as<float>(), n_pixels, p.spp, ox.as<float>(), op.as<float>());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(out_xyz, ox.p, n_rec * 12, hipMemcpyDeviceToHost));
-    if (out_pos) HIP_TRY(ctx, hipMemcpy(out_pos, op.p, n_rec * 8, hipMemcpyDeviceToHost));
+    std::vector<float> hx((size_t) n_rec * 3), hp(out_pos ? (size_t) n_rec * 2 : 0);
+    HIP_TRY(ctx, hipMemcpy(hx.data(), ox.p, n_rec * 12, hipMemcpyDeviceToHost));
+    if (out_pos) HIP_TRY(ctx, hipMemcpy(hp.data(), op.p, n_rec * 8, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n_listed; ++i) {
+        std::memcpy(out_xyz + i * p.spp * 3, hx.data() + (size_t) place[i] * p.spp * 3, (size_t) p.spp * 12);
+        if (out_pos) std::memcpy(out_pos + i * p.spp * 2, hp.data() + (size_t) place[i] * p.spp * 2, (size_t) p.spp * 8);
+    }
     return MSK_OK;
 }
 

@@ -38,7 +38,9 @@ namespace msk {
 #define MSK_PRIM_ID 0x03ffffffu
 #define MSK_CLASS_SHIFT 27
 #define MSK_N_CLASSES 4
-#define MSK_DEPTH_MASK 0xffffu
+#define MSK_DEPTH_SHIFT 20                 /* id.y: 20 bits of sample index (msk_gpu_render rejects more than 2^20 samples per pixel and pass), */
+#define MSK_SI_MASK 0xfffffu               /* 12 bits of depth: a path that reaches bounce 4094 is cut (Russian roulette makes that a 1e-89 event) */
+#define MSK_MAX_DEPTH 4094u
 
 struct DeviceScene {
     const float4 *nodes;        // 4 x float4 per node (msk_bvh.h)
@@ -80,7 +82,9 @@ struct DeviceScene {
 };
 
 struct PathState {
-    uint4 *id;          // {pass pixel j, owned-sample index si, film pixel y*W+x, depth}
+    uint2 *id;          // {film pixel y*W+x, owned-sample index si | depth << MSK_DEPTH_SHIFT}: the RNG key needs the film pixel and
+                        // the sample index at every bounce; the pass pixel (the record's address) follows from the film pixel
+                        // through PassParams::pix_to_j when the path is finished
     float4 *wl, *thr, *res;
     float4 *ray_o;      // o.xyz, tmin
     float4 *ray_d;      // d.xyz, then: camera ray: tmax (> 0); bounce ray (tmax = inf): minus the pdf of the BSDF sample that made
@@ -133,6 +137,7 @@ struct PassParams {
     uint32_t spp_owned, sample_first, sample_stride;
     int32_t rr_depth, max_depth, hide_emitters;
     const uint4 *pix_table;       // pass pixel j -> {film index y*W+x, x | y << 16 inside its block, block off_x - border, off_y - border (int bits)}
+    const uint32_t *pix_to_j;     // film index -> pass pixel j (pixels of this pass only)
     float4 *rec_a;                // per sample {X,Y,Z,pos.x}; the record of (j, si) is j * spp_owned + si: [block][pixel][sample], a pixel's
     float *rec_b;                 // per sample pos.y           samples contiguous (the film replay streams them in that order)
     uint32_t packed;              // 1: the records carry the sample's filter weights instead of its position (SampleWeights below):
@@ -179,6 +184,14 @@ template <int LEVEL> MSK_DEV float4 ld4(const float4 *p) {
 }
 template <int LEVEL> MSK_DEV uint4 ld4(const uint4 *p) {
     if (MSK_NT >= LEVEL) { const msk_v4u x = __builtin_nontemporal_load((const msk_v4u *) p); return make_uint4(x.x, x.y, x.z, x.w); }
+    return *p;
+}
+typedef uint32_t msk_v2u __attribute__((ext_vector_type(2)));
+template <int LEVEL> MSK_DEV void st2(uint2 *p, uint2 v) {
+    if (MSK_NT >= LEVEL) { msk_v2u x = {v.x, v.y}; __builtin_nontemporal_store(x, (msk_v2u *) p); } else *p = v;
+}
+template <int LEVEL> MSK_DEV uint2 ld2(const uint2 *p) {
+    if (MSK_NT >= LEVEL) { const msk_v2u x = __builtin_nontemporal_load((const msk_v2u *) p); return make_uint2(x.x, x.y); }
     return *p;
 }
 
@@ -1060,8 +1073,8 @@ MSK_DEV uint32_t nonfinite_flag(float a, float b, float c) {
 
 // render_sample's tail for one finished path (integrator.cpp:115-125): ray weight, XYZ, film position -> sample record
 template <bool DIFFUSE_ONLY>
-MSK_DEV void emit_record(const DeviceScene &sc, const SceneTables &tb, const PassParams &pp, spec wl, spec res, uint32_t j,
-                         uint32_t si, uint32_t pix) {
+MSK_DEV void emit_record(const DeviceScene &sc, const SceneTables &tb, const PassParams &pp, spec wl, spec res, uint32_t pix, uint32_t si) {
+    const uint32_t j = pp.pix_to_j[pix];
     spec wgt;
 #pragma unroll
     for (int k = 0; k < 4; ++k) wgt.v[k] = wavelength_weight(wl.v[k]);
@@ -1094,7 +1107,7 @@ MSK_DEV void emit_record(const DeviceScene &sc, const SceneTables &tb, const Pas
 // fp64 cosh, twelve CIE lookups, one RNG draw — about a fifth of this kernel's instructions) then runs with all lanes
 // busy instead of once per chunk for the ~25 % of its lanes that happened to finish.
 #define MSK_DONE_Q 128                     /* entries per wave: up to 63 parked + 64 new */
-struct DoneQueue { float4 *wl, *res; uint4 *id; };
+struct DoneQueue { float4 *wl, *res; uint2 *id; };      // id: {film pixel, sample index}
 
 // Material-sorted shading (general variant).  Before a region is shaded its live paths are ordered by the material class of
 // the surface their ray has just hit (bits 27..28 of the hit record's prim word, delivered by the traversal): a counting
@@ -1158,7 +1171,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
 
     // A chunk's state as it is loaded.  (Measured and rejected: issuing the NEXT chunk's loads before this one is shaded — legal
     // with two-half regions — costs 30 VGPRs = one wave per SIMD and is slower, 21.6 vs 20.7 ms of shading per bench step.)
-    struct ChunkIn { uint4 id; float4 wl, thr, res, rd4, hit, contrib; float2 aux; };
+    struct ChunkIn { uint2 id; float4 wl, thr, res, rd4, hit, contrib; float2 aux; };
     const uint32_t first_new = n_in - rc.n_new;      // live index of the first camera sample the last sweep started
     bool sorted = false;
     if (!DIFFUSE_ONLY && ss.perm) sorted = sort_by_class(st, in, ss, lane);
@@ -1171,7 +1184,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
         const uint32_t c = live_index(c0);
         const uint32_t i = in.slot(c < n_in ? c : 0u);
         ChunkIn k;
-        k.id = ld4<1>(st.id + i); k.wl = ld4<1>(st.wl + i); k.rd4 = ld4<2>(st.ray_d + i); k.hit = ld4<2>(st.hit + i);
+        k.id = ld2<1>(st.id + i); k.wl = ld4<1>(st.wl + i); k.rd4 = ld4<2>(st.ray_d + i); k.hit = ld4<2>(st.hit + i);
         k.thr = make_float4(1.f, 1.f, 1.f, 1.f); k.res = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < first_new) { k.thr = ld4<1>(st.thr + i); k.res = ld4<1>(st.res + i); }      // (integrator.cpp:104 / path.cpp:24-25 for the rest)
         k.contrib = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1186,7 +1199,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
         const bool shadow_in = c < in.ns;          // this path's last bounce sent a shadow ray (ns <= n_in)
         // ---- load
         const ChunkIn cur = load_chunk(c0);
-        const uint4 id = cur.id;
+        const uint2 id = cur.id;
         spec wl = from4(cur.wl), thr = from4(cur.thr), res = from4(cur.res);
         const float4 rd4 = cur.rd4;
         float4 hit = cur.hit;
@@ -1196,10 +1209,11 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
         hit.w = __uint_as_float(__float_as_uint(hit.w) & MSK_PRIM_ID);
         float bs_pdf = -rd4.w;                                             // meaningful for depth > 1 (PathState::ray_d)
         float eta = cur.aux.x, nee_pdf = cur.aux.y;                        // carried only by the general variant
-        uint32_t depth = id.w & MSK_DEPTH_MASK;
+        uint32_t depth = id.y >> MSK_DEPTH_SHIFT;
+        const uint32_t s_own = id.y & MSK_SI_MASK;
         const f3 rd = mk3(rd4.x, rd4.y, rd4.z);
-        const uint32_t pix = id.z;
-        const uint32_t sidx = pp.sample_first + id.y * pp.sample_stride;
+        const uint32_t pix = id.x;
+        const uint32_t sidx = pp.sample_first + s_own * pp.sample_stride;
         const uint64_t key = counter_key(pp.seed, pix, sidx);
 
         bool alive = active;
@@ -1382,6 +1396,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
                 }
             }
         }
+        if (depth > MSK_MAX_DEPTH) alive = false;      // 12 bits of depth in the state word (never reached: see MSK_MAX_DEPTH)
         // ---- finished paths: park them; 64 parked paths become records together (emit_record)
         {
             const bool fin = active && !alive;
@@ -1389,17 +1404,17 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
             if (fm != 0ull) {
                 if (fin) {
                     const uint32_t q = n_queued + (uint32_t) __popcll(fm & ((1ull << lane) - 1ull));
-                    dq.wl[q] = to4(wl); dq.res[q] = to4(res); dq.id[q] = make_uint4(id.x, id.y, id.z, 0u);
+                    dq.wl[q] = to4(wl); dq.res[q] = to4(res); dq.id[q] = make_uint2(pix, s_own);
                 }
                 n_queued += (uint32_t) __popcll(fm);
                 wave_sync();
                 if (n_queued >= MSK_WAVE) {
                     const spec qwl = from4(dq.wl[lane]), qres = from4(dq.res[lane]);
-                    const uint4 qid = dq.id[lane];
-                    emit_record<DIFFUSE_ONLY>(sc, tb, pp, qwl, qres, qid.x, qid.y, qid.z);
+                    const uint2 qid = dq.id[lane];
+                    emit_record<DIFFUSE_ONLY>(sc, tb, pp, qwl, qres, qid.x, qid.y);
                     // move the rest (< 64 entries) to the front
                     const uint32_t rem = n_queued - MSK_WAVE;
-                    float4 a = make_float4(0, 0, 0, 0), b = a; uint4 c4 = make_uint4(0, 0, 0, 0);
+                    float4 a = make_float4(0, 0, 0, 0), b = a; uint2 c4 = make_uint2(0, 0);
                     if (lane < rem) { a = dq.wl[MSK_WAVE + lane]; b = dq.res[MSK_WAVE + lane]; c4 = dq.id[MSK_WAVE + lane]; }
                     wave_sync();
                     if (lane < rem) { dq.wl[lane] = a; dq.res[lane] = b; dq.id[lane] = c4; }
@@ -1414,7 +1429,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
         if (alive) {
             const unsigned long long below = (1ull << lane) - 1ull;
             const uint32_t o = base_out + (has_shadow ? cur_s + (uint32_t) __popcll(m_s & below) : last - (cur_n + (uint32_t) __popcll(m_n & below)));
-            st4<1>(st.id + o, make_uint4(id.x, id.y, id.z, depth));
+            st2<1>(st.id + o, make_uint2(pix, s_own | (depth << MSK_DEPTH_SHIFT)));
             st4<1>(st.wl + o, to4(wl)); st4<1>(st.thr + o, to4(thr)); st4<1>(st.res + o, to4(res));
             st4<4>(st.ray_o + o, new_o); st4<4>(st.ray_d + o, new_d);
             if (has_shadow) { st4<4>(st.sh + o, new_sh); st4<1>(st.contrib + o, to4(contrib)); }
@@ -1426,8 +1441,8 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
     // ---- the paths still parked (< 64)
     if (lane < n_queued) {
         const spec qwl = from4(dq.wl[lane]), qres = from4(dq.res[lane]);
-        const uint4 qid = dq.id[lane];
-        emit_record<DIFFUSE_ONLY>(sc, tb, pp, qwl, qres, qid.x, qid.y, qid.z);
+        const uint2 qid = dq.id[lane];
+        emit_record<DIFFUSE_ONLY>(sc, tb, pp, qwl, qres, qid.x, qid.y);
     }
     // ---- regeneration: fill the free tail with new camera samples (integrator.cpp:103-116)
     const uint32_t n_free = pp.region_size - (cur_s + cur_n);
@@ -1469,7 +1484,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
         const f3 dw = mk3(m[0] * dl.x + (m[1] * dl.y + m[2] * dl.z), m[4] * dl.x + (m[5] * dl.y + m[6] * dl.z),
                           m[8] * dl.x + (m[9] * dl.y + m[10] * dl.z));
         const uint32_t o = base_out + (last - (cur_n + k));         // the new samples carry no shadow ray: they continue that group
-        st4<1>(st.id + o, make_uint4(j, si, pix, 1u));
+        st2<1>(st.id + o, make_uint2(pix, si | (1u << MSK_DEPTH_SHIFT)));
         st4<1>(st.wl + o, to4(wl));                                      // thr = 1, res = 0: RegionCtl::n_new
         st4<4>(st.ray_o + o, make_float4(ow.x, ow.y, ow.z, sc.near_clip * inv_z));
         st4<4>(st.ray_d + o, make_float4(dw.x, dw.y, dw.z, sc.far_clip * inv_z));
@@ -1489,7 +1504,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
 MSK_DEV DoneQueue done_queue(float4 *base) {
     DoneQueue dq;
     float4 *qbase = base + (threadIdx.x / MSK_WAVE) * (3 * MSK_DONE_Q);
-    dq.wl = qbase; dq.res = qbase + MSK_DONE_Q; dq.id = (uint4 *) (qbase + 2 * MSK_DONE_Q);
+    dq.wl = qbase; dq.res = qbase + MSK_DONE_Q; dq.id = (uint2 *) (qbase + 2 * MSK_DONE_Q);
     return dq;
 }
 
@@ -1581,8 +1596,8 @@ k_aov_primary(DeviceScene sc, PathState st, PassParams pp, AovParams ap) {
     const RegionView rv = region_view(wave, pp.region_size, pp.regions[wave].count, pp.regions[wave].half_ns);
     for (uint32_t c = lane; c < rv.n; c += MSK_WAVE) {
         const uint32_t i = rv.slot(c);
-        const uint4 id = st.id[i];
-        if ((id.w & MSK_DEPTH_MASK) != 1u) continue;
+        const uint2 id = st.id[i];
+        if ((id.y >> MSK_DEPTH_SHIFT) != 1u) continue;
         const float4 hit = st.hit[i];
         float val[13];
 #pragma unroll
@@ -1609,13 +1624,13 @@ k_aov_primary(DeviceScene sc, PathState st, PassParams pp, AovParams ap) {
             val[1] = hit.x; val[2] = p.x; val[3] = p.y; val[4] = p.z; val[5] = u; val[6] = v;
             val[7] = n.x; val[8] = n.y; val[9] = n.z; val[10] = ns.x; val[11] = ns.y; val[12] = ns.z;
         }
-        const uint32_t pix = id.z;
-        const uint64_t key = counter_key(pp.seed, pix, pp.sample_first + id.y * pp.sample_stride);
+        const uint32_t pix = id.x, s_own = id.y & MSK_SI_MASK, j = pp.pix_to_j[pix];
+        const uint64_t key = counter_key(pp.seed, pix, pp.sample_first + s_own * pp.sample_stride);
         const f2 jit = counter_pair(key, 0);
         const float px = (float) (pix % (uint32_t) sc.width) + jit.x;
-        const size_t r = (size_t) id.x * pp.spp_owned + id.y;
+        const size_t r = (size_t) j * pp.spp_owned + s_own;
         uint32_t wxw = 0;
-        if (pp.packed) wxw = sample_weights(sc, pp.pix_table[id.x], px, (float) (pix / (uint32_t) sc.width) + jit.y).x;
+        if (pp.packed) wxw = sample_weights(sc, pp.pix_table[j], px, (float) (pix / (uint32_t) sc.width) + jit.y).x;
         for (uint32_t g = 0; g < ap.n_groups; ++g) {
             const uint32_t code = ap.code[g];
             float o[3];
