@@ -306,6 +306,12 @@ def main():
             name = "k_shade_gen || k_trace (%d streams)" % n_streams
             achieved = pair_achieved
             per_iter = max(iters // n_streams, 1)            # iterations of the whole pool (every stream launches its own)
+            # (the thin end of a pass runs as k_wavefront launches that are booked as 16 iterations each: where the committed
+            # single-stream profile of this workload says how many whole-pool launches a step is, that count is used, so that
+            # `bytes_per_launch` and `traffic` describe the same unit)
+            prof_launches = prof("k_shade_gen", "launches")
+            if prof_launches and args.spp == SPP_PER_GPU:
+                per_iter = int(prof_launches) * args.steps
             bytes_per_launch = (bytes_trace + bytes_shade) / per_iter
             avg_launch_ms = ms_wavefront / per_iter
             ts, tt = prof("k_shade_gen", "hbm_bytes_per_launch"), prof("k_trace", "hbm_bytes_per_launch")
