@@ -154,6 +154,30 @@ def profile_counters():
     return pm
 
 
+def profile_single_stream():
+    """Achieved HBM-side GB/s of the two wavefront kernels when each launch has the GPU to itself, from the COMMITTED profiles:
+    PMC bytes per launch (profiles/pmc_summary.json) over the average launch duration of the MSK_STREAMS=1 kernel trace
+    (profiles/r02_kernel_stats_1stream.csv).  Not measured in this run; labelled as such in the line."""
+    import csv
+    pm = profile_counters()
+    out = {}
+    try:
+        rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_kernel_stats_1stream.csv"))))
+    except Exception:
+        return None
+    for key in ("k_shade_gen", "k_trace"):
+        b = next((v.get("hbm_bytes_per_launch") for k, v in pm.items() if k.startswith(key) and isinstance(v, dict)), None)
+        r = next((r for r in rows if ("msk::" + key) in r["Name"]), None)
+        if b is None or r is None:
+            continue
+        us = float(r["AverageNs"]) / 1e3
+        gbs = b / (us * 1e-6) / 1e9
+        out[key] = {"hbm_bytes_per_launch": round(b), "avg_launch_us": round(us, 1), "achieved": round(gbs, 1), "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    out["source"] = "committed profiles (rocprofv3 PMC + MSK_STREAMS=1 kernel trace), not this run"
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -352,7 +376,7 @@ def main():
                          "ms_trace_timed": round(ms_trace, 2), "ms_shade_timed": round(ms_shade, 2),
                          "ms_resolve": round(sum(s.ms_resolve for s in stats), 2),
                          "ms_total_device": round(sum(s.ms_total for s in stats), 2),
-                         "valu": valu},
+                         "valu": valu, "per_kernel_single_stream_profile": profile_single_stream()},
         }
         if not args.no_cpu_baseline and world == 1:
             # the reference CLI caps TBB at 8 threads (main.cpp:43-44): that run is `cpu_baseline`; the same port on every
