@@ -599,6 +599,15 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
         else hipExtLaunchKernelGGL(k_trace_r<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         return;
     }
+    // LDS-resident scenes: k_trace_q (job queues with lane replacement, refill when 32 lanes are idle); MSK_TRACE_QUEUE=0: k_trace<0>
+    const uint32_t queue_refill = refill_env >= 0 ? 0u : std::min(64u, env_u32("MSK_TRACE_QUEUE", 32));
+    const size_t bits_off = (lds + 15) & ~(size_t) 15;
+    const size_t lds_q = bits_off + (size_t) (MSK_BLOCK / MSK_WAVE) * (pp.region_size / 8);       // + one bit per slot and wave
+    if (sc->trace_mode == 0 && queue_refill && sc->lds_scene && lds_q <= 64 * 1024) {
+        const uint32_t grid_s = (pp.region_count * pp.trace_split * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
+        hipExtLaunchKernelGGL(k_trace_q, dim3(grid_s), dim3(MSK_BLOCK), lds_q, stream, t0, t1, 0, sc->dev, st, pp, queue_refill, (uint32_t) (bits_off / 16));
+        return;
+    }
     if (sc->trace_mode == 0) {     // pp.trace_split waves per region (LDS-resident scene: no stack overflow array to size).
         // Measured: 2 waves per region -6 % trace on the cbox (twice the waves to balance the tail of a launch), 4 the same.
         const uint32_t grid_s = (pp.region_count * pp.trace_split * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;

@@ -198,6 +198,13 @@ template <int LEVEL> MSK_DEV uint2 ld2(const uint2 *p) {
 // ------------------------------------------------------------------------------------------
 // traversal
 // ------------------------------------------------------------------------------------------
+// Lanes of one wave exchanging data through LDS: the compiler may otherwise run one side of a divergent region past the
+// other side's LDS accesses (measured, see the k_trace note).
+MSK_DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 MSK_DEV float xor_sign(float a, uint32_t s) { return __uint_as_float(__float_as_uint(a) ^ s); }
 
 // Embree 3 Moeller-Trumbore, restated (see oracle/oracle.cpp header for the derivation);
@@ -568,6 +575,121 @@ MSK_DEV void trace_chunks(const DeviceScene &sc, const PathState &st, const Pass
 template <int MODE>
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_trace(DeviceScene sc, PathState st, PassParams pp) { trace_chunks<MODE>(sc, st, pp); }
+
+// ------------------------------------------------------------------------------------------
+// k_trace_q: the LDS-resident binary tree walked as two JOB QUEUES per wave — first the region's shadow rays (slots c < ns,
+// any-hit), then its extension rays (closest hit) — with the while-while loop of traverse() and lane replacement hoisted into
+// its outer iteration: when at least `refill` lanes have no ray, they take the wave's next jobs.  In k_trace<0> a chunk's 64
+// rays start together and the wave steps until the longest of them is done (36 % of the lanes active in an inner-node step);
+// here a finished lane idles only until enough of its neighbours have finished too.  Both queues run specialised code (the
+// any-hit loop returns at the first accepted triangle, the closest-hit loop keeps (t, prim) minima), unlike k_trace_r's one
+// stream for both.  The shadow results wait in an LDS bit per slot until the slot's extension ray writes the hit record.
+// Same per-ray arithmetic as traverse(): same hits, bit for bit.
+// ------------------------------------------------------------------------------------------
+template <bool ANY>
+MSK_DEV void trace_queue(const DeviceScene &sc, const TraceLds &g, const PathState &st, const RegionView &rv, const LaneStack<false> &stack,
+                         uint32_t n_jobs, uint32_t sub, uint32_t split, uint32_t *unocc_bits, uint32_t lane, uint32_t refill) {
+    const uint32_t DONE = 0xffffffffu;
+    // this wave's jobs: the slots of the chunks k with k % split == sub, in order
+    const uint32_t n_chunks = (n_jobs + MSK_WAVE - 1) / MSK_WAVE;
+    const uint32_t my_chunks = n_chunks > sub ? (n_chunks - sub + split - 1) / split : 0u;
+    uint32_t my_total = my_chunks * MSK_WAVE;
+    if (my_chunks && ((my_chunks - 1) * split + sub) == n_chunks - 1) my_total -= n_chunks * MSK_WAVE - n_jobs;      // the partial last chunk
+    uint32_t next = 0;                                   // jobs handed out so far (wave-uniform)
+    bool active = false;
+    uint32_t c = 0;
+    f3 o = mk3(0, 0, 0), d = o, idir = o, oi = o;
+    float tmin = 0.f, tfar = 0.f, bt = 0.f, bu = 0.f, bv = 0.f;
+    uint32_t bp = MSK_NO_PRIM, cur = DONE;
+    int sp = 0;
+    bool occluded = false;
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        if (next < my_total && ((uint32_t) __popcll(idle) >= refill || idle == ~0ull)) {
+            if (!active) {
+                const uint32_t q = next + (uint32_t) __popcll(idle & ((1ull << lane) - 1ull));
+                if (q < my_total) {
+                    c = ((q >> 6) * split + sub) * MSK_WAVE + (q & 63u);
+                    const uint32_t slot = rv.slot(c);
+                    const float4 ro = st.ray_o[slot];
+                    const float4 rd = ANY ? st.sh[slot] : st.ray_d[slot];
+                    o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z);
+                    tmin = ro.w; tfar = ANY ? rd.w : slot_tmax(rd.w);
+                    idir = slab_idir(d); oi = mk3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
+                    bt = tfar; bu = 0.f; bv = 0.f; bp = MSK_NO_PRIM; sp = 0; occluded = false;
+                    cur = sc.n_tris ? sc.root_ref : DONE;
+                    active = true;
+                }
+            }
+            next += (uint32_t) __popcll(idle);
+        }
+        if (__ballot(active) == 0ull) break;             // (an all-idle wave refills while jobs remain: nothing is left)
+        // ---- inner nodes, until every lane with a ray holds a leaf or has run out of nodes
+        while (active && !(cur & MSK_LEAF_BIT)) {
+            const float4 *n = g.nodes + (size_t) cur * 4;
+            const float4 a = n[0], b = n[1], cc = n[2], m = n[3];
+            float t0, t1;
+            const bool h0 = box_test(a.x, a.z, b.x, b.z, cc.x, cc.z, idir, oi, tmin, bt, &t0);
+            const bool h1 = box_test(a.y, a.w, b.y, b.w, cc.y, cc.w, idir, oi, tmin, bt, &t1);
+            const uint32_t c0 = __float_as_uint(m.x), c1 = __float_as_uint(m.y);
+            if (h0 && h1) {
+                const bool swap = t1 < t0;
+                cur = swap ? c1 : c0;
+                stack.push(sp, swap ? c0 : c1);
+            } else if (h0) { cur = c0; }
+            else if (h1) { cur = c1; }
+            else if (sp > 0) { cur = stack.pop(sp); }
+            else { cur = DONE; }
+        }
+        // ---- the leaf
+        if (active && cur != DONE) {
+            const uint32_t first = (cur & 0x7fffffffu) >> 5, cnt = cur & 31u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const float4 *q = g.tris + (size_t) (first + i) * 6;
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                float t, u, v;
+                if (tri_test(q0, q1, q2, q3, o, d, tmin, tfar, &t, &u, &v, q + 4, sc.tri_pad)) {
+                    if (ANY) { occluded = true; break; }
+                    const uint32_t prim = __float_as_uint(q0.w);
+                    if (bp == MSK_NO_PRIM || t < bt || (t == bt && (prim & MSK_PRIM_ID) < (bp & MSK_PRIM_ID))) { bt = t; bu = u; bv = v; bp = prim; }
+                }
+            }
+            if (sp > 0 && !(ANY && occluded)) cur = stack.pop(sp); else cur = DONE;
+        }
+        // ---- finished rays
+        if (active && cur == DONE) {
+            if (ANY) { if (!occluded) atomicOr(&unocc_bits[c >> 5], 1u << (c & 31u)); }
+            else {
+                const bool valid = (bp != MSK_NO_PRIM) && (bt != tfar);           // scene.cpp:234 tfar != maxt
+                const uint32_t unocc = ((unocc_bits[c >> 5] >> (c & 31u)) & 1u) ? MSK_HIT_UNOCCLUDED : 0u;
+                st.hit[rv.slot(c)] = make_float4(valid ? bt : MSK_INF_F, bu, bv, __uint_as_float((valid ? bp : MSK_PRIM_MASK) | unocc));
+            }
+            active = false;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_trace_q(DeviceScene sc, PathState st, PassParams pp, uint32_t refill, uint32_t bits_f4) {
+    extern __shared__ float4 lds_dyn[];
+    uint32_t *stack_base = (uint32_t *) lds_dyn;                         // stack_entries * MSK_BLOCK words
+    float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
+    const TraceLds g = stage_scene(sc, scene_lds, true, false);
+    // behind the staged scene: one bit per slot of a region and wave (the shadow rays' results)
+    uint32_t *bits = (uint32_t *) (lds_dyn + bits_f4) + (threadIdx.x / MSK_WAVE) * (pp.region_size / 32u);
+    const LaneStack<false> stack{stack_base + threadIdx.x, nullptr, (int) sc.stack_entries, 0};
+    const uint32_t gwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
+    const uint32_t lwave = gwave / pp.trace_split, sub = gwave % pp.trace_split;
+    const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
+    if (lwave >= pp.region_count) return;
+    const uint32_t wave = pp.region_first + lwave;
+    const RegionView rv = region_view(wave, pp.region_size, pp.regions[wave].count, pp.regions[wave].half_ns);
+    for (uint32_t i = lane; i < pp.region_size / 32u; i += MSK_WAVE) bits[i] = 0u;
+    wave_sync();
+    trace_queue<true>(sc, g, st, rv, stack, rv.ns, sub, pp.trace_split, bits, lane, refill);
+    wave_sync();
+    trace_queue<false>(sc, g, st, rv, stack, rv.n, sub, pp.trace_split, bits, lane, refill);
+}
 
 // ------------------------------------------------------------------------------------------
 // k_trace_r: the same rays with lane replacement.  Every lane is a small state machine {slot, phase (shadow / closest),
@@ -1026,13 +1148,6 @@ MSK_DEV spec bsdf_sample(const BsdfRec &b, f3 wi, float sample1, f2 sample, spec
 // ------------------------------------------------------------------------------------------
 // k_shade_gen
 // ------------------------------------------------------------------------------------------
-// Lanes of one wave exchanging data through LDS: the compiler may otherwise run one side of a divergent region past the
-// other side's LDS accesses (measured, see the k_trace note).
-MSK_DEV void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // ImageBlock::put's per-sample part (imageblock.cpp:84-96), done once per sample instead of once per (sample, target pixel):
 // a sample of block pixel (lx, ly) can only reach the five target columns lx .. lx + 4 and rows ly .. ly + 4 of the bordered
