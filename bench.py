@@ -296,11 +296,11 @@ def main():
         n_shade = sum(s.n_shade_launches for s in stats)
         # algorithmic bytes of the SoA path state each kernel must move; a "segment" is a slot that is live
         # after a shading sweep (written by it, traced, read by the next sweep), a "shadow ray" one that carries a shadow ray:
-        #   k_trace      48 B/segment (ray_o, ray_d in; hit out) + 16 B/shadow ray (sh in)
+        #   k_trace_q    48 B/segment (ray_o, ray_d in; hit out) + 32 B/shadow ray (ray_o, sh in: the shadow queue reads the origin too)
         #   k_shade_gen  176 B/segment (id 8 B, wl, thr, res, ray_d, hit in; id 8 B, wl, thr, res, ray_o, ray_d out)
         #                - 64 B/sample (a new camera sample's thr = 1 and res = 0 are neither written nor read)
         #                + 48 B/shadow ray (contrib in; sh, contrib out) + 20 B/sample (record out)
-        bytes_trace = seg * 48 + shd * 16
+        bytes_trace = seg * 48 + shd * 32
         bytes_shade = seg * 176 - smp * 64 + shd * 48 + smp * 20
         # the two kernels take nearly the same time on this workload and which one is ahead depends on the box; the shading
         # kernel (five times the bytes) is reported unless the traversal kernel is clearly the longer one
