@@ -246,7 +246,13 @@ void flatten_scene(const Scene *scene, const Sensor *sensor, FlatScene &out);
 // spectral data owned by the host (core/spectrum.h:78-80, spectra/d65.cpp:12-27)
 const float *cie1931_xyz_table();   // 3 * 95
 const float *d65_table();           // 95
-Color3 srgb_model_fetch(const Color3 &rgb);     // src/librender/srgb.cpp:11-28 (own solver, rgb2spec.cpp)
+Color3 srgb_model_fetch(const Color3 &rgb);     // src/librender/srgb.cpp:11-28: trilinear fetch in the res-64 sRGB table (rgb2spec.cpp)
+const std::string &srgb_model_source();         // where that table came from (a file, or "(computed)")
+// the table itself (rgb2spec_table.cpp; replaces ext/rgb2spec): optimiser, file I/O ("SPEC" layout of data/srgb.coeff), fetch
+void rgb2spec_build_table(int res, std::vector<float> &scale, std::vector<float> &data, int threads);
+void rgb2spec_write_table(const std::string &path, const std::vector<float> &scale, const std::vector<float> &data);
+bool rgb2spec_read_table(const std::string &path, std::vector<float> &scale, std::vector<float> &data);
+void rgb2spec_fetch_table(int res, const float *scale, const float *data, const float rgb_in[3], float out[3]);
 
 // image output (core/image.h): float RGBA
 void write_pfm(const std::string &path, int w, int h, int channels, const float *data);

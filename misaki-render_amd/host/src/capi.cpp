@@ -105,6 +105,16 @@ int msk_host_srgb_model_fetch(const float *rgb, float *out) {
     try { Color3 c = srgb_model_fetch(Color3{rgb[0], rgb[1], rgb[2]}); out[0] = c.r; out[1] = c.g; out[2] = c.b; return 0; }
     catch (const std::exception &e) { return fail(e); }
 }
+// the res-`res` sRGB upsampling table computed by this library's optimiser, written in the layout of data/srgb.coeff
+int msk_host_rgb2spec_build(int res, const char *path, int threads) {
+    try { std::vector<float> scale, data; rgb2spec_build_table(res, scale, data, threads); rgb2spec_write_table(path, scale, data); return 0; }
+    catch (const std::exception &e) { return fail(e); }
+}
+// where srgb_model_fetch's table came from (loads or computes it if that has not happened yet)
+int msk_host_srgb_model_source(char *buf, size_t cap) {
+    try { const std::string &s = srgb_model_source(); if (s.size() + 1 > cap) Throw("buffer too small"); std::memcpy(buf, s.c_str(), s.size() + 1); return 0; }
+    catch (const std::exception &e) { return fail(e); }
+}
 int msk_host_write_image(const char *path, int w, int h, int channels, const float *data) {
     try {
         std::string p(path);

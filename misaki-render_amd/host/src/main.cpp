@@ -1,6 +1,7 @@
 // misaki-cli — command line front end (the reference's src/apps/main.cpp hard-codes its scene path
 // and takes no arguments; this one takes them):
 //   misaki-cli scene.xml [-o output.(exr|pfm)] [-D name=value ...] [-q]
+//   misaki-cli --make-srgb-coeff out.coeff [res]     (what the reference's rgb2spec_opt tool does at build time)
 #include <misaki/render.h>
 
 #include <cstring>
@@ -11,6 +12,14 @@ using namespace misaki;
 int main(int argc, char **argv) {
     std::string scene_path, out_path;
     xml::ParameterList params;
+    if (argc >= 3 && std::strcmp(argv[1], "--make-srgb-coeff") == 0) {
+        try {
+            std::vector<float> scale, data;
+            rgb2spec_build_table(argc > 3 ? std::atoi(argv[3]) : 64, scale, data, 0);
+            rgb2spec_write_table(argv[2], scale, data);
+        } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return 1; }
+        return 0;
+    }
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "-o" && i + 1 < argc) out_path = argv[++i];

@@ -33,6 +33,8 @@ def load():
         lib.msk_host_aov_names.argtypes = [vp, C.c_char_p, C.c_size_t]
         lib.msk_host_aov_types.argtypes = [vp, vp, C.c_size_t]
         lib.msk_host_srgb_model_fetch.argtypes = [vp, vp]
+        lib.msk_host_rgb2spec_build.argtypes = [C.c_int, C.c_char_p, C.c_int]
+        lib.msk_host_srgb_model_source.argtypes = [C.c_char_p, C.c_size_t]
         lib.msk_host_write_image.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, vp]
         lib.msk_host_set_log_level.argtypes = [C.c_int]
         lib.msk_host_set_log_level(3)
@@ -106,6 +108,17 @@ def srgb_model_fetch(rgb):
     a, o = np.asarray(rgb, np.float32), np.zeros(3, np.float32)
     _check(load().msk_host_srgb_model_fetch(a.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p)))
     return tuple(float(x) for x in o)
+
+
+def rgb2spec_build(res, path, threads=0):
+    """The res^3 x 3 sRGB upsampling table computed by the library's optimiser (host/src/rgb2spec_table.cpp) -> file."""
+    _check(load().msk_host_rgb2spec_build(int(res), str(path).encode(), int(threads)))
+
+
+def srgb_model_source():
+    buf = C.create_string_buffer(4096)
+    _check(load().msk_host_srgb_model_source(buf, len(buf)))
+    return buf.value.decode()
 
 
 def write_image(path, img):

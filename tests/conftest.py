@@ -40,20 +40,27 @@ def golden():
     import json
     g = os.path.join(ROOT, "tests", "golden")
     return {"triplets": json.load(open(os.path.join(g, "rgb2spec_triplets.json"))),
+            "sweep": json.load(open(os.path.join(g, "rgb2spec_sweep.json"))),
             "spectral": json.load(open(os.path.join(g, "spectral_tables.json")))}
 
 
 @pytest.fixture(scope="session")
 def golden_lookup(golden):
-    """rgb -> coefficients as the reference's own rgb2spec_fetch returned them (bit patterns)."""
+    """The PRODUCT's srgb_model_fetch (misaki-render_amd/rgb2spec.py), checked on the way: for every colour the reference's
+    own rgb2spec_fetch was recorded for (tests/golden/rgb2spec_triplets.json) the coefficients must be bit-identical.
+    Scenes in the tests are therefore built with the product's upsampling, not with injected reference values."""
     import struct
+    r2s = importlib.import_module("misaki-render_amd.rgb2spec")
     table = {}
     for v in golden["triplets"].values():
         key = tuple(round(float(x), 7) for x in v["rgb"])
         table[key] = tuple(struct.unpack(">f", bytes.fromhex(h))[0] for h in v["coeff_hex"])
 
     def lookup(rgb):
-        return table[tuple(round(float(x), 7) for x in rgb)]
+        got = r2s.srgb_model_fetch(rgb)
+        want = table.get(tuple(round(float(x), 7) for x in rgb))
+        assert want is None or got == want, (rgb, got, want)
+        return got
     return lookup
 
 

@@ -11,6 +11,10 @@ Outputs are numbers, not source text:
                          rgb2spec_fetch (ext/rgb2spec/rgb2spec.c:77-119, compiled into
                          oracle/_ref/librgb2spec.so) on the res-64 table its own optimiser
                          wrote (oracle/_ref/srgb.coeff), as float32 bit patterns
+  rgb2spec_sweep.json    the same for 640 more colours (seeded random in the cube, near-black,
+                         greys, primaries / secondaries, table nodes and cell boundaries,
+                         out-of-gamut inputs that the fetch clamps): rgb and coefficients as
+                         float32 bit patterns, plus the sha256 of the reference-built table
 """
 import ctypes as C
 import json
@@ -70,7 +74,36 @@ def main():
         out[name] = {"rgb": list(rgb), "coeff_hex": [f32_hex(o[i]) for i in range(3)],
                      "coeff": [float(o[i]) for i in range(3)]}
     json.dump(out, open(f"{HERE}/rgb2spec_triplets.json", "w"), indent=1)
-    print("wrote fixtures:", len(cie), len(d65), len(out))
+
+    import hashlib
+    import numpy as np
+    rng = np.random.default_rng(20261004)
+    cols = [rng.random(3) for _ in range(400)]
+    cols += [rng.random(3) * 10.0 ** -rng.integers(1, 7) for _ in range(60)]                 # dark colours
+    cols += [np.full(3, v) for v in np.linspace(0.0, 1.0, 41)[1:]]                           # greys (black excluded: NaN there)
+    cols += [np.array(c, float) for c in ((1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (0, 1, 1), (1, 0, 1), (1, 1, 1))]
+    cols += [np.array(c, float) * v for c in ((1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (0, 1, 1), (1, 0, 1)) for v in (0.25, 0.5, 0.75)]
+    scale = np.fromfile(f"{ROOT}/oracle/_ref/srgb.coeff", np.float32, 64, offset=8)
+    for k in (1, 5, 12, 13, 31, 62, 63):                                                     # table nodes and cell faces
+        for i, j in ((0, 0), (63, 63), (17, 40), (32, 1)):
+            b = float(scale[k])
+            cols.append(np.array([b * i / 63.0, b * j / 63.0, b]))
+            cols.append(np.array([b, b * i / 63.0, b * j / 63.0]))
+    cols += [np.array(c, float) for c in ((2.0, 0.5, 0.25), (0.3, 1.5, -0.2), (-1.0, -2.0, 0.7), (1.0, 1.0, 0.999999), (5e-8, 0.0, 0.0))]
+    cols += [rng.random(3) for _ in range(640 - len(cols))]
+    sweep = []
+    for rgb in cols:
+        rgb = np.asarray(rgb, np.float32)
+        a = (C.c_float * 3)(*[float(v) for v in rgb])
+        o = (C.c_float * 3)()
+        lib.rgb2spec_fetch(model, a, o)
+        sweep.append([f32_hex(float(v)) for v in rgb] + [f32_hex(o[i]) for i in range(3)])
+    sha = hashlib.sha256(open(f"{ROOT}/oracle/_ref/srgb.coeff", "rb").read()).hexdigest()
+    json.dump({"_comment": "rgb (3 x float32 hex) -> coefficients (3 x float32 hex) from the reference's rgb2spec_fetch on the "
+                           "res-64 sRGB table the reference's rgb2spec_opt wrote in this container (platform libm); table_sha256 "
+                           "is that file's hash", "table_sha256": sha, "table_bytes": os.path.getsize(f"{ROOT}/oracle/_ref/srgb.coeff"),
+               "rows": sweep}, open(f"{HERE}/rgb2spec_sweep.json", "w"), indent=0)
+    print("wrote fixtures:", len(cie), len(d65), len(out), len(sweep))
 
 
 if __name__ == "__main__":

@@ -61,22 +61,72 @@ def test_flatten_cbox(hostmirror, golden_lookup):
     assert d.film.filter_radius == 2.0 and d.film.filter_lut[32] == 0.0
 
 
-def test_own_rgb2spec_reproduces_the_colour(golden):
-    """The package's own upsampling returns spectra that integrate back to the requested sRGB colour
-    and stay close to the reference model's spectra (coefficients differ: direct fit vs table lookup)."""
+def _sweep_rows(golden):
+    import struct
+    unhex = lambda h: struct.unpack(">f", bytes.fromhex(h))[0]
+    rows = [([unhex(h) for h in r[:3]], [unhex(h) for h in r[3:]]) for r in golden["sweep"]["rows"]]
+    rows += [([float(np.float32(x)) for x in v["rgb"]], [unhex(h) for h in v["coeff_hex"]]) for v in golden["triplets"].values()]
+    return rows
+
+
+def test_product_srgb_model_fetch_is_the_references(golden):
+    """srgb_model_fetch of the product (python mirror AND C++ host library) against 652 colours fetched by the reference's own
+    rgb2spec_fetch from the table the reference's own optimiser wrote (tests/golden/make_golden.py): bit-identical
+    coefficients, hence max |dS(lambda)| = 0 over 360-830 nm (the bar asked for was 2e-7)."""
     import importlib
     r2s = importlib.import_module("misaki-render_amd.rgb2spec")
-    t, tbl, _ = r2s._quadrature()
-    lam = 360.0 + 470.0 * t
-    for name in ("white", "green", "red", "box", "mid_1", "mid_2", "mid_3", "luminaire_reflectance"):
-        rgb = golden["triplets"][name]["rgb"]
-        c = r2s.srgb_model_fetch(rgb)
-        back = tbl @ r2s.eval_spectrum(c, lam)
-        assert np.allclose(back, rgb, atol=2e-3), (name, back, rgb)
-        ref = r2s.eval_spectrum(golden["triplets"][name]["coeff"], lam)
-        assert np.abs(r2s.eval_spectrum(c, lam) - ref).max() < 0.03, name
-    assert r2s.srgb_model_fetch((0.5, 0.5, 0.5)) == (0.0, 0.0, 0.0)
-    assert r2s.srgb_model_fetch((0, 0, 0))[2] == -np.inf and r2s.srgb_model_fetch((1, 1, 1))[2] == np.inf
+    hostlib = importlib.import_module("misaki-render_amd.hostlib")
+    lam = np.linspace(360.0, 830.0, 471)
+    worst = 0.0
+    for rgb, want in _sweep_rows(golden):
+        got_py = r2s.srgb_model_fetch(rgb)
+        got_cc = hostlib.srgb_model_fetch(rgb)
+        worst = max(worst, float(np.abs(r2s.eval_spectrum(got_py, lam) - r2s.eval_spectrum(want, lam)).max()),
+                    float(np.abs(r2s.eval_spectrum(got_cc, lam) - r2s.eval_spectrum(want, lam)).max()))
+        assert np.array_equal(np.float32(got_py).view(np.uint32), np.float32(want).view(np.uint32)), (rgb, got_py, want)
+        assert np.array_equal(np.float32(got_cc).view(np.uint32), np.float32(want).view(np.uint32)), (rgb, got_cc, want)
+    assert worst <= 2e-7
+    # white is not S = 1 in the reference's table, grey 0.5 is not exactly flat; black is this product's one deviation
+    assert 0.9 < r2s.eval_spectrum(r2s.srgb_model_fetch((1, 1, 1)), [550.0])[0] < 0.99
+    assert r2s.srgb_model_fetch((0.5, 0.5, 0.5)) != (0.0, 0.0, 0.0)
+    assert r2s.srgb_model_fetch((0, 0, 0)) == (0.0, 0.0, -np.inf) == hostlib.srgb_model_fetch((0, 0, 0))
+
+
+def test_product_table_is_the_references_table(golden, tmp_path):
+    """The table srgb_model_fetch reads was computed by the product's own optimiser (host/src/rgb2spec_table.cpp, run by
+    `make -C misaki-render_amd/host`): byte for byte the file the reference's rgb2spec_opt wrote in the same image.  A small
+    table built here through the C API reproduces the corresponding nodes of the big one's construction (determinism, threads)."""
+    import hashlib
+    import importlib
+    r2s = importlib.import_module("misaki-render_amd.rgb2spec")
+    hostlib = importlib.import_module("misaki-render_amd.hostlib")
+    assert os.path.basename(r2s.TABLE_PATH) == "srgb.coeff" and "oracle" not in r2s.TABLE_PATH and "reference" not in r2s.TABLE_PATH
+    blob = open(r2s.TABLE_PATH, "rb").read()
+    assert len(blob) == golden["sweep"]["table_bytes"]
+    assert hashlib.sha256(blob).hexdigest() == golden["sweep"]["table_sha256"]
+    assert hostlib.srgb_model_source() == r2s.TABLE_PATH
+    a, b = tmp_path / "a.coeff", tmp_path / "b.coeff"
+    hostlib.rgb2spec_build(10, a, threads=1)
+    hostlib.rgb2spec_build(10, b, threads=5)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    with pytest.raises(hostlib.HostError) as e:          # too coarse a grid for the warm start: fails loudly, as the reference's tool does
+        hostlib.rgb2spec_build(6, tmp_path / "c.coeff")
+    assert "singular Jacobian" in str(e.value)
+    res, scale, data = r2s.read_table(a)
+    assert res == 10 and scale[0] == 0 and scale[-1] == 1 and np.isfinite(data).all()
+    # round trip through the model: the spectrum of a table node integrates back to the node's colour
+    lam = np.linspace(360.0, 830.0, 941)
+    cie = np.array(golden["spectral"]["cie1931_xyz"]).reshape(3, 95)
+    d65 = np.array(golden["spectral"]["d65"])
+    grid = np.linspace(360.0, 830.0, 95)
+    cmf = np.stack([np.interp(lam, grid, c) for c in cie]); ill = np.interp(lam, grid, d65)
+    m = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]])
+    for l, k, j, i in ((0, 9, 2, 3), (1, 6, 0, 9), (2, 7, 8, 1)):
+        rgb = np.zeros(3); bb = float(scale[k])
+        rgb[l], rgb[(l + 1) % 3], rgb[(l + 2) % 3] = bb, bb * i / 9.0, bb * j / 9.0
+        s = r2s.eval_spectrum(tuple(float(v) for v in data[l, k, j, i]), lam)
+        back = m @ ((cmf * ill * s).sum(1) / (cmf[1] * ill).sum())
+        assert np.allclose(back, rgb, atol=2e-3), (rgb, back)
 
 
 def test_develop_matches_hdrfilm_formula(hostmirror):
