@@ -61,10 +61,17 @@ def parse_args():
 
 def launch_ranks(args):
     """`python bench.py --gpus N` from a bare shell: start N ranks as CHILD processes (this process has not touched a
-    GPU and never will), one per GPU, rendezvous on 127.0.0.1.  Returns the exit code for the shell."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    GPU and never will), one per GPU, rendezvous on 127.0.0.1.  Every child is watched: the first rank that exits with an
+    error ends the others (a rank that dies before or inside the rendezvous would otherwise leave the rest waiting for the
+    process-group timeout), and that rank's code is the exit code.  Returns the exit code for the shell."""
+    import threading
+    # the port stays bound (SO_REUSEADDR on both sides) until just before the children start, which narrows the window in
+    # which another process can take it; a rendezvous failure ends every rank through the watch loop below
+    sock = socket.socket()
+    sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
@@ -72,11 +79,34 @@ def launch_ranks(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out)
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)     # drain rank 0's pipe meanwhile
+    reader.start()
+    rc = 0
+    pending = set(range(args.gpus))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = abs(code)
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()
+                deadline = time.time() + 10
+                for q in pending:
+                    try:
+                        procs[q].wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        procs[q].kill()
+        if pending:
+            time.sleep(0.05)
+    reader.join(timeout=5)
+    sys.stdout.write("".join(x for x in out if x))
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return rc
 
 
 def cpu_baseline(abi, hm, flat, threads, seconds_target=12.0):
@@ -106,6 +136,27 @@ def cpu_baseline(abi, hm, flat, threads, seconds_target=12.0):
             "affinity_cpus": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": quota,
             "sample": f"cbox {WIDTH}x{HEIGHT} @ {spp} spp ({st.samples} samples, {dt:.1f} s), pcg_block sampler, "
                       f"own BVH instead of Embree, one 32x32 tile per task", "host_cpus": os.cpu_count()}
+
+
+def l2_vs_cpu(abi, hm, flat, film_gpu, prm):
+    """BASELINE's second half of the metric: per-pixel L2 of the developed image against the CPU path — the oracle renders
+    the SAME workload (full size, same counter RNG, same seed) on every host thread, both films are developed as
+    HDRFilm::image() does (films/hdrfilm.cpp:48-90: rgb = xyz_to_srgb(XYZ) / W) and compared per pixel."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding
+    sc = oracle_binding.load().scene(flat)
+    threads = len(os.sched_getaffinity(0))
+    t0 = time.perf_counter()
+    film_cpu, st = sc.render(prm, threads)
+    dt = time.perf_counter() - t0
+    sc.close()
+    a, b = hm.develop(film_gpu)[..., :3].astype(np.float64), hm.develop(film_cpu)[..., :3].astype(np.float64)
+    l2 = np.sqrt(((a - b) ** 2).sum(-1))
+    return {"max": float(l2.max()), "rmse": float(np.sqrt((l2 ** 2).mean())), "pixels_gt_1e-4": int((l2 > 1e-4).sum()),
+            "pixels": int(l2.size), "film_bit_identical": bool(np.array_equal(film_gpu, film_cpu)),
+            "cpu": f"oracle, counter RNG, seed {prm.seed}, {threads} threads, {st.samples} samples in {dt:.1f} s "
+                   f"({st.samples / dt / 1e6:.2f} Msamples/s)", "on": "developed linear-sRGB pixels (HDRFilm::image)"}
 
 
 def other_configs(abi, hm, ctx):
@@ -191,6 +242,8 @@ def main():
     mg = importlib.import_module("misaki-render_amd.multigpu")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MSK_BENCH_TEST_FAIL_RANK") == str(rank):      # tests/test_bench_launch.py: a rank that dies before the rendezvous
+        sys.exit(3)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
@@ -378,13 +431,28 @@ def main():
                          "ms_total_device": round(sum(s.ms_total for s in stats), 2),
                          "valu": valu, "per_kernel_single_stream_profile": profile_single_stream()},
         }
+        if world == 1:
+            # SURVEY 8(d) defines t_render "incl. final film copy-back": the same K steps through msk_gpu_render (host film,
+            # 5 MB over PCIe per step); `value` above keeps the film in HBM, as the multi-GPU reduce needs it
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                film_host, _ = scene.render(prm)
+            dt_host = time.perf_counter() - t1
+            out["ms_per_step_incl_copyback"] = round(dt_host / args.steps * 1e3, 3)
+            out["value_incl_copyback"] = round(samples_step * args.steps / dt_host / 1e6, 2)
+        # the measured headline is safe on stderr before anything slower or riskier runs (CPU baselines, other configs)
+        print("bench.py headline (extras follow on stdout): " + json.dumps(out), file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:
+            try:
+                out["l2_vs_cpu"] = l2_vs_cpu(abi, hm, flat, film_host, prm)
+            except Exception as e:
+                out["l2_vs_cpu"] = {"error": str(e)[:300]}
             # the reference CLI caps TBB at 8 threads (main.cpp:43-44): that run is `cpu_baseline`; the same port on every
             # hardware thread of this host rides along (SURVEY §8d asks for both)
             out["cpu_baseline"] = cpu_baseline(abi, hm, flat, min(8, os.cpu_count() or 1))
             n_all = len(os.sched_getaffinity(0))
             if n_all > 8:
-                out["cpu_baseline_all_threads"] = cpu_baseline(abi, hm, flat, n_all)
+                out["cpu_baseline_all_threads"] = cpu_baseline(abi, hm, flat, n_all, seconds_target=8.0)
         else:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_other_configs:

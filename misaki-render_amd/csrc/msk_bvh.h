@@ -236,8 +236,9 @@ struct Collapser {
         float *o = &out[(size_t) me * 32];
         for (int i = 0; i < 4; ++i)
             for (int a = 0; a < 3; ++a) {
-                o[a * 4 + i] = i < ns ? s[i].lo[a] : 0.f;
-                o[12 + a * 4 + i] = i < ns ? s[i].hi[a] : 0.f;
+                // an unused slot holds an inverted box: the slab test misses it like any other box (node4_step has no other test)
+                o[a * 4 + i] = i < ns ? s[i].lo[a] : 3e38f;
+                o[12 + a * 4 + i] = i < ns ? s[i].hi[a] : -3e38f;
             }
         std::memcpy(&o[24], refs, 16);
         return me;
@@ -257,6 +258,7 @@ struct Collapser8 {
     const std::vector<float> &n2;
     std::vector<float> out;
     int max_depth = 0;
+    bool ok = true;                      // false: a quantised box failed its containment check (extents beyond the exponent clamp)
     typedef Collapser::Slot Slot;
     void children(uint32_t node, Slot *a, Slot *b) const { Collapser c{n2, {}, 0}; c.children(node, a, b); }
     uint32_t collapse(uint32_t node, int depth) {
@@ -307,7 +309,7 @@ struct Collapser8 {
                 double ql = std::floor(((double) s[i].lo[a] - (double) origin[a]) / sc), qh = std::ceil(((double) s[i].hi[a] - (double) origin[a]) / sc);
                 ql = std::max(0.0, std::min(255.0, ql)); qh = std::max(0.0, std::min(255.0, qh));
                 // exact in double: origin + q * 2^e; the decoded box must contain the child's
-                if ((double) origin[a] + ql * sc > (double) s[i].lo[a] || (double) origin[a] + qh * sc < (double) s[i].hi[a]) std::abort();
+                if ((double) origin[a] + ql * sc > (double) s[i].lo[a] || (double) origin[a] + qh * sc < (double) s[i].hi[a]) ok = false;
                 q[a][i] = (uint8_t) ql; q[3 + a][i] = (uint8_t) qh;
             }
         }
@@ -320,13 +322,16 @@ struct Collapser8 {
         return me;
     }
 };
-static inline void collapse8(Built &b) {
+// false (and no 8-wide tree) when a box cannot be quantised conservatively: the caller keeps the full-precision 4-wide tree
+static inline bool collapse8(Built &b) {
     b.nodes8.clear(); b.root_ref8 = b.root_ref; b.max_depth8 = 0;
-    if (b.root_ref & 0x80000000u) return;
-    Collapser8 c{b.nodes, {}, 0};
+    if (b.root_ref & 0x80000000u) return true;
+    Collapser8 c{b.nodes, {}, 0, true};
     b.root_ref8 = c.collapse(b.root_ref, 1);
+    if (!c.ok) { b.root_ref8 = b.root_ref; return false; }
     b.nodes8 = std::move(c.out);
     b.max_depth8 = c.max_depth;
+    return true;
 }
 
 }  // namespace mskbvh

@@ -94,6 +94,14 @@ struct msk_scene {
     size_t tree_bytes = 0;             // node array the traversal walks
 };
 
+#ifdef MSK_COUNT
+// instrumented builds only: reads and clears the traversal counters of msk_kernels.h
+extern "C" int msk_gpu_debug_counts(unsigned long long *out16) {
+    unsigned long long z[16] = {};
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out16, HIP_SYMBOL(msk_counts), sizeof z) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(msk_counts), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
 // ------------------------------------------------------------------------------------------
 extern "C" const char *msk_gpu_last_error(const msk_ctx *ctx) {
     return ctx ? ctx->last_error.c_str() : g_last_error.c_str();
@@ -415,9 +423,9 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     s->trace_lds_bytes = stack_bytes + (s->lds_scene ? scene_bytes : 0);
     s->trace_mode = s->lds_scene ? 0 : 1;
     s->tree_bytes = bvh.nodes.size() * 4;
-    if (!s->lds_scene && env_u32("MSK_WIDE_BVH", MSK_WIDE_BVH_DEFAULT) == 8 && !(bvh.root_ref & MSK_LEAF_BIT)) {
+    // (a tree whose boxes cannot be quantised conservatively — extents beyond the exponent range — keeps the 4-wide form)
+    if (!s->lds_scene && env_u32("MSK_WIDE_BVH", MSK_WIDE_BVH_DEFAULT) == 8 && !(bvh.root_ref & MSK_LEAF_BIT) && mskbvh::collapse8(bvh)) {
         // the tree stays in HBM/L2: eight quantised child boxes per 128-byte line (msk_bvh.h: collapse8)
-        mskbvh::collapse8(bvh);
         hipError_t e8 = s->nodes8.upload(bvh.nodes8);
         if (e8 != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(e8)); }
         ds.nodes8 = s->nodes8.as<float4>(); ds.root_ref8 = bvh.root_ref8; ds.n_nodes8 = (uint32_t) (bvh.nodes8.size() / 32);
@@ -450,7 +458,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         // array (LaneStack) — any tree depth works within a fixed 24 KB of LDS per block.  (Measured: the cap does not
         // change the trace time between 8 and 40 entries; the traversal needs >= 4 waves per SIMD and has them.)
         ds.stack_entries = std::min(ds.stack_total, std::max(4u, env_u32("MSK_STACK_CAP", 24) & ~3u));
-        s->trace_lds_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4;
+        s->trace_lds_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4 + (size_t) MSK_BLOCK * 16;       // + four words per lane (node4_step)
     }
     // LDS plan of k_shade_gen: the small lookup tables (tri_verts, mesh/bsdf/emitter records, cdf, d65, cie)
     const size_t table_bytes = ((size_t) ds.n_tris * 6 + ds.n_meshes + ds.n_bsdf_f4 + ds.n_emitters * 2 +
@@ -830,6 +838,12 @@ static int check_params(msk_ctx *ctx, const msk_render_params *p, int block_min)
     if (p->rr_depth <= 0) return fail(ctx, MSK_ERR_INVALID_ARG, "\"rr_depth\" must be set to a value greater than zero!");
     if (p->max_depth < 0 && p->max_depth != -1)
         return fail(ctx, MSK_ERR_INVALID_ARG, "\"max_depth\" must be set to -1 (infinite) or a value >= 0");
+    // the path state holds 12 bits of depth: a path is cut after bounce MSK_MAX_DEPTH.  Unreachable with Russian roulette from a
+    // depth below that (survival <= 0.95 per bounce); a bound or a roulette start beyond it would be cut silently, so refuse
+    if (p->max_depth > (int) MSK_MAX_DEPTH)
+        return fail(ctx, MSK_ERR_UNSUPPORTED, "max_depth %d: the path state holds bounces up to %u", p->max_depth, MSK_MAX_DEPTH);
+    if (p->max_depth < 0 && p->rr_depth > (int) MSK_MAX_DEPTH)
+        return fail(ctx, MSK_ERR_UNSUPPORTED, "rr_depth %d with unbounded max_depth: the path state holds bounces up to %u", p->rr_depth, MSK_MAX_DEPTH);
     if (p->block_size < block_min || p->block_size > 64)
         return fail(ctx, MSK_ERR_INVALID_ARG, "block_size %d outside [%d, 64]", p->block_size, block_min);
     const uint32_t bs = p->block_stride ? p->block_stride : 1;

@@ -271,6 +271,7 @@ MSK_DEV bool box_test(float lox, float loy, float loz, float hix, float hiy, flo
 template <bool OVF>
 struct LaneStack {
     uint32_t *lds; uint32_t *ovf; int cap; size_t stride;
+    uint32_t *scratch = nullptr;        // OVF kernels: 4 words of LDS per lane (node4_step's child references), else unused
     MSK_DEV void push(int &sp, uint32_t v) const {
         if (!OVF || sp < cap) lds[sp * MSK_BLOCK] = v; else ovf[(size_t) (sp - cap) * stride] = v;
         sp += 1;
@@ -338,12 +339,74 @@ MSK_DEV bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict
     return false;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// One visit of a 4-wide node in HBM/L2 (msk_bvh.h: collapse4), written against the measured issue costs of gfx950's VALU
+// (tools/micro/valu_ops.hip: v_fma / v_mul / v_add / v_sub / v_and / v_or / v_xor / v_add_u32 / v_ashrrev take ~2.3-3 cycles of
+// a SIMD per wave64 instruction; v_min / v_max / v_max3 / v_cmp / v_cndmask_e64 / v_lshl / v_and_or / v_min_u32 ~4.1) — the
+// traversal kernels are bound by VALU issue, so the step is built from few and cheap instructions:
+//   * near / far planes are picked by ADDRESS: the ray holds, per axis, the byte offset of its near plane quadruple inside
+//     the node (0 or 48, by the sign of the reciprocal direction: Sel4); the far one is that offset ^ 48.  24 v_min / v_max of
+//     the order-free slab test are gone, six loads go through a buffer resource with 32-bit per-lane offsets;
+//   * an unused slot holds an inverted box (lo = +3e38, hi = -3e38: collapse4), so it misses like any other box;
+//   * a miss becomes an all-ones key through the sign of t1 - t0 (v_sub, v_ashrrev, v_or), a hit the bits of its entry
+//     distance with the slot number in the two low bits; four keys are sorted by five v_min_u32 / v_max_u32 pairs;
+//   * the children's references go to four words of LDS per lane and come back by index (ds_read_b32 at the key's low bits).
+// Only culling and visiting ORDER are involved (hit selection is by (t, prim)): same hits as every other traversal.
+// ------------------------------------------------------------------------------------------
+struct Sel4 { uint32_t kx, ky, kz; };          // byte offsets of the near-plane quadruples: {0|48, 16 + (0|48), 32 + (0|48)}
+MSK_DEV Sel4 make_sel4(f3 idir) {
+    Sel4 s;
+    s.kx = idir.x < 0.f ? 48u : 0u; s.ky = idir.y < 0.f ? 64u : 16u; s.kz = idir.z < 0.f ? 80u : 32u;
+    return s;
+}
+typedef uint32_t msk_u4 __attribute__((ext_vector_type(4)));
+MSK_DEV __amdgpu_buffer_rsrc_t nodes4_rsrc(const DeviceScene &sc) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *) sc.nodes4, 0, sc.n_nodes4 * 128u, 0x00020000);
+}
+// returns the next node / leaf reference (0xffffffff: nothing left), pushes the other hit children farthest first
+template <bool OVF>
+MSK_DEV uint32_t node4_step(__amdgpu_buffer_rsrc_t rsrc, uint32_t node, const Sel4 &sel, f3 idir, f3 oi, float tmin, float tcur,
+                            const LaneStack<OVF> &stack, int &sp) {
+    const uint32_t base = node << 7;
+    const uint32_t ax = base + sel.kx, ay = base + sel.ky, az = base + sel.kz;
+    const msk_u4 nx = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ax, 0, 0), fx = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ax ^ 48u, 0, 0);
+    const msk_u4 ny = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ay, 0, 0), fy = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ay ^ 80u, 0, 0);   // 16 <-> 64
+    const msk_u4 nz = __builtin_amdgcn_raw_buffer_load_b128(rsrc, az, 0, 0), fz = __builtin_amdgcn_raw_buffer_load_b128(rsrc, az ^ 112u, 0, 0);  // 32 <-> 80
+    const msk_u4 rf = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 96u, 0, 0);
+    *(msk_u4 *) stack.scratch = rf;
+    uint32_t key[4];
+#define MSK_CHILD(I, C) {                                                                                                        \
+        const float t0 = fmaxf(fmaxf(fmaxf(__fmaf_rn(__uint_as_float(nx.C), idir.x, -oi.x), __fmaf_rn(__uint_as_float(ny.C), idir.y, -oi.y)), \
+                                     __fmaf_rn(__uint_as_float(nz.C), idir.z, -oi.z)), tmin);                                   \
+        const float t1 = fminf(fminf(fminf(__fmaf_rn(__uint_as_float(fx.C), idir.x, -oi.x), __fmaf_rn(__uint_as_float(fy.C), idir.y, -oi.y)), \
+                                     __fmaf_rn(__uint_as_float(fz.C), idir.z, -oi.z)), tcur);                                   \
+        const uint32_t miss = (uint32_t) ((int32_t) __float_as_uint(t1 * 1.0000004f - t0) >> 31);                              \
+        key[I] = ((__float_as_uint(t0) & 0x7ffffff0u) | (uint32_t) ((I) << 2)) | miss; }
+    MSK_CHILD(0, x) MSK_CHILD(1, y) MSK_CHILD(2, z) MSK_CHILD(3, w)
+#undef MSK_CHILD
+#define MSK_CSWAPU(a, b) { const uint32_t lo_ = a < b ? a : b; b = a < b ? b : a; a = lo_; }
+    MSK_CSWAPU(key[0], key[1]) MSK_CSWAPU(key[2], key[3]) MSK_CSWAPU(key[0], key[2]) MSK_CSWAPU(key[1], key[3]) MSK_CSWAPU(key[1], key[2])
+#undef MSK_CSWAPU
+    const uint32_t NONE = 0xffffffffu;
+    const char *sc4 = (const char *) stack.scratch;
+    if (key[0] == NONE) return sp > 0 ? stack.pop(sp) : NONE;
+    if (key[1] != NONE) {
+        if (key[2] != NONE) {
+            if (key[3] != NONE) stack.push(sp, *(const uint32_t *) (sc4 + (key[3] & 12u)));
+            stack.push(sp, *(const uint32_t *) (sc4 + (key[2] & 12u)));
+        }
+        stack.push(sp, *(const uint32_t *) (sc4 + (key[1] & 12u)));
+    }
+    return *(const uint32_t *) (sc4 + (key[0] & 12u));
+}
+
 // The same traversal over the 4-wide nodes of msk_bvh.h (one 128-byte line per visit, half the dependent round trips
 // of the binary tree); used when the tree lives in HBM/L2.  Hit selection is by (t, prim), so the result is the binary
 // tree's, bit for bit.
 #define MSK_EMPTY4 0xfffffffeu
 template <bool ANY, bool OVF>
-MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restrict__ tris, float tri_pad, uint32_t root_ref,
+MSK_DEV bool traverse4(__amdgpu_buffer_rsrc_t rsrc, const float4 *__restrict__ nodes, const float4 *__restrict__ tris, float tri_pad, uint32_t root_ref,
                        uint32_t n_tris, f3 o, f3 d, float tmin, float tmax, const LaneStack<OVF> &stack, float *best_t, float *best_u,
                        float *best_v, uint32_t *best_prim) {
     float bt = tmax, bu = 0.f, bv = 0.f;
@@ -355,8 +418,14 @@ MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restric
     int sp = 0;
     uint32_t cur = root_ref;
     const uint32_t DONE = 0xffffffffu;
+    const Sel4 sel = make_sel4(idir);
     while (cur != DONE) {
         while (!(cur & MSK_LEAF_BIT)) {
+            if constexpr (OVF) {                     // tree in HBM/L2: the cheap visit (node4_step); rsrc covers `nodes`
+                cur = node4_step<OVF>(rsrc, cur, sel, idir, oi, tmin, bt, stack, sp);
+                if (cur == DONE) break;
+                continue;
+            }
             const float4 *n = nodes + (size_t) cur * 8;
             const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], rf = n[6];
             float t0, t1, t2, t3;
@@ -533,7 +602,7 @@ template <int MODE, bool ANY>
 MSK_DEV bool traverse_scene(const DeviceScene &sc, const TraceLds &g, f3 o, f3 d, float tmin, float tmax, const LaneStack<MSK_OVF(MODE)> &stack,
                             float *bt, float *bu, float *bv, uint32_t *bp) {
     if constexpr (MODE == 4) return traverse8<ANY, true>(sc.nodes8, g.tris, sc.tri_pad, sc.root_ref8, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
-    else if (MODE == 2 || MODE == 3) return traverse4<ANY, MSK_OVF(MODE)>(MODE == 3 ? g.nodes : sc.nodes4, g.tris, sc.tri_pad, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+    else if (MODE == 2 || MODE == 3) return traverse4<ANY, MSK_OVF(MODE)>(nodes4_rsrc(sc), MODE == 3 ? g.nodes : sc.nodes4, g.tris, sc.tri_pad, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
     return traverse<ANY, MSK_OVF(MODE)>(g.nodes, g.tris, sc.tri_pad, sc.root_ref, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
 }
 
@@ -545,7 +614,8 @@ MSK_DEV void trace_chunks(const DeviceScene &sc, const PathState &st, const Pass
     float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
     TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE, MODE == 3);
     const LaneStack<MSK_OVF(MODE)> stack{stack_base + threadIdx.x, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
-                                     (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK};
+                                     (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK,
+                                     MSK_OVF(MODE) ? stack_base + sc.stack_entries * MSK_BLOCK + threadIdx.x * 4 : nullptr};
     const uint32_t gwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
     const uint32_t lwave = gwave / pp.trace_split, sub = gwave % pp.trace_split;     // region of this launch, and which of its chunks
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
@@ -697,7 +767,23 @@ k_trace_q(DeviceScene sc, PathState st, PassParams pp, uint32_t refill, uint32_t
 // (or nothing else is running), so a long ray no longer idles the 63 lanes that shared its chunk.  Each lane's
 // arithmetic is exactly traverse()'s: same hit, bit for bit.
 // ------------------------------------------------------------------------------------------
+#ifdef MSK_COUNT
+// instrumented builds only (tools/build_variant.sh count -DMSK_COUNT; read through msk_gpu_debug_counts): traversal work of
+// k_trace_r.  [0] rays, [1] quanta (wave-level), [2] active lanes summed over quanta, [3] inner-node steps (wave-level),
+// [4] inner-node visits (lanes), [5] triangle steps (wave-level), [6] triangle tests (lanes), [7] leaf visits (lanes)
+__device__ unsigned long long msk_counts[16];
+MSK_DEV bool first_active_lane() {
+    const unsigned long long e = __builtin_amdgcn_read_exec();
+    return __builtin_amdgcn_mbcnt_hi((uint32_t) (e >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) e, 0u)) == 0u;
+}
+#define MSK_CNT(i, v) atomicAdd(&msk_counts[i], (unsigned long long) (v))
+#define MSK_CNT_WAVE(i) do { if (first_active_lane()) atomicAdd(&msk_counts[i], 1ull); } while (0)
+#else
+#define MSK_CNT(i, v) do {} while (0)
+#define MSK_CNT_WAVE(i) do {} while (0)
+#endif
 struct TravState {
+    Sel4 sel;
     f3 o, d, idir, oi;
     float tmin, tmax, bt, bu, bv;
     uint32_t bp, cur;
@@ -706,6 +792,7 @@ struct TravState {
 MSK_DEV void trav_begin(TravState &t, uint32_t root_ref, uint32_t n_tris, f3 o, f3 d, float tmin, float tmax) {
     t.o = o; t.d = d; t.tmin = tmin; t.tmax = tmax;
     t.idir = slab_idir(d);
+    t.sel = make_sel4(t.idir);
     t.oi = mk3(o.x * t.idir.x, o.y * t.idir.y, o.z * t.idir.z);
     t.bt = tmax; t.bu = 0.f; t.bv = 0.f; t.bp = MSK_NO_PRIM; t.sp = 0;
     t.cur = n_tris ? root_ref : 0xffffffffu;
@@ -719,33 +806,16 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
     const uint32_t DONE = 0xffffffffu;
     int steps = 0;
     bool found = false;
+    __amdgpu_buffer_rsrc_t rsrc4;
+    if constexpr (MODE == 2) rsrc4 = nodes4_rsrc(sc);
     while (!(t.cur & MSK_LEAF_BIT) && steps < max_inner) {
         ++steps;
+        MSK_CNT_WAVE(3); MSK_CNT(4, 1);
         if constexpr (MODE == 4) {
             t.cur = node8_step<true>(sc.nodes8, t.cur, t.o, t.d, t.idir, t.tmin, t.bt, stack, t.sp);
             if (t.cur == MSK_NONE_REF && t.sp > 0) t.cur = stack.pop(t.sp);
-        } else if (MODE == 2) {
-            const float4 *n = sc.nodes4 + (size_t) t.cur * 8;
-            const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], rf = n[6];
-            float t0, t1, t2, t3;
-            const bool h0 = box_test(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t.idir, t.oi, t.tmin, t.bt, &t0);
-            const bool h1 = box_test(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t.idir, t.oi, t.tmin, t.bt, &t1);
-            const bool h2 = box_test(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t.idir, t.oi, t.tmin, t.bt, &t2);
-            const bool h3 = box_test(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t.idir, t.oi, t.tmin, t.bt, &t3);
-            uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
-            t0 = (h0 && r0 != MSK_EMPTY4) ? t0 : MSK_INF_F; t1 = (h1 && r1 != MSK_EMPTY4) ? t1 : MSK_INF_F;
-            t2 = (h2 && r2 != MSK_EMPTY4) ? t2 : MSK_INF_F; t3 = (h3 && r3 != MSK_EMPTY4) ? t3 : MSK_INF_F;
-#define MSK_CSWAP(ta, ra, tb, rb) { const bool s_ = tb < ta; const float tt_ = s_ ? tb : ta; const uint32_t rr_ = s_ ? rb : ra; \
-                                    tb = s_ ? ta : tb; rb = s_ ? ra : rb; ta = tt_; ra = rr_; }
-            MSK_CSWAP(t0, r0, t1, r1) MSK_CSWAP(t2, r2, t3, r3) MSK_CSWAP(t0, r0, t2, r2) MSK_CSWAP(t1, r1, t3, r3) MSK_CSWAP(t1, r1, t2, r2)
-#undef MSK_CSWAP
-            if (t0 != MSK_INF_F) {
-                if (t3 != MSK_INF_F) { stack.push(t.sp, r3); }
-                if (t2 != MSK_INF_F) { stack.push(t.sp, r2); }
-                if (t1 != MSK_INF_F) { stack.push(t.sp, r1); }
-                t.cur = r0;
-            } else if (t.sp > 0) { t.cur = stack.pop(t.sp); }
-            else { t.cur = DONE; }
+        } else if constexpr (MODE == 2) {
+            t.cur = node4_step<true>(rsrc4, t.cur, t.sel, t.idir, t.oi, t.tmin, t.bt, stack, t.sp);
         } else {
             const float4 *n = g.nodes + (size_t) t.cur * 4;
             const float4 a = n[0], b = n[1], c = n[2], m = n[3];
@@ -765,7 +835,9 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
     }
     if (t.cur != DONE && (t.cur & MSK_LEAF_BIT)) {
         const uint32_t first = (t.cur & 0x7fffffffu) >> 5, cnt = t.cur & 31u;
+        MSK_CNT(7, 1);
         for (uint32_t i = 0; i < cnt; ++i) {
+            MSK_CNT_WAVE(5); MSK_CNT(6, 1);
             const float4 *q = g.tris + (size_t) (first + i) * (MSK_OVF(MODE) ? 4 : 6);
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             float tt, u, v;
@@ -789,7 +861,8 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
     float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
     TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE, MODE == 3);
     const LaneStack<MSK_OVF(MODE)> stack{stack_base + threadIdx.x, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
-                                     (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK};
+                                     (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK,
+                                     MSK_OVF(MODE) ? stack_base + sc.stack_entries * MSK_BLOCK + threadIdx.x * 4 : nullptr};
     const uint32_t lwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
     if (lwave >= pp.region_count) return;
@@ -825,9 +898,12 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
             next += (uint32_t) __popcll(idle);
         }
         if (__ballot(active) == 0ull) break;          // next >= n here: an all-idle wave always refills while slots remain
+        MSK_CNT_WAVE(1);
         if (active) {
+            MSK_CNT(2, 1);
             const bool occ = trav_quantum<MODE>(sc, g, t, stack, max_inner, shadow_phase);
             if (t.cur == 0xffffffffu) {
+                MSK_CNT(0, 1);
                 if (shadow_phase) {
                     unocc = occ ? 0u : MSK_HIT_UNOCCLUDED;
                     shadow_phase = false;
@@ -852,7 +928,8 @@ k_trace_batch(DeviceScene sc, const float4 *rays, uint64_t n, float4 *out_hit, u
     float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
     TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE, MODE == 3);
     const LaneStack<MSK_OVF(MODE)> stack{stack_base + threadIdx.x, stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
-                                     (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK};
+                                     (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK,
+                                     MSK_OVF(MODE) ? stack_base + sc.stack_entries * MSK_BLOCK + threadIdx.x * 4 : nullptr};
     for (uint64_t i = (uint64_t) blockIdx.x * MSK_BLOCK + threadIdx.x; i < n; i += (uint64_t) gridDim.x * MSK_BLOCK) {
         const float4 ro = rays[2 * i], rd = rays[2 * i + 1];
         float bt, bu, bv; uint32_t bp;

@@ -53,6 +53,16 @@ def test_single_rank_dry_run():
 import pytest
 
 
+def test_a_dead_rank_ends_the_launch_quickly():
+    """A rank that exits before the rendezvous must not leave the others (and the shell) waiting for the process-group
+    timeout: the launcher stops the siblings and returns the failing rank's code."""
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120, env=dict(os.environ, MSK_BENCH_TEST_FAIL_RANK="1"))
+    assert r.returncode == 3 and "rank 1 exited with code 3" in r.stderr and time.time() - t0 < 60
+
+
 @pytest.mark.gpu
 def test_two_ranks_rehearsed_on_one_gpu():
     """The N = 2 path with real renders: two rank processes spawned from a bare shell, both on cuda:0, sample shards

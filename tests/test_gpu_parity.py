@@ -244,6 +244,25 @@ def test_headline_size_properties(gpu_ctx, abi, hostmirror, golden_lookup):
     g.close()
 
 
+def test_config2_full_size_film_bit_exact(gpu_ctx, abi, hostmirror, oracle, golden_lookup):
+    """BASELINE config 2 at FULL size — cbox 512x512 @ 512 spp, counter RNG, seed 0 (134 M samples; the oracle takes 20-30 s on
+    the box's host threads): the GPU film equals the oracle's film bit for bit, hence per-pixel L2 of the developed image = 0
+    (the north star allows 1e-4)."""
+    import os
+    flat = cbox(hostmirror, golden_lookup, 512, 512)
+    prm = abi.render_params(spp=512, seed=0)
+    g = abi.Scene(gpu_ctx, flat)
+    film, st = g.render(prm)
+    g.close()
+    o = oracle.scene(flat)
+    ref, rst = o.render(prm, threads=len(os.sched_getaffinity(0)))
+    o.close()
+    assert st.samples == rst.samples == 512 * 512 * 512
+    assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+    a, b = hostmirror.develop(film)[..., :3].astype(np.float64), hostmirror.develop(ref)[..., :3].astype(np.float64)
+    assert np.sqrt(((a - b) ** 2).sum(-1)).max() == 0.0
+
+
 def test_two_emitters(gpu_ctx, abi, hostmirror, oracle, golden_lookup):
     """Multi-emitter selection path of Scene::sample_emitter_direct (scene.cpp:78-88)."""
     second = hostmirror.MeshSpec("lamp2", [((100, 300, 558), (200, 300, 558), (200, 400, 558), (100, 400, 558))],
@@ -292,6 +311,14 @@ def test_error_behaviour(scene256, gpu_ctx, abi, hostmirror, golden_lookup):
         g.render(abi.render_params(spp=4, max_depth=-2))          # integrator.cpp:135-136
     with pytest.raises(abi.MskError):
         g.render(abi.render_params(spp=0))
+    # the path state holds bounces up to 4094: a bound or a roulette start beyond that is refused, not silently cut
+    with pytest.raises(abi.MskError) as e:
+        g.render(abi.render_params(spp=1, max_depth=5000))
+    assert e.value.code == abi.MSK_ERR_UNSUPPORTED and "max_depth" in str(e.value)
+    with pytest.raises(abi.MskError) as e:
+        g.render(abi.render_params(spp=1, rr_depth=5000))
+    assert e.value.code == abi.MSK_ERR_UNSUPPORTED and "rr_depth" in str(e.value)
+    g.render(abi.render_params(spp=1, rr_depth=5000, max_depth=12))       # bounded: fine
     bad = cbox(hostmirror, golden_lookup, 32, 32)
     bad.desc.meshes[2].bsdf_id = 99
     with pytest.raises(abi.MskError) as e:
