@@ -169,13 +169,16 @@ def _ptr(a):
 
 
 class Context:
-    """msk_ctx: one per process / per GPU."""
+    """msk_ctx: one per process.  `device` is a HIP ordinal, or a sequence of ordinals for a GROUP context (msk_gpu_init with
+    n > 1: renders are sample-sharded over the members and the films summed on the first device; an ordinal may repeat)."""
 
     def __init__(self, device=0):
         self.lib = load_library()
         self.handle = C.c_void_p()
-        ids = (C.c_int * 1)(device)
-        rc = self.lib.msk_gpu_init(ids, 1, C.byref(self.handle))
+        devs = [int(device)] if isinstance(device, int) else [int(d) for d in device]
+        self.devices = devs
+        ids = (C.c_int * len(devs))(*devs)
+        rc = self.lib.msk_gpu_init(ids, len(devs), C.byref(self.handle))
         if rc != MSK_OK:
             raise MskError(rc, (self.lib.msk_gpu_last_error(None) or b"").decode())
 

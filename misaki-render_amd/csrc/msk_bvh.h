@@ -51,6 +51,15 @@ struct Built {
     std::vector<float> nodes4;
     uint32_t root_ref4 = 0;
     int max_depth4 = 0;
+    // The same 4-wide nodes (same numbering, same child refs) with QUANTISED child boxes, 16 dwords (64 B) per node — what the
+    // traversal of a tree in HBM/L2 reads: four 16-byte loads per visit instead of seven (the traversal is bound by the number
+    // of per-lane load instructions, msk_kernels.h: node4q_step):
+    //   dw 0-2 origin (low corner of the node's box), dw 3 scale.x   dw 4-5 scale.y, scale.z (extent / 255, rounded up)
+    //   dw 6-8 lo.x lo.y lo.z, dw 9-11 hi.x hi.y hi.z: one byte per slot (slot s = byte s); child box = [origin + lo * scale,
+    //          origin + hi * scale], rounded OUTWARDS around the padded box of nodes4 (checked in exact arithmetic)
+    //   dw 12-15 child refs; an unused slot holds an inverted box (lo = 255, hi = 0) and the reference of an empty leaf
+    // Empty (and nodes4 used instead) if a box cannot be quantised conservatively.
+    std::vector<uint32_t> nodes4q;
     // 8-wide form with QUANTISED child boxes (collapse8): 32 dwords (128 B = one L2 line) per node,
     //   dw 0-2  origin (the low corner of the node's box)      dw 3  meta: bits 0-1 ordering axis, bits 8-15 mask of used slots
     //   dw 4-6  scale (a power of two per axis)                dw 7  -
@@ -201,7 +210,10 @@ struct Collapser {
     const std::vector<float> &n2;
     std::vector<float> out;
     int max_depth = 0;
+    std::vector<uint32_t> out_q;        // the quantised twin (Built::nodes4q)
+    bool ok_q = true;
     struct Slot { uint32_t ref; float lo[3], hi[3]; };
+    void quantise(uint32_t me, const Slot *s, int ns, const uint32_t *refs);
     static float area(const Slot &s) {
         float dx = s.hi[0] - s.lo[0], dy = s.hi[1] - s.lo[1], dz = s.hi[2] - s.lo[2];
         return 2.f * (dx * dy + dy * dz + dz * dx);
@@ -241,15 +253,47 @@ struct Collapser {
                 o[12 + a * 4 + i] = i < ns ? s[i].hi[a] : -3e38f;
             }
         std::memcpy(&o[24], refs, 16);
+        quantise(me, s, ns, refs);
         return me;
     }
 };
+inline void Collapser::quantise(uint32_t me, const Slot *s, int ns, const uint32_t *refs) {
+    if (out_q.size() < ((size_t) me + 1) * 16) out_q.resize(((size_t) me + 1) * 16, 0u);
+    uint32_t *q = &out_q[(size_t) me * 16];
+    float origin[3], scale[3];
+    uint32_t lo_b[3] = {0, 0, 0}, hi_b[3] = {0, 0, 0};
+    for (int a = 0; a < 3; ++a) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int i = 0; i < ns; ++i) { lo = std::min(lo, (double) s[i].lo[a]); hi = std::max(hi, (double) s[i].hi[a]); }
+        origin[a] = (float) lo;
+        const double ext = hi - (double) origin[a];
+        // the finest grid that still spans the node: scale = ext / 255 rounded up to a float (a power of two would be up to twice
+        // as coarse and cost ~10 % more leaf visits); a degenerate axis gets a tiny positive scale
+        float sf = ext > 0 ? (float) (ext / 255.0) : 1e-30f;
+        if (!(sf > 0.f) || !std::isfinite(sf)) { ok_q = false; sf = 1.f; }
+        while (255.0 * (double) sf < ext) sf = std::nextafterf(sf, INFINITY);
+        scale[a] = sf;
+        const double sc = (double) sf;
+        for (int i = 0; i < 4; ++i) {
+            if (i >= ns) { lo_b[a] |= 255u << (8 * i); continue; }                 // inverted: lo = 255, hi = 0
+            double ql = std::floor(((double) s[i].lo[a] - (double) origin[a]) / sc), qh = std::ceil(((double) s[i].hi[a] - (double) origin[a]) / sc);
+            ql = std::max(0.0, std::min(255.0, ql)); qh = std::max(0.0, std::min(255.0, qh));
+            // exact in double: the decoded box must contain the child's
+            if (!((double) origin[a] + ql * sc <= (double) s[i].lo[a] && (double) origin[a] + qh * sc >= (double) s[i].hi[a])) ok_q = false;
+            lo_b[a] |= (uint32_t) ql << (8 * i); hi_b[a] |= (uint32_t) qh << (8 * i);
+        }
+    }
+    std::memcpy(&q[0], origin, 12); std::memcpy(&q[3], &scale[0], 4); std::memcpy(&q[4], &scale[1], 8);
+    for (int a = 0; a < 3; ++a) { q[6 + a] = lo_b[a]; q[9 + a] = hi_b[a]; }
+    for (int i = 0; i < 4; ++i) q[12 + i] = refs[i] == kEmpty4 ? 0x80000000u : refs[i];       // empty leaf: first 0, count 0
+}
 static inline void collapse4(Built &b) {
-    b.nodes4.clear(); b.root_ref4 = b.root_ref; b.max_depth4 = 0;
+    b.nodes4.clear(); b.nodes4q.clear(); b.root_ref4 = b.root_ref; b.max_depth4 = 0;
     if (b.root_ref & 0x80000000u) return;            // a single leaf: nothing to collapse
     Collapser c{b.nodes, {}, 0};
     b.root_ref4 = c.collapse(b.root_ref, 1);
     b.nodes4 = std::move(c.out);
+    if (c.ok_q) b.nodes4q = std::move(c.out_q);
     b.max_depth4 = c.max_depth;
 }
 

@@ -11,6 +11,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -24,7 +25,10 @@ using namespace msk;
 
 static thread_local std::string g_last_error;
 
+#define MSK_MAX_GROUP 8                 /* devices behind one context (msk_multi.h) */
+struct msk_group;
 struct msk_ctx {
+    msk_group *group = nullptr;        // non-null: a group context (msk_gpu_init with n > 1); the fields below describe its first device
     int device = 0;
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop;
@@ -83,16 +87,23 @@ static uint32_t env_u32(const char *name, uint32_t def);
 struct Workspace;
 struct msk_scene {
     msk_ctx *ctx = nullptr;
+    // a scene of a group context: one ordinary scene per member, the members' films, staging copies for members without
+    // peer access, and the summed film (msk_multi.h); everything below `ws` is then unused but dev.width / dev.height
+    std::vector<msk_scene *> parts;
+    DevBuf part_films[MSK_MAX_GROUP], staged[MSK_MAX_GROUP], group_film;
     Workspace *ws = nullptr;           // render buffers, kept between calls (hipMalloc/hipFree of GBs costs milliseconds)
     DeviceScene dev;
-    DevBuf nodes, nodes4, nodes8, tris, tri_bounds, tri_verts, tri_frames, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
+    DevBuf nodes, nodes4, nodes4q, nodes8, tris, tris3, tri_bounds, tri_verts, tri_frames, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
     bool lds_scene = false, lds_tables = false, all_diffuse = true;
-    int trace_mode = 0;                // 0 binary tree in LDS, 1 binary tree in HBM/L2, 2 4-wide tree in HBM/L2, 4 8-wide quantised tree in HBM/L2
+    int trace_mode = 0;                // 0 binary tree in LDS, 1 binary tree in HBM/L2, 2 4-wide tree in HBM/L2, 4 8-wide quantised tree in HBM/L2,
+                                       // 5 4-wide tree with quantised boxes in HBM/L2 (64-byte nodes; the default for trees in HBM)
     size_t trace_lds_bytes = 0, shade_lds_bytes = 0;
     int bvh_depth = 0;
     uint32_t n_tris = 0;
     size_t tree_bytes = 0;             // node array the traversal walks
 };
+
+#include "msk_multi.h"
 
 #ifdef MSK_COUNT
 // instrumented builds only: reads and clears the traversal counters of msk_kernels.h
@@ -110,8 +121,9 @@ extern "C" const char *msk_gpu_last_error(const msk_ctx *ctx) {
 extern "C" int msk_gpu_init(const int *device_ids, int n, msk_ctx **out_ctx) {
     if (!out_ctx) return fail(nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_init: out_ctx is NULL");
     *out_ctx = nullptr;
-    if (n != 1 || !device_ids)
-        return fail(nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_init: exactly one device per context (got n=%d)", n);
+    if (n < 1 || !device_ids)
+        return fail(nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_init: at least one device per context (got n=%d)", n);
+    if (n > 1) return group_init(device_ids, n, out_ctx);          // msk_multi.h: one member context per entry
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
         return fail(nullptr, MSK_ERR_NO_DEVICE, "msk_gpu_init: no HIP device visible");
@@ -142,6 +154,7 @@ extern "C" int msk_gpu_init(const int *device_ids, int n, msk_ctx **out_ctx) {
 
 extern "C" void msk_gpu_shutdown(msk_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->group) { group_shutdown(ctx); return; }
     (void) hipSetDevice(ctx->device);
     for (auto ev : ctx->events) (void) hipEventDestroy(ev);
     for (int k = 0; k < MSK_MAX_STREAMS - 1; ++k) {
@@ -155,6 +168,14 @@ extern "C" void msk_gpu_shutdown(msk_ctx *ctx) {
 
 extern "C" int msk_gpu_describe(const msk_ctx *ctx, char *buf, uint64_t buf_size) {
     if (!ctx || !buf || !buf_size) return fail(nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_describe: bad argument");
+    if (ctx->group) {
+        char one[512];
+        msk_gpu_describe(ctx->group->ctxs[0], one, sizeof one);
+        std::string ids;
+        for (msk_ctx *c : ctx->group->ctxs) ids += (ids.empty() ? "" : ",") + std::to_string(c->device);
+        snprintf(buf, (size_t) buf_size, "%zu devices [%s], sample-sharded, film summed on device %d; each: %s", ctx->group->ctxs.size(), ids.c_str(), ctx->device, one);
+        return MSK_OK;
+    }
     snprintf(buf, (size_t) buf_size, "%s (%s), %d CUs, %.1f GiB HBM, LDS/block %zu KiB; libmsk_gpu ABI %d, fp-contract off",
              ctx->prop.name, ctx->prop.gcnArchName, ctx->prop.multiProcessorCount,
              ctx->prop.totalGlobalMem / 1073741824.0, ctx->prop.sharedMemPerBlock / 1024, MSK_ABI_VERSION);
@@ -169,6 +190,7 @@ static inline float h_dot(const float *a, const float *b) { return a[0] * b[0] +
 extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_scene **out) {
     if (!ctx || !d || !out) return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: NULL argument");
     *out = nullptr;
+    if (ctx->group) return group_scene_create(ctx, d, out);
     if (d->abi_version != MSK_ABI_VERSION)
         return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: abi_version %u != %u", d->abi_version, MSK_ABI_VERSION);
     if (d->film.width <= 0 || d->film.height <= 0 || !(d->film.filter_radius > 0.f))
@@ -441,6 +463,22 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         ds.stack_entries = (uint32_t) ((3 * bvh.max_depth4 + 2 + 3) & ~3);     // up to three pushes per level
         s->trace_mode = 2;
         s->tree_bytes = bvh.nodes4.size() * 4;
+        // the walked form: 64-byte nodes with quantised child boxes (MSK_QUANT_BVH=0: the full-precision 128-byte ones) and
+        // three-load triangle records, packed on the device from `tris`
+        if (env_u32("MSK_QUANT_BVH", 1) && !bvh.nodes4q.empty()) {
+            hipError_t eq = s->nodes4q.upload(bvh.nodes4q);
+            if (eq != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(eq)); }
+            ds.nodes4q = s->nodes4q.as<float4>();
+            s->trace_mode = 5;
+            s->tree_bytes = bvh.nodes4q.size() * 4;
+        }
+        {
+            hipError_t et = s->tris3.alloc(std::max<size_t>((size_t) d->n_faces * 48, 16));
+            if (et != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(et)); }
+            ds.tris3 = s->tris3.as<float4>();
+            if (d->n_faces) hipLaunchKernelGGL(k_pack_tris3, dim3((d->n_faces + MSK_BLOCK - 1) / MSK_BLOCK), dim3(MSK_BLOCK), 0, ctx->stream,
+                                               s->tris.as<float4>(), d->n_faces, s->tris3.as<float4>());
+        }
     } else if (s->lds_scene && env_u32("MSK_WIDE_LDS", 0) && !(bvh.root_ref & MSK_LEAF_BIT)) {
         // experiment knob, off by default: the 4-wide tree staged in LDS (half the dependent LDS round trips per ray).
         // Measured on cbox: trace 12.45 vs 12.34 ms for the binary tree — no gain.
@@ -453,11 +491,11 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         s->trace_mode = 3;
     }
     ds.stack_total = ds.stack_entries;
-    if (s->trace_mode == 1 || s->trace_mode == 2 || s->trace_mode == 4) {
+    if (s->trace_mode == 1 || s->trace_mode == 2 || s->trace_mode == 4 || s->trace_mode == 5) {
         // trees in HBM: only the first MSK_STACK_CAP entries of a lane's stack live in LDS, the rest in an HBM overflow
-        // array (LaneStack) — any tree depth works within a fixed 24 KB of LDS per block.  (Measured: the cap does not
-        // change the trace time between 8 and 40 entries; the traversal needs >= 4 waves per SIMD and has them.)
-        ds.stack_entries = std::min(ds.stack_total, std::max(4u, env_u32("MSK_STACK_CAP", 24) & ~3u));
+        // array (LaneStack) — any tree depth works within a fixed 16 KB (+ 4 KB of node4_step scratch) of LDS per block, which
+        // leaves room for six blocks per CU.  (Measured: the cap does not change the trace time between 8 and 40 entries.)
+        ds.stack_entries = std::min(ds.stack_total, std::max(4u, env_u32("MSK_STACK_CAP", 16) & ~3u));
         s->trace_lds_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4 + (size_t) MSK_BLOCK * 16;       // + four words per lane (node4_step)
     }
     // LDS plan of k_shade_gen: the small lookup tables (tri_verts, mesh/bsdf/emitter records, cdf, d65, cie)
@@ -489,6 +527,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
 void free_workspace(msk_scene *scene);
 extern "C" void msk_gpu_scene_destroy(msk_scene *scene) {
     if (!scene) return;
+    if (scene->ctx->group) { group_scene_destroy(scene); return; }
     (void) hipSetDevice(scene->ctx->device);
     free_workspace(scene);
     delete scene;
@@ -604,6 +643,7 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
         if (sc->trace_mode == 4) hipExtLaunchKernelGGL(k_trace_r<4>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         else if (sc->trace_mode == 0) hipExtLaunchKernelGGL(k_trace_r<0>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         else if (sc->trace_mode == 1) hipExtLaunchKernelGGL(k_trace_r<1>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
+        else if (sc->trace_mode == 5) hipExtLaunchKernelGGL(k_trace_r<5>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         else hipExtLaunchKernelGGL(k_trace_r<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         return;
     }
@@ -624,6 +664,7 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
     else if (sc->trace_mode == 1) hipExtLaunchKernelGGL(k_trace<1>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
     else if (sc->trace_mode == 2) hipExtLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
     else if (sc->trace_mode == 4) hipExtLaunchKernelGGL(k_trace<4>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
+    else if (sc->trace_mode == 5) hipExtLaunchKernelGGL(k_trace<5>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
     else hipExtLaunchKernelGGL(k_trace<3>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
 }
 
@@ -862,7 +903,7 @@ static uint32_t owned_spp(const msk_render_params *p) {
 // wants many waves per launch).  Long rays (k_trace_r): 4096 regions of 2048 slots = 8 M, so that lane replacement has a long
 // list of rays to keep the lanes busy with.
 static void pool_shape(const msk_scene *sc, uint64_t total_samples, uint32_t *region_size, uint32_t *n_regions) {
-    const bool big = sc->trace_mode == 1 || sc->trace_mode == 2 || sc->trace_mode == 4;
+    const bool big = sc->trace_mode == 1 || sc->trace_mode == 2 || sc->trace_mode == 4 || sc->trace_mode == 5;
     // trees in HBM: one traversal wave per region at 5 waves per SIMD = 5120 resident waves; with 4096 regions the four loops'
     // launches never filled the GPU (8192 regions: config-5-class render 173 vs 191 ms, config-3-class 205 vs 227 ms)
     // LDS-resident scenes: 6144 x 1024 (with the state's cache policy in place — msk_kernels.h, MSK_NT — fewer, longer regions
@@ -1076,11 +1117,13 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
 extern "C" int msk_gpu_render_device(msk_scene *scene, const msk_render_params *params, float *d_film_xyzaw, void *hip_stream,
                                      msk_stats *stats) {
     if (!scene || !d_film_xyzaw) return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_render_device: NULL argument");
+    if (scene->ctx->group) return group_render_device(scene, params, d_film_xyzaw, (hipStream_t) hip_stream, stats);
     return render_impl(scene, params, d_film_xyzaw, (hipStream_t) hip_stream, stats);
 }
 
 extern "C" int msk_gpu_render(msk_scene *scene, const msk_render_params *params, float *film_xyzaw, msk_stats *stats) {
     if (!scene || !film_xyzaw) return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_render: NULL argument");
+    if (scene->ctx->group) return group_render(scene, params, film_xyzaw, stats);
     msk_ctx *ctx = scene->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!scene->ws) scene->ws = new Workspace();
@@ -1107,6 +1150,7 @@ extern "C" int msk_gpu_render_aov(msk_scene *scene, const msk_render_params *par
                                   float *film, msk_stats *stats) {
     if (!scene || !film || !params || (n_aovs && !aov_types))
         return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_render_aov: NULL argument");
+    if (scene->ctx->group) return group_render_aov(scene, params, aov_types, n_aovs, film, stats);
     msk_ctx *ctx = scene->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     AovPlan plan;
@@ -1151,6 +1195,10 @@ extern "C" int msk_gpu_render_aov(msk_scene *scene, const msk_render_params *par
 extern "C" int msk_gpu_sample_pixels(msk_scene *scene, const msk_render_params *prm, uint64_t n_pixels, const int32_t *pixels,
                                      float *out_xyz, float *out_pos) {
     if (!scene || !pixels || !out_xyz) return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_sample_pixels: NULL argument");
+    if (scene->ctx->group) {             // sub-stage entry points of a group run on its first member
+        const int rc = msk_gpu_sample_pixels(scene->parts[0], prm, n_pixels, pixels, out_xyz, out_pos);
+        return rc ? group_fail(scene->ctx, 0, rc) : MSK_OK;
+    }
     msk_ctx *ctx = scene->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = check_params(ctx, prm, 1);
@@ -1226,6 +1274,9 @@ static int trace_batch(msk_scene *scene, uint64_t n, const float *rays, float *o
     else if (scene->trace_mode == 4)
         hipLaunchKernelGGL(k_trace_batch<4>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
                            d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
+    else if (scene->trace_mode == 5)
+        hipLaunchKernelGGL(k_trace_batch<5>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
+                           d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
     else
         hipLaunchKernelGGL(k_trace_batch<3>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
                            d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
@@ -1237,9 +1288,11 @@ static int trace_batch(msk_scene *scene, uint64_t n, const float *rays, float *o
 
 extern "C" int msk_gpu_trace_closest(msk_scene *scene, uint64_t n, const float *rays, float *out_hit) {
     if (!scene || (n && (!rays || !out_hit))) return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_trace_closest: NULL argument");
+    if (scene->ctx->group) { const int rc = trace_batch(scene->parts[0], n, rays, out_hit, nullptr); return rc ? group_fail(scene->ctx, 0, rc) : MSK_OK; }
     return trace_batch(scene, n, rays, out_hit, nullptr);
 }
 extern "C" int msk_gpu_trace_any(msk_scene *scene, uint64_t n, const float *rays, uint8_t *out_occluded) {
     if (!scene || (n && (!rays || !out_occluded))) return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_trace_any: NULL argument");
+    if (scene->ctx->group) { const int rc = trace_batch(scene->parts[0], n, rays, nullptr, out_occluded); return rc ? group_fail(scene->ctx, 0, rc) : MSK_OK; }
     return trace_batch(scene, n, rays, nullptr, out_occluded);
 }

@@ -46,6 +46,10 @@ struct DeviceScene {
     const float4 *nodes;        // 4 x float4 per node (msk_bvh.h)
     const float4 *nodes4;       // 8 x float4 per 4-wide node, or nullptr (scenes whose BVH is staged in LDS use `nodes`)
     uint32_t root_ref4, n_nodes4;
+    const float4 *nodes4q;      // 4 x float4 per 4-wide node with quantised child boxes (msk_bvh.h: Built::nodes4q; same numbering as
+                                // nodes4), or nullptr: what the traversal of a tree in HBM/L2 reads
+    const float4 *tris3;        // 3 x float4 per triangle, leaf order: [v0 | prim] [e1 | e2.x] [e2.y e2.z - -] — `tris` without the
+                                // normal (recomputed per test: e2 x e1, the builder's operations): three loads per test instead of four
     const float4 *nodes8;       // 8 x float4 per 8-wide node with quantised child boxes (msk_bvh.h: collapse8), or nullptr
     uint32_t root_ref8, n_nodes8;
     const float4 *tris;         // 4 x float4 per triangle, leaf order (msk_bvh.h)
@@ -385,6 +389,12 @@ MSK_DEV uint32_t node4_step(__amdgpu_buffer_rsrc_t rsrc, uint32_t node, const Se
         key[I] = ((__float_as_uint(t0) & 0x7ffffff0u) | (uint32_t) ((I) << 2)) | miss; }
     MSK_CHILD(0, x) MSK_CHILD(1, y) MSK_CHILD(2, z) MSK_CHILD(3, w)
 #undef MSK_CHILD
+#ifdef MSK_EXP_LOAD     /* experiment: MSK_EXP_LOAD more 16-byte loads per visit (the node's zero padding) — is the texture addresser the bound? */
+    { const msk_u4 ex_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 112u, 0, 0); key[0] |= ex_.x; }
+#endif
+#ifdef MSK_EXP_VALU     /* experiment: MSK_EXP_VALU more dependent fast VALU instructions per visit — is VALU issue the bound? */
+    { float z_ = tmin; for (int e_ = 0; e_ < MSK_EXP_VALU; ++e_) z_ = __fmaf_rn(z_, idir.x, oi.x); key[0] |= z_ == 12345.678f ? 16u : 0u; }
+#endif
 #define MSK_CSWAPU(a, b) { const uint32_t lo_ = a < b ? a : b; b = a < b ? b : a; a = lo_; }
     MSK_CSWAPU(key[0], key[1]) MSK_CSWAPU(key[2], key[3]) MSK_CSWAPU(key[0], key[2]) MSK_CSWAPU(key[1], key[3]) MSK_CSWAPU(key[1], key[2])
 #undef MSK_CSWAPU
@@ -401,12 +411,82 @@ MSK_DEV uint32_t node4_step(__amdgpu_buffer_rsrc_t rsrc, uint32_t node, const Se
     return *(const uint32_t *) (sc4 + (key[0] & 12u));
 }
 
+
+// The visit above over the QUANTISED twin of the node (Built::nodes4q, 64 bytes): four 16-byte loads instead of seven.  The
+// traversal of a tree in HBM/L2 is bound by the texture addresser — about one cycle per lane and load instruction whatever its
+// width (measured: one more 16-byte load of the node's own line per visit +7 % trace time, 32 more dependent VALU instructions
+// +1.4 %) — so bytes per visit are what counts, and the VALU has room for the decoding: t = q * (scale * idir) + (origin * idir -
+// o * idir) for the plane byte q (v_cvt_f32_ubyte, v_fma).  Near / far plane words are picked by the ray's sign masks (v_bfi).
+// The decoded boxes contain the padded full-precision ones (checked when they are built), so this, too, only culls.
+struct Sel4q { uint32_t mx, my, mz; };          // all ones where the reciprocal direction is negative (near plane = hi)
+MSK_DEV Sel4q make_sel4q(f3 idir) {
+    Sel4q s;
+    s.mx = idir.x < 0.f ? 0xffffffffu : 0u; s.my = idir.y < 0.f ? 0xffffffffu : 0u; s.mz = idir.z < 0.f ? 0xffffffffu : 0u;
+    return s;
+}
+MSK_DEV __amdgpu_buffer_rsrc_t nodes4q_rsrc(const DeviceScene &sc) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *) sc.nodes4q, 0, sc.n_nodes4 * 64u, 0x00020000);
+}
+template <bool OVF>
+MSK_DEV uint32_t node4q_step(__amdgpu_buffer_rsrc_t rsrc, uint32_t node, const Sel4q &sel, f3 idir, f3 oi, float tmin, float tcur,
+                             const LaneStack<OVF> &stack, int &sp) {
+    const uint32_t base = node << 6;
+    const msk_u4 h0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base, 0, 0), h1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 16u, 0, 0);
+    const msk_u4 h2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 32u, 0, 0), rf = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 48u, 0, 0);
+    *(msk_u4 *) stack.scratch = rf;
+    // h0 = origin.xyz, scale.x   h1 = scale.y, scale.z, lo.x[4], lo.y[4]   h2 = lo.z[4], hi.x[4], hi.y[4], hi.z[4]
+    const float ax = __uint_as_float(h0.w) * idir.x, ay = __uint_as_float(h1.x) * idir.y, az = __uint_as_float(h1.y) * idir.z;
+    const float bx = __fmaf_rn(__uint_as_float(h0.x), idir.x, -oi.x), by = __fmaf_rn(__uint_as_float(h0.y), idir.y, -oi.y),
+                bz = __fmaf_rn(__uint_as_float(h0.z), idir.z, -oi.z);
+    const uint32_t nx = (h2.y & sel.mx) | (h1.z & ~sel.mx), fx = (h1.z & sel.mx) | (h2.y & ~sel.mx);
+    const uint32_t ny = (h2.z & sel.my) | (h1.w & ~sel.my), fy = (h1.w & sel.my) | (h2.z & ~sel.my);
+    const uint32_t nz = (h2.w & sel.mz) | (h2.x & ~sel.mz), fz = (h2.x & sel.mz) | (h2.w & ~sel.mz);
+    uint32_t key[4];
+#define MSK_QB(w, k) ((float) (((w) >> (8 * (k))) & 0xffu))
+#define MSK_CHILD(I) {                                                                                                            \
+        const float t0 = fmaxf(fmaxf(fmaxf(__fmaf_rn(MSK_QB(nx, I), ax, bx), __fmaf_rn(MSK_QB(ny, I), ay, by)), __fmaf_rn(MSK_QB(nz, I), az, bz)), tmin); \
+        const float t1 = fminf(fminf(fminf(__fmaf_rn(MSK_QB(fx, I), ax, bx), __fmaf_rn(MSK_QB(fy, I), ay, by)), __fmaf_rn(MSK_QB(fz, I), az, bz)), tcur); \
+        const uint32_t miss = (uint32_t) ((int32_t) __float_as_uint(t1 * 1.0000004f - t0) >> 31);                               \
+        key[I] = ((__float_as_uint(t0) & 0x7ffffff0u) | (uint32_t) ((I) << 2)) | miss; }
+    MSK_CHILD(0) MSK_CHILD(1) MSK_CHILD(2) MSK_CHILD(3)
+#undef MSK_CHILD
+#undef MSK_QB
+#define MSK_CSWAPU(a, b) { const uint32_t lo_ = a < b ? a : b; b = a < b ? b : a; a = lo_; }
+    MSK_CSWAPU(key[0], key[1]) MSK_CSWAPU(key[2], key[3]) MSK_CSWAPU(key[0], key[2]) MSK_CSWAPU(key[1], key[3]) MSK_CSWAPU(key[1], key[2])
+#undef MSK_CSWAPU
+    const uint32_t NONE = 0xffffffffu;
+    const char *sc4 = (const char *) stack.scratch;
+    if (key[0] == NONE) return sp > 0 ? stack.pop(sp) : NONE;
+    if (key[1] != NONE) {
+        if (key[2] != NONE) {
+            if (key[3] != NONE) stack.push(sp, *(const uint32_t *) (sc4 + (key[3] & 12u)));
+            stack.push(sp, *(const uint32_t *) (sc4 + (key[2] & 12u)));
+        }
+        stack.push(sp, *(const uint32_t *) (sc4 + (key[1] & 12u)));
+    }
+    return *(const uint32_t *) (sc4 + (key[0] & 12u));
+}
+
+// a triangle of a tree in HBM/L2: three loads (DeviceScene::tris3), the normal recomputed with the builder's operations
+MSK_DEV __amdgpu_buffer_rsrc_t tris3_rsrc(const DeviceScene &sc) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *) sc.tris3, 0, sc.n_tris * 48u, 0x00020000);
+}
+MSK_DEV void load_tri3(__amdgpu_buffer_rsrc_t rsrc, uint32_t k, float4 &q0, float4 &q1, float4 &q2, float4 &q3) {
+    const uint32_t off = k * 48u;
+    const msk_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16u, 0, 0),
+                 c = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32u, 0, 0);
+    q0 = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+    q1 = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), 0.f);
+    q2 = make_float4(__uint_as_float(b.w), __uint_as_float(c.x), __uint_as_float(c.y), 0.f);
+    q3 = make_float4(q2.y * q1.z - q2.z * q1.y, q2.z * q1.x - q2.x * q1.z, q2.x * q1.y - q2.y * q1.x, 0.f);     // Ng = e2 x e1 (msk_bvh.h: build)
+}
+
 // The same traversal over the 4-wide nodes of msk_bvh.h (one 128-byte line per visit, half the dependent round trips
 // of the binary tree); used when the tree lives in HBM/L2.  Hit selection is by (t, prim), so the result is the binary
 // tree's, bit for bit.
 #define MSK_EMPTY4 0xfffffffeu
 template <bool ANY, bool OVF>
-MSK_DEV bool traverse4(__amdgpu_buffer_rsrc_t rsrc, const float4 *__restrict__ nodes, const float4 *__restrict__ tris, float tri_pad, uint32_t root_ref,
+MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restrict__ tris, float tri_pad, uint32_t root_ref,
                        uint32_t n_tris, f3 o, f3 d, float tmin, float tmax, const LaneStack<OVF> &stack, float *best_t, float *best_u,
                        float *best_v, uint32_t *best_prim) {
     float bt = tmax, bu = 0.f, bv = 0.f;
@@ -418,14 +498,8 @@ MSK_DEV bool traverse4(__amdgpu_buffer_rsrc_t rsrc, const float4 *__restrict__ n
     int sp = 0;
     uint32_t cur = root_ref;
     const uint32_t DONE = 0xffffffffu;
-    const Sel4 sel = make_sel4(idir);
     while (cur != DONE) {
         while (!(cur & MSK_LEAF_BIT)) {
-            if constexpr (OVF) {                     // tree in HBM/L2: the cheap visit (node4_step); rsrc covers `nodes`
-                cur = node4_step<OVF>(rsrc, cur, sel, idir, oi, tmin, bt, stack, sp);
-                if (cur == DONE) break;
-                continue;
-            }
             const float4 *n = nodes + (size_t) cur * 8;
             const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], rf = n[6];
             float t0, t1, t2, t3;
@@ -457,6 +531,45 @@ MSK_DEV bool traverse4(__amdgpu_buffer_rsrc_t rsrc, const float4 *__restrict__ n
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             float t, u, v;
             if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v, OVF ? nullptr : q + 4, tri_pad)) {
+                if (ANY) return true;
+                const uint32_t prim = __float_as_uint(q0.w);
+                if (bp == MSK_NO_PRIM || t < bt || (t == bt && (prim & MSK_PRIM_ID) < (bp & MSK_PRIM_ID))) { bt = t; bu = u; bv = v; bp = prim; }
+            }
+        }
+        if (sp > 0) { cur = stack.pop(sp); } else cur = DONE;
+    }
+    *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
+    return false;
+}
+
+// The 4-wide tree in HBM/L2 (trace modes 2 and 5): node4_step / node4q_step visits, three-load triangles.
+template <bool ANY, bool QUANT>
+MSK_DEV bool traverse4h(const DeviceScene &sc, f3 o, f3 d, float tmin, float tmax, const LaneStack<true> &stack, float *best_t, float *best_u,
+                        float *best_v, uint32_t *best_prim) {
+    float bt = tmax, bu = 0.f, bv = 0.f;
+    uint32_t bp = MSK_NO_PRIM;
+    *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
+    if (sc.n_tris == 0) return false;
+    const f3 idir = slab_idir(d);
+    const f3 oi = mk3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
+    const __amdgpu_buffer_rsrc_t rn = QUANT ? nodes4q_rsrc(sc) : nodes4_rsrc(sc), rt = tris3_rsrc(sc);
+    const Sel4 sel = make_sel4(idir);
+    const Sel4q selq = make_sel4q(idir);
+    int sp = 0;
+    uint32_t cur = sc.root_ref4;
+    const uint32_t DONE = 0xffffffffu;
+    while (cur != DONE) {
+        while (!(cur & MSK_LEAF_BIT)) {
+            if constexpr (QUANT) cur = node4q_step<true>(rn, cur, selq, idir, oi, tmin, bt, stack, sp);
+            else cur = node4_step<true>(rn, cur, sel, idir, oi, tmin, bt, stack, sp);
+        }
+        if (cur == DONE) break;
+        const uint32_t first = (cur & 0x7fffffffu) >> 5, cnt = cur & 31u;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            float4 q0, q1, q2, q3;
+            load_tri3(rt, first + i, q0, q1, q2, q3);
+            float t, u, v;
+            if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v, nullptr, sc.tri_pad)) {
                 if (ANY) return true;
                 const uint32_t prim = __float_as_uint(q0.w);
                 if (bp == MSK_NO_PRIM || t < bt || (t == bt && (prim & MSK_PRIM_ID) < (bp & MSK_PRIM_ID))) { bt = t; bu = u; bv = v; bp = prim; }
@@ -596,14 +709,15 @@ MSK_DEV float slot_tmax(float rd_w) {
 #define MSK_HIT_UNOCCLUDED 0x80000000u
 #define MSK_PRIM_MASK 0x7fffffffu
 // MODE 0: binary tree staged in LDS; 1: binary tree in HBM/L2; 2: 4-wide tree in HBM/L2; 3: 4-wide tree staged in LDS;
-// 4: 8-wide tree with quantised boxes in HBM/L2
-#define MSK_OVF(MODE) ((MODE) == 1 || (MODE) == 2 || (MODE) == 4)      /* the stack can overflow to HBM only when the tree lives there */
+// 4: 8-wide tree with quantised boxes in HBM/L2; 5: 4-wide tree with quantised boxes in HBM/L2 (64-byte nodes: the default)
+#define MSK_OVF(MODE) ((MODE) == 1 || (MODE) == 2 || (MODE) == 4 || (MODE) == 5)      /* the stack can overflow to HBM only when the tree lives there */
 template <int MODE, bool ANY>
 MSK_DEV bool traverse_scene(const DeviceScene &sc, const TraceLds &g, f3 o, f3 d, float tmin, float tmax, const LaneStack<MSK_OVF(MODE)> &stack,
                             float *bt, float *bu, float *bv, uint32_t *bp) {
-    if constexpr (MODE == 4) return traverse8<ANY, true>(sc.nodes8, g.tris, sc.tri_pad, sc.root_ref8, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
-    else if (MODE == 2 || MODE == 3) return traverse4<ANY, MSK_OVF(MODE)>(nodes4_rsrc(sc), MODE == 3 ? g.nodes : sc.nodes4, g.tris, sc.tri_pad, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
-    return traverse<ANY, MSK_OVF(MODE)>(g.nodes, g.tris, sc.tri_pad, sc.root_ref, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+    if constexpr (MODE == 2 || MODE == 5) return traverse4h<ANY, MODE == 5>(sc, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+    else if constexpr (MODE == 4) return traverse8<ANY, true>(sc.nodes8, g.tris, sc.tri_pad, sc.root_ref8, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+    else if constexpr (MODE == 3) return traverse4<ANY, false>(g.nodes, g.tris, sc.tri_pad, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+    else return traverse<ANY, MSK_OVF(MODE)>(g.nodes, g.tris, sc.tri_pad, sc.root_ref, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
 }
 
 template <int MODE>
@@ -783,7 +897,8 @@ MSK_DEV bool first_active_lane() {
 #define MSK_CNT_WAVE(i) do {} while (0)
 #endif
 struct TravState {
-    Sel4 sel;
+    Sel4 sel;           // trace mode 2
+    Sel4q selq;         // trace mode 5 (the unused one of the two is dead code in either instantiation)
     f3 o, d, idir, oi;
     float tmin, tmax, bt, bu, bv;
     uint32_t bp, cur;
@@ -792,7 +907,7 @@ struct TravState {
 MSK_DEV void trav_begin(TravState &t, uint32_t root_ref, uint32_t n_tris, f3 o, f3 d, float tmin, float tmax) {
     t.o = o; t.d = d; t.tmin = tmin; t.tmax = tmax;
     t.idir = slab_idir(d);
-    t.sel = make_sel4(t.idir);
+    t.sel = make_sel4(t.idir); t.selq = make_sel4q(t.idir);
     t.oi = mk3(o.x * t.idir.x, o.y * t.idir.y, o.z * t.idir.z);
     t.bt = tmax; t.bu = 0.f; t.bv = 0.f; t.bp = MSK_NO_PRIM; t.sp = 0;
     t.cur = n_tris ? root_ref : 0xffffffffu;
@@ -806,8 +921,10 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
     const uint32_t DONE = 0xffffffffu;
     int steps = 0;
     bool found = false;
-    __amdgpu_buffer_rsrc_t rsrc4;
+    __amdgpu_buffer_rsrc_t rsrc4, rsrc_t3;
     if constexpr (MODE == 2) rsrc4 = nodes4_rsrc(sc);
+    if constexpr (MODE == 5) rsrc4 = nodes4q_rsrc(sc);
+    if constexpr (MODE == 2 || MODE == 5) rsrc_t3 = tris3_rsrc(sc);
     while (!(t.cur & MSK_LEAF_BIT) && steps < max_inner) {
         ++steps;
         MSK_CNT_WAVE(3); MSK_CNT(4, 1);
@@ -816,6 +933,8 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
             if (t.cur == MSK_NONE_REF && t.sp > 0) t.cur = stack.pop(t.sp);
         } else if constexpr (MODE == 2) {
             t.cur = node4_step<true>(rsrc4, t.cur, t.sel, t.idir, t.oi, t.tmin, t.bt, stack, t.sp);
+        } else if constexpr (MODE == 5) {
+            t.cur = node4q_step<true>(rsrc4, t.cur, t.selq, t.idir, t.oi, t.tmin, t.bt, stack, t.sp);
         } else {
             const float4 *n = g.nodes + (size_t) t.cur * 4;
             const float4 a = n[0], b = n[1], c = n[2], m = n[3];
@@ -839,7 +958,9 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
         for (uint32_t i = 0; i < cnt; ++i) {
             MSK_CNT_WAVE(5); MSK_CNT(6, 1);
             const float4 *q = g.tris + (size_t) (first + i) * (MSK_OVF(MODE) ? 4 : 6);
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            float4 q0, q1, q2, q3;
+            if constexpr (MODE == 2 || MODE == 5) load_tri3(rsrc_t3, first + i, q0, q1, q2, q3);
+            else { q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; }
             float tt, u, v;
             if (tri_test(q0, q1, q2, q3, t.o, t.d, t.tmin, t.tmax, &tt, &u, &v, MSK_OVF(MODE) ? nullptr : q + 4, sc.tri_pad)) {
                 if (any) { found = true; break; }
@@ -852,8 +973,15 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
     return found;
 }
 
+// Six waves per SIMD (80 VGPRs, no scratch in the default instantiation <5>; the unconstrained build takes 90 = five waves).
+// Alone the kernel gains nothing from the sixth wave (65.3 vs 66.2 ms on the config-5-class scene), beside the shading kernel's
+// 168-VGPR waves in the four-loop mode the smaller footprint is worth 7 % of the render (77.7 vs 84.0 ms); seven waves (72 VGPRs,
+// 44 bytes of scratch) are slower in both (71.6 / 88.4 ms).
+#ifndef MSK_TRACE_R_WAVES
+#define MSK_TRACE_R_WAVES 6, 6
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(MSK_BLOCK)
+__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_TRACE_R_WAVES)))
 k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner) {
     constexpr bool LDS_SCENE = MODE == 0 || MODE == 3;
     extern __shared__ float4 lds_dyn[];
@@ -889,9 +1017,9 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
                     unocc = 0; active = true;
                     if (shadow_phase) {
                         const float4 s = st.sh[slot];
-                        trav_begin(t, MODE == 4 ? sc.root_ref8 : MODE == 2 ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(s.x, s.y, s.z), ro.w, s.w);
+                        trav_begin(t, MODE == 4 ? sc.root_ref8 : (MODE == 2 || MODE == 5) ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(s.x, s.y, s.z), ro.w, s.w);
                     } else {
-                        trav_begin(t, MODE == 4 ? sc.root_ref8 : MODE == 2 ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+                        trav_begin(t, MODE == 4 ? sc.root_ref8 : (MODE == 2 || MODE == 5) ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
                     }
                 }
             }
@@ -907,7 +1035,7 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
                 if (shadow_phase) {
                     unocc = occ ? 0u : MSK_HIT_UNOCCLUDED;
                     shadow_phase = false;
-                    trav_begin(t, MODE == 4 ? sc.root_ref8 : MODE == 2 ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+                    trav_begin(t, MODE == 4 ? sc.root_ref8 : (MODE == 2 || MODE == 5) ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
                 } else {
                     const bool valid = (t.bp != MSK_NO_PRIM) && (t.bt != rd.w);
                     st.hit[slot] = make_float4(valid ? t.bt : MSK_INF_F, t.bu, t.bv, __uint_as_float((valid ? t.bp : MSK_PRIM_MASK) | unocc));
@@ -916,6 +1044,14 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
             }
         }
     }
+}
+
+// tris (4 x float4: v0|prim, e1, e2, Ng) -> tris3 (3 x float4: v0|prim, e1|e2.x, e2.y e2.z - -), at scene creation
+__global__ void __launch_bounds__(MSK_BLOCK) k_pack_tris3(const float4 *tris, uint32_t n, float4 *out) {
+    const uint32_t k = blockIdx.x * MSK_BLOCK + threadIdx.x;
+    if (k >= n) return;
+    const float4 a = tris[(size_t) k * 4], e1 = tris[(size_t) k * 4 + 1], e2 = tris[(size_t) k * 4 + 2];
+    out[(size_t) k * 3] = a; out[(size_t) k * 3 + 1] = make_float4(e1.x, e1.y, e1.z, e2.x); out[(size_t) k * 3 + 2] = make_float4(e2.y, e2.z, 0.f, 0.f);
 }
 
 // batch entry points for the sub-stage parity tests (msk_gpu_trace_closest / _any)

@@ -813,12 +813,28 @@ void flatten_scene(const Scene *scene, const Sensor *sensor, FlatScene &out) {
     d.n_textures = (uint32_t) out.textures.size(); d.textures = out.textures.data();
 }
 
+// "0,1,2" -> {0,1,2}; empty -> {single}
+static std::vector<int> parse_gpu_devices(const std::string &list, int single) {
+    std::vector<int> ids;
+    for (auto &tok : string::tokenize(list, ", ")) {
+        char *end = nullptr;
+        const long v = std::strtol(tok.c_str(), &end, 10);
+        if (end == tok.c_str() || *end || v < 0) Throw("\"gpu_devices\": \"{}\" is not a list of device ordinals", list);
+        ids.push_back((int) v);
+    }
+    if (ids.empty()) ids.push_back(single);
+    return ids;
+}
+
 // =========================================================================== the "path" integrator
 // integrators/path.cpp:19-21,133-140 — same plugin name and properties; render() runs on the MI355X.
 class PathTracer final : public MonteCarloIntegrator {
 public:
     PathTracer(const Properties &props) : MonteCarloIntegrator(props) {
         m_device = props.int_("gpu_device", 0);
+        // gpu_devices="0,1,2": several GPUs behind this one integrator — the C ABI renders the samples sharded
+        // over them and sums the films on the first (msk_gpu_init with n > 1); overrides gpu_device
+        m_devices = parse_gpu_devices(props.string("gpu_devices", ""), m_device);
         // The reference's PathTracer shadows max_depth / rr_depth / hide_emitters with private members
         // fixed at -1 / 5 / false (path.cpp:135-136); `honor_properties` opts into the values
         // the XML specifies instead.
@@ -847,7 +863,7 @@ public:
         FlatScene flat;
         flatten_scene(scene, sensor, flat);
         fill_params(sensor, flat.params);
-        if (!m_ctx && msk_gpu_init(&m_device, 1, &m_ctx) != MSK_OK) Throw("{}", msk_gpu_last_error(nullptr));
+        if (!m_ctx && msk_gpu_init(m_devices.data(), (int) m_devices.size(), &m_ctx) != MSK_OK) Throw("{}", msk_gpu_last_error(nullptr));
         msk_scene *gs = nullptr;
         if (msk_gpu_scene_create(m_ctx, &flat.desc, &gs) != MSK_OK) Throw("{}", msk_gpu_last_error(m_ctx));
         ref<ImageBlock> whole = new ImageBlock(size, 5);
@@ -866,6 +882,7 @@ public:
     MSK_DECLARE_CLASS()
 private:
     int m_device = 0;
+    std::vector<int> m_devices;
     bool m_honor = false;
     msk_ctx *m_ctx = nullptr;
     msk_stats m_last_stats{};
@@ -879,6 +896,7 @@ class AOVIntegrator final : public MonteCarloIntegrator {
 public:
     AOVIntegrator(const Properties &props) : MonteCarloIntegrator(props) {
         m_device = props.int_("gpu_device", 0);
+        m_devices = parse_gpu_devices(props.string("gpu_devices", ""), m_device);
         for (const std::string &token : string::tokenize(props.string("aovs", ""))) {
             std::vector<std::string> item = string::tokenize(token, ":");
             if (item.size() != 2 || item[0].empty() || item[1].empty()) {
@@ -932,7 +950,7 @@ public:
         FlatScene flat;
         flatten_scene(scene, sensor, flat);
         fill_params(sensor, flat.params);
-        if (!m_ctx && msk_gpu_init(&m_device, 1, &m_ctx) != MSK_OK) Throw("{}", msk_gpu_last_error(nullptr));
+        if (!m_ctx && msk_gpu_init(m_devices.data(), (int) m_devices.size(), &m_ctx) != MSK_OK) Throw("{}", msk_gpu_last_error(nullptr));
         msk_scene *gs = nullptr;
         if (msk_gpu_scene_create(m_ctx, &flat.desc, &gs) != MSK_OK) Throw("{}", msk_gpu_last_error(m_ctx));
         ref<ImageBlock> whole = new ImageBlock(size, channels.size());
@@ -952,6 +970,7 @@ private:
     std::vector<std::string> m_names;
     ref<PathTracer> m_path;
     int m_device = 0;
+    std::vector<int> m_devices;
     msk_ctx *m_ctx = nullptr;
     msk_stats m_last_stats{};
 };

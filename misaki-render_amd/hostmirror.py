@@ -189,7 +189,7 @@ def write_scene_xml(meshes, directory, width, height, spp, camera=None, integrat
     out = ['<scene>', '    <default name="spp" value="%d"/>' % spp, '    <default name="width" value="%d"/>' % width,
            '    <default name="height" value="%d"/>' % height, '    <integrator type="path">']
     for k, val in (integrator_props or {}).items():
-        tag = "boolean" if isinstance(val, bool) else "integer"
+        tag = "boolean" if isinstance(val, bool) else "string" if isinstance(val, str) else "integer"
         out.append('        <%s name="%s" value="%s"/>' % (tag, k, str(val).lower()))
     out += ['    </integrator>', '    <sensor type="perspective">',
             '        <float name="near_clip" value="%.9g"/>' % camera["near"], '        <float name="far_clip" value="%.9g"/>' % camera["far"],

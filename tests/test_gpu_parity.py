@@ -188,12 +188,15 @@ def test_large_mesh_uses_hbm_bvh(gpu_ctx, abi, hostmirror, oracle, golden_lookup
                                  dict(MSK_TRACE_REFILL="48", MSK_TRACE_QUANTUM="1"), dict(MSK_LDS_SCENE_KB="0", MSK_WIDE_BVH="0"),
                                  dict(MSK_STACK_CAP="4"), dict(MSK_STACK_CAP="4", MSK_TRACE_REFILL="0", MSK_WIDE_BVH="0"),
                                  dict(MSK_WIDE_LDS="1", MSK_TRACE_REFILL="0"),
+                                 dict(MSK_QUANT_BVH="0"), dict(MSK_QUANT_BVH="0", MSK_TRACE_REFILL="0"), dict(MSK_QUANT_BVH="0", MSK_STACK_CAP="4"),
+                                 dict(MSK_BVH_BUILD="gpu", MSK_QUANT_BVH="0"),
                                  dict(MSK_WIDE_BVH="8"), dict(MSK_WIDE_BVH="8", MSK_TRACE_REFILL="0"),
                                  dict(MSK_WIDE_BVH="8", MSK_STACK_CAP="4", MSK_TRACE_QUANTUM="2"),
                                  dict(MSK_BVH_BUILD="gpu"), dict(MSK_BVH_BUILD="gpu", MSK_WIDE_BVH="0", MSK_STACK_CAP="4"),
                                  dict(MSK_BVH_BUILD="gpu", MSK_WIDE_BVH="8"), dict(MSK_BVH_BUILD="gpu", MSK_BVH_LEAF="1", MSK_TRACE_REFILL="0")])
 def test_every_traversal_kernel_gives_the_same_film(gpu_ctx, abi, hostmirror, oracle, golden_lookup, monkeypatch, env):
-    """k_trace<0|1|2|4> (chunk loop) and k_trace_r<0|1|2|4> (lane replacement), binary, 4-wide and 8-wide quantised trees, built
+    """k_trace<0|1|2|4|5> (chunk loop) and k_trace_r<0|1|2|4|5> (lane replacement), binary, 4-wide (64-byte quantised nodes: the
+    default for trees in HBM; MSK_QUANT_BVH=0: the full-precision 128-byte ones) and 8-wide quantised trees, built
     by the host's binned-SAH builder or on the device (MSK_BVH_BUILD=gpu, msk_lbvh.hip): hit selection is by (t, prim), so
     every one of them must reproduce the oracle's film bit for bit."""
     for k, v in env.items():
@@ -330,6 +333,49 @@ def test_error_behaviour(scene256, gpu_ctx, abi, hostmirror, golden_lookup):
         abi.Scene(gpu_ctx, bad)
     with pytest.raises(abi.MskError):
         g.sample_pixels(abi.render_params(spp=1), np.array([[300, 2]], np.int32))
+
+
+def test_two_members_behind_one_context(abi, hostmirror, oracle, golden_lookup):
+    """msk_gpu_init(ids, n = 2) — rehearsed on the one GPU of the box with ids = {0, 0}: two member contexts, each renders the
+    sample indices s = k (mod 2), the films are summed on the first device by k_film_sum.  The union of the shards is the
+    single-context sample set, so statistics are equal and the film differs from the single-context (= oracle) film only by
+    the re-association of two partial sums per pixel."""
+    flat = cbox(hostmirror, golden_lookup, 96, 64)
+    prm = abi.render_params(spp=9, seed=5)                     # odd: the members own 5 and 4 samples per pixel
+    with abi.Context(0) as one:
+        s1 = abi.Scene(one, flat)
+        ref, st1 = s1.render(prm)
+        s1.close()
+    with abi.Context((0, 0)) as grp:
+        assert "2 devices [0,0]" in grp.describe()
+        s2 = abi.Scene(grp, flat)
+        film, st2 = s2.render(prm)
+        film_b, _ = s2.render(prm)
+        # a caller-side shard of the samples composes with the members' split
+        half_a, _ = s2.render(abi.render_params(spp=9, seed=5, sample_first=0, sample_stride=2))
+        half_b, _ = s2.render(abi.render_params(spp=9, seed=5, sample_first=1, sample_stride=2))
+        one_spp, st_one = s2.render(abi.render_params(spp=1, seed=5))          # the second member owns nothing
+        aov, _ = s2.render_aov(prm, [abi.MSK_AOV_DEPTH, abi.MSK_AOV_PATH_RGBA])
+        px = np.array([[3, 4], [50, 60]], np.int32)
+        xyz, _ = s2.sample_pixels(abi.render_params(spp=4, seed=5), px)
+        with pytest.raises(abi.MskError) as e:
+            s2.render(abi.render_params(spp=0))
+        assert "member 0 of 2" in str(e.value)
+        s2.close()
+    assert (st2.samples, st2.segments, st2.shadow_rays) == (st1.samples, st1.segments, st1.shadow_rays)
+    assert np.array_equal(film, film_b)
+    assert np.allclose(film, ref, rtol=2e-6, atol=1e-6) and np.array_equal(film[..., 4].sum(dtype=np.float64) > 0, True)
+    a, b = hostmirror.develop(film)[..., :3], hostmirror.develop(ref)[..., :3]
+    assert np.abs(a - b).max() < 1e-4
+    assert np.allclose(half_a + half_b, ref, rtol=2e-6, atol=1e-6)
+    assert st_one.samples == 96 * 64 and np.isfinite(one_spp).all()
+    assert aov.shape[-1] == 5 + 1 + 4 and np.allclose(aov[..., :3], ref[..., :3], rtol=2e-6, atol=1e-6)
+    o = oracle.scene(flat)
+    xyz_ref, _ = o.sample_pixels(abi.render_params(spp=4, seed=5), px)
+    o.close()
+    assert np.array_equal(xyz.view(np.uint32), xyz_ref.view(np.uint32))
+    with pytest.raises(abi.MskError):
+        abi.Context([0] * 9)
 
 
 def test_scene_lifecycle_releases_device_memory(gpu_ctx, abi, hostmirror, golden_lookup):

@@ -157,6 +157,27 @@ def test_render_through_the_plugin_interface(hostlib, hostmirror, oracle, tmp_pa
     sc.close()
 
 
+@pytest.mark.gpu
+def test_plugin_gpu_devices_property(hostlib, hostmirror, oracle, tmp_path):
+    """<integrator type="path"><string name="gpu_devices" value="0,0"/>: the plugin hands both ordinals to msk_gpu_init, the
+    library shards the samples over two member contexts and sums the films (msk_multi.h) — rehearsed on one GPU."""
+    xml = hostmirror.write_scene_xml(hostmirror.cbox_meshes(), str(tmp_path), 64, 48, 6, integrator_props={"gpu_devices": "0,0"})
+    assert 'name="gpu_devices"' in open(xml).read()
+    sc = hostlib.HostScene(xml)
+    film, rgba, st = sc.render()
+    flat = sc.flatten()
+    ref, rst = oracle.scene(flat).render(flat.params, threads=4)
+    assert st.samples == rst.samples == 64 * 48 * 6 and st.segments == rst.segments
+    assert np.allclose(film, ref, rtol=2e-6, atol=1e-6)
+    assert np.abs(rgba[..., :3] - hostmirror.develop(ref)[..., :3]).max() < 1e-4
+    sc.close()
+    bad = open(xml).read().replace('value="0,0"', 'value="0,x"')
+    (tmp_path / "bad.xml").write_text(bad)
+    with pytest.raises(hostlib.HostError) as e:
+        hostlib.HostScene(str(tmp_path / "bad.xml"))
+    assert "gpu_devices" in str(e.value)
+
+
 def _cli():
     import __graft_entry__ as ge
     ge.build_gpu_library()
