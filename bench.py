@@ -155,23 +155,37 @@ def l2_vs_cpu(abi, hm, flat, film_gpu, prm):
     l2 = np.sqrt(((a - b) ** 2).sum(-1))
     return {"max": float(l2.max()), "rmse": float(np.sqrt((l2 ** 2).mean())), "pixels_gt_1e-4": int((l2 > 1e-4).sum()),
             "pixels": int(l2.size), "film_bit_identical": bool(np.array_equal(film_gpu, film_cpu)),
-            "cpu": f"oracle, counter RNG, seed {prm.seed}, {threads} threads, {st.samples} samples in {dt:.1f} s "
-                   f"({st.samples / dt / 1e6:.2f} Msamples/s)", "on": "developed linear-sRGB pixels (HDRFilm::image)"}
+            "cpu": f"oracle, counter RNG, seed {prm.seed}, {threads} threads, cbox {WIDTH}x{HEIGHT} @ {prm.spp} spp = {st.samples} samples in {dt:.1f} s "
+                   f"({st.samples / dt / 1e6:.2f} Msamples/s)", "cpu_msamples_per_s": round(st.samples / dt / 1e6, 4), "cpu_threads": threads,
+            "on": "developed linear-sRGB pixels (HDRFilm::image)"}
+
+
+def mesh_profile(tag):
+    """profiles/r03_<tag>.json (tools/profile_mesh.sh + summarize_mesh_profiles.py on one MI355X): per-kernel PMC figures of the
+    mesh configs — HBM bytes per segment / per ray and wave64 VALU instructions per ray of the committed profile."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", f"r03_{tag}.json")))
+    except Exception:
+        return None
 
 
 def other_configs(abi, hm, ctx):
     """BASELINE configs 3, 4 and 5 as one GPU sees them (N = 1 only, after the timed region): config 4 whole on this GPU,
     configs 3 / 5 on the bunny- / teapot-class stand-ins (the reference ships no meshes), config 5 at the 128-spp share
-    one GPU of eight renders.  Two renders each, the second is reported (the first one also allocates the workspace)."""
+    one GPU of eight renders.  Two renders each, the second is reported (the first one also allocates the workspace).
+    Every entry carries its own `roofline`: algorithmic bytes of the path state the two wavefront kernels move (DESIGN.md §5;
+    the general shading variant carries 8 more bytes per segment in and out) over the render's device time against the HBM
+    peak, and — for the mesh configs — the PMC-measured bytes and VALU instructions of the committed profile scaled to this
+    run's segments and rays (labelled as coming from the profile)."""
     out = []
     jobs = [
         ("config 3 class: 70 k-triangle rough-conductor mesh in the Cornell room, 1024x1024 @ 256 spp",
-         lambda: hm.bunny_class_scene(1024), 256),
+         lambda: hm.bunny_class_scene(1024), 256, "c3"),
         ("config 5 class: 146 k-triangle rough-dielectric mesh in the Cornell room, 1024x1024 @ 128 spp (one GPU's share of 1024 spp on 8)",
-         lambda: hm.teapot_class_scene(1024), 128),
-        ("config 4 on ONE GPU: cbox 1920x1080 @ 4096 spp", lambda: hm.cbox_scene(1920, 1080), 4096),
+         lambda: hm.teapot_class_scene(1024), 128, "c5"),
+        ("config 4 on ONE GPU: cbox 1920x1080 @ 4096 spp", lambda: hm.cbox_scene(1920, 1080), 4096, None),
     ]
-    for name, make, spp in jobs:
+    for name, make, spp, tag in jobs:
         try:
             flat = make()
             t0 = time.perf_counter()
@@ -183,12 +197,41 @@ def other_configs(abi, hm, ctx):
                 t0 = time.perf_counter()
                 film, st = sc.render(prm)
                 dt = time.perf_counter() - t0
-            out.append({"workload": name, "triangles": int(flat.desc.n_faces), "samples": int(st.samples),
+            general = tag is not None                         # non-diffuse BSDFs: the general shading variant (aux in the state)
+            seg, smp, shd = int(st.segments), int(st.samples), int(st.shadow_rays)
+            b_shade = seg * (176 + (16 if general else 0)) - smp * 64 + shd * 48 + smp * 20
+            b_trace = seg * 48 + shd * (16 if general else 32)        # k_trace_r reads ray_o once per slot; k_trace_q once per queue
+            ms_wave = max(st.ms_total - st.ms_resolve, 1e-6)
+            gbs = (b_shade + b_trace) / (ms_wave * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_shade_gen || k_trace", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_sample": round((b_shade + b_trace) / max(smp, 1), 1),
+                    "note": "state bytes of both wavefront kernels over the wavefront phase's device time; the traversal of a tree in "
+                            "HBM/L2 is bound by load issue and latency, not by these bytes (DESIGN.md §9)"}
+            prof = mesh_profile(tag) if tag else None
+            if prof:
+                k = prof.get("kernels", {})
+                tr = next((v for n, v in k.items() if n.startswith("k_trace")), {})
+                sh = next((v for n, v in k.items() if n.startswith("k_shade")), {})
+                rays = seg + shd
+                if tr.get("hbm_bytes_per_ray") and sh.get("hbm_bytes_per_segment"):
+                    t_gbs = (tr["hbm_bytes_per_ray"] * rays + sh["hbm_bytes_per_segment"] * seg) / (ms_wave * 1e-3) / 1e9
+                    roof["traffic_gbs_from_profile"] = round(t_gbs, 1)
+                    roof["traffic_frac_from_profile"] = round(t_gbs / HBM_PEAK_GBS, 4)
+                if tr.get("valu_insts_per_ray") and sh.get("valu_insts_per_segment"):
+                    ginst = (tr["valu_insts_per_ray"] * rays + sh["valu_insts_per_segment"] * seg) / (ms_wave * 1e-3) / 1e9
+                    roof["valu"] = {"achieved": round(ginst, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instr/s",
+                                    "frac": round(ginst / VALU_PEAK_GINST, 4),
+                                    "note": "peak = 2 cycles per wave64 instruction (v_fma / v_add class); min / max / cmp / cndmask / "
+                                            "shifts / conversions take 4 (tools/micro/valu_ops.hip), so full issue is reached well below 1"}
+                if tr.get("l2_hit_rate") is not None:
+                    roof["l2_hit_rate_trace_from_profile"] = tr["l2_hit_rate"]
+                roof["profile_source"] = prof.get("_source")
+            out.append({"workload": name, "triangles": int(flat.desc.n_faces), "samples": smp,
                         "value": round(st.samples / dt / 1e6, 1), "unit": "Msamples/s", "ms": round(dt * 1e3, 1),
                         "ms_device": round(st.ms_total, 1), "segments_per_sample": round(st.segments / max(st.samples, 1), 3),
                         "iterations": int(st.iterations), "passes": int(st.passes), "ms_resolve": round(st.ms_resolve, 1),
                         "scene_create_s": round(t_scene, 2), "finite": bool(__import__("numpy").isfinite(film).all()),
-                        "timing": "wall time of msk_gpu_render incl. the film copy-back (PCIe)"})
+                        "timing": "wall time of msk_gpu_render incl. the film copy-back (PCIe)", "roofline": roof})
             sc.close()
         except Exception as e:                                       # reported, never fatal for the headline line
             out.append({"workload": name, "error": str(e)[:300]})
@@ -208,12 +251,12 @@ def profile_counters():
 def profile_single_stream():
     """Achieved HBM-side GB/s of the two wavefront kernels when each launch has the GPU to itself, from the COMMITTED profiles:
     PMC bytes per launch (profiles/pmc_summary.json) over the average launch duration of the MSK_STREAMS=1 kernel trace
-    (profiles/r02_kernel_stats_1stream.csv).  Not measured in this run; labelled as such in the line."""
+    (profiles/r03_kernel_stats_1stream.csv).  Not measured in this run; labelled as such in the line."""
     import csv
     pm = profile_counters()
     out = {}
     try:
-        rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_kernel_stats_1stream.csv"))))
+        rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_kernel_stats_1stream.csv"))))
     except Exception:
         return None
     for key in ("k_shade_gen", "k_trace"):
@@ -407,7 +450,10 @@ def main():
                     "frac": round(ginst / VALU_PEAK_GINST, 4), "insts_per_segment": {"k_shade_gen": vs, "k_trace": vt},
                     "source": pm.get("_source", "profiles/pmc_summary.json"),
                     "note": "wave64 VALU instructions (SQ_INSTS_VALU of the committed profile / its segments) x this run's segments "
-                            "/ wavefront-phase wall time; peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction"}
+                            "/ wavefront-phase wall time; peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction — the rate of "
+                            "the v_fma / v_add / v_mul / v_and class only: v_min / v_max / v_cmp / v_cndmask / shifts / conversions / "
+                            "packed and fp64 operations issue at 4 cycles, transcendentals at 8 (measured: tools/micro/valu_ops.hip, "
+                            "profiles/r03_valu_ops.txt), so an instruction stream of this mix saturates issue at a frac of about 0.6"}
         out = {
             "metric": "Msamples/s (paths x spp) on cbox@512spp", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -434,9 +480,12 @@ def main():
         if world == 1:
             # SURVEY 8(d) defines t_render "incl. final film copy-back": the same K steps through msk_gpu_render (host film,
             # 5 MB over PCIe per step); `value` above keeps the film in HBM, as the multi-GPU reduce needs it
+            import numpy as np
+            film_host = np.zeros((HEIGHT, WIDTH, 5), np.float32)
+            scene.render(prm, out=film_host)                  # (maps the array's pages, allocates the library's pinned staging buffer)
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                film_host, _ = scene.render(prm)
+                scene.render(prm, out=film_host)
             dt_host = time.perf_counter() - t1
             out["ms_per_step_incl_copyback"] = round(dt_host / args.steps * 1e3, 3)
             out["value_incl_copyback"] = round(samples_step * args.steps / dt_host / 1e6, 2)
@@ -450,9 +499,12 @@ def main():
             # the reference CLI caps TBB at 8 threads (main.cpp:43-44): that run is `cpu_baseline`; the same port on every
             # hardware thread of this host rides along (SURVEY §8d asks for both)
             out["cpu_baseline"] = cpu_baseline(abi, hm, flat, min(8, os.cpu_count() or 1))
-            n_all = len(os.sched_getaffinity(0))
-            if n_all > 8:
-                out["cpu_baseline_all_threads"] = cpu_baseline(abi, hm, flat, n_all, seconds_target=8.0)
+            # every hardware thread of this host: the full-size counter-RNG render l2_vs_cpu just timed (same port, same work
+            # per sample but for the sampler; rendering it a second time with the PCG sampler would add 20 s for the same figure)
+            l2 = out.get("l2_vs_cpu") or {}
+            if l2.get("cpu_msamples_per_s"):
+                out["cpu_baseline_all_threads"] = {"value": l2["cpu_msamples_per_s"], "unit": "Msamples/s", "cores": l2["cpu_threads"], "kind": "port",
+                                                   "sample": l2["cpu"], "host_cpus": os.cpu_count()}
         else:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_other_configs:

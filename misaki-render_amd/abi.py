@@ -220,9 +220,11 @@ class Scene:
     def height(self):
         return self.flat.desc.film.height
 
-    def render(self, params):
-        """-> (film float32[H,W,5] of weighted sums {X,Y,Z,A,W}, Stats)."""
-        film = np.empty((self.height, self.width, 5), np.float32)
+    def render(self, params, out=None):
+        """-> (film float32[H,W,5] of weighted sums {X,Y,Z,A,W}, Stats).  out: an array to fill instead of a new one (a
+        caller that renders repeatedly keeps its pages mapped: a fresh 5 MB array costs more in page faults than the copy)."""
+        film = out if out is not None else np.empty((self.height, self.width, 5), np.float32)
+        assert film.dtype == np.float32 and film.flags.c_contiguous and film.shape == (self.height, self.width, 5)
         st = Stats()
         self.ctx.check(self.ctx.lib.msk_gpu_render(self.handle, C.byref(params), _ptr(film), C.byref(st)))
         return film, st

@@ -590,6 +590,8 @@ struct Workspace {
     uint64_t plan_n_pix = 0;
     DevBuf counts_init; unsigned long long counts_total = 0; uint32_t counts_regions = 0;
     DevBuf block_buf, blocks, block_of, spiral, pix, pix_inv, rec_a, rec_b, film, bands;
+    void *host_film = nullptr; size_t host_film_bytes = 0;       // pinned staging buffer of msk_gpu_render's film copy-back
+    ~Workspace() { if (host_film) (void) hipHostFree(host_film); }
     uint32_t n_bands = 0;
     DevBuf aov_rec[MSK_MAX_AOV_GROUPS + 1], aov_block_buf[MSK_MAX_AOV_GROUPS + 1];   // [n_groups] = the nested path's RGB
 };
@@ -1132,7 +1134,22 @@ extern "C" int msk_gpu_render(msk_scene *scene, const msk_render_params *params,
     HIP_TRY(ctx, film.reserve(bytes));
     int rc = render_impl(scene, params, film.as<float>(), nullptr, stats);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpy(film_xyzaw, film.p, bytes, hipMemcpyDeviceToHost));
+    // film copy-back through a pinned staging buffer kept with the workspace: device -> pinned at link speed, then one host
+    // memcpy into the caller's (pageable) array — a pageable hipMemcpy of the 5 MB bench film took 2-3 ms, this takes ~0.5
+    Workspace &ws = *scene->ws;
+    if (ws.host_film_bytes < bytes) {
+        if (ws.host_film) (void) hipHostFree(ws.host_film);
+        ws.host_film = nullptr; ws.host_film_bytes = 0;
+        if (hipHostMalloc(&ws.host_film, bytes, hipHostMallocDefault) == hipSuccess) ws.host_film_bytes = bytes;
+        else { (void) hipGetLastError(); ws.host_film = nullptr; }
+    }
+    if (ws.host_film) {
+        HIP_TRY(ctx, hipMemcpyAsync(ws.host_film, film.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(film_xyzaw, ws.host_film, bytes);
+    } else {
+        HIP_TRY(ctx, hipMemcpy(film_xyzaw, film.p, bytes, hipMemcpyDeviceToHost));
+    }
     return MSK_OK;
 }
 

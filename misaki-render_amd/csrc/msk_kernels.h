@@ -389,10 +389,10 @@ MSK_DEV uint32_t node4_step(__amdgpu_buffer_rsrc_t rsrc, uint32_t node, const Se
         key[I] = ((__float_as_uint(t0) & 0x7ffffff0u) | (uint32_t) ((I) << 2)) | miss; }
     MSK_CHILD(0, x) MSK_CHILD(1, y) MSK_CHILD(2, z) MSK_CHILD(3, w)
 #undef MSK_CHILD
-#ifdef MSK_EXP_LOAD     /* experiment: MSK_EXP_LOAD more 16-byte loads per visit (the node's zero padding) — is the texture addresser the bound? */
+#ifdef MSK_EXP_LOAD     /* what-if builds (tools/build_variant.sh): one more 16-byte load of the node's own line per visit (its zero padding) */
     { const msk_u4 ex_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 112u, 0, 0); key[0] |= ex_.x; }
 #endif
-#ifdef MSK_EXP_VALU     /* experiment: MSK_EXP_VALU more dependent fast VALU instructions per visit — is VALU issue the bound? */
+#ifdef MSK_EXP_VALU     /* what-if builds: MSK_EXP_VALU more dependent VALU instructions per visit */
     { float z_ = tmin; for (int e_ = 0; e_ < MSK_EXP_VALU; ++e_) z_ = __fmaf_rn(z_, idir.x, oi.x); key[0] |= z_ == 12345.678f ? 16u : 0u; }
 #endif
 #define MSK_CSWAPU(a, b) { const uint32_t lo_ = a < b ? a : b; b = a < b ? b : a; a = lo_; }
@@ -785,6 +785,7 @@ MSK_DEV void trace_queue(const DeviceScene &sc, const TraceLds &g, const PathSta
     f3 o = mk3(0, 0, 0), d = o, idir = o, oi = o;
     float tmin = 0.f, tfar = 0.f, bt = 0.f, bu = 0.f, bv = 0.f;
     uint32_t bp = MSK_NO_PRIM, cur = DONE;
+    uint32_t kx = 0u, ky = 8u, kz = 16u;              // byte offsets of the near-plane pairs inside a node (by the signs of idir)
     int sp = 0;
     bool occluded = false;
     for (;;) {
@@ -800,6 +801,7 @@ MSK_DEV void trace_queue(const DeviceScene &sc, const TraceLds &g, const PathSta
                     o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z);
                     tmin = ro.w; tfar = ANY ? rd.w : slot_tmax(rd.w);
                     idir = slab_idir(d); oi = mk3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
+                    kx = idir.x < 0.f ? 24u : 0u; ky = idir.y < 0.f ? 32u : 8u; kz = idir.z < 0.f ? 40u : 16u;
                     bt = tfar; bu = 0.f; bv = 0.f; bp = MSK_NO_PRIM; sp = 0; occluded = false;
                     cur = sc.n_tris ? sc.root_ref : DONE;
                     active = true;
@@ -810,12 +812,20 @@ MSK_DEV void trace_queue(const DeviceScene &sc, const TraceLds &g, const PathSta
         if (__ballot(active) == 0ull) break;             // (an all-idle wave refills while jobs remain: nothing is left)
         // ---- inner nodes, until every lane with a ray holds a leaf or has run out of nodes
         while (active && !(cur & MSK_LEAF_BIT)) {
-            const float4 *n = g.nodes + (size_t) cur * 4;
-            const float4 a = n[0], b = n[1], cc = n[2], m = n[3];
-            float t0, t1;
-            const bool h0 = box_test(a.x, a.z, b.x, b.z, cc.x, cc.z, idir, oi, tmin, bt, &t0);
-            const bool h1 = box_test(a.y, a.w, b.y, b.w, cc.y, cc.w, idir, oi, tmin, bt, &t1);
-            const uint32_t c0 = __float_as_uint(m.x), c1 = __float_as_uint(m.y);
+            // near / far planes by ADDRESS instead of by v_min / v_max: a node is {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z} as pairs
+            // (child 0, child 1) of floats, the ray holds the byte offset of its near pair per axis (by the sign of idir) and the
+            // far pair is that offset ^ {24, 40, 56}: twelve of the slowest VALU instructions of the step become LDS offsets
+            const char *nb = (const char *) (g.nodes + (size_t) cur * 4);
+            const float2 nx = *(const float2 *) (nb + kx), fx = *(const float2 *) (nb + (kx ^ 24u));
+            const float2 ny = *(const float2 *) (nb + ky), fy = *(const float2 *) (nb + (ky ^ 40u));
+            const float2 nz = *(const float2 *) (nb + kz), fz = *(const float2 *) (nb + (kz ^ 56u));
+            const uint2 m = *(const uint2 *) (nb + 48);
+            const float t0 = fmaxf(fmaxf(fmaxf(__fmaf_rn(nx.x, idir.x, -oi.x), __fmaf_rn(ny.x, idir.y, -oi.y)), __fmaf_rn(nz.x, idir.z, -oi.z)), tmin);
+            const float t1 = fmaxf(fmaxf(fmaxf(__fmaf_rn(nx.y, idir.x, -oi.x), __fmaf_rn(ny.y, idir.y, -oi.y)), __fmaf_rn(nz.y, idir.z, -oi.z)), tmin);
+            const float e0 = fminf(fminf(fminf(__fmaf_rn(fx.x, idir.x, -oi.x), __fmaf_rn(fy.x, idir.y, -oi.y)), __fmaf_rn(fz.x, idir.z, -oi.z)), bt);
+            const float e1 = fminf(fminf(fminf(__fmaf_rn(fx.y, idir.x, -oi.x), __fmaf_rn(fy.y, idir.y, -oi.y)), __fmaf_rn(fz.y, idir.z, -oi.z)), bt);
+            const bool h0 = t0 <= e0 * 1.0000004f, h1 = t1 <= e1 * 1.0000004f;
+            const uint32_t c0 = m.x, c1 = m.y;
             if (h0 && h1) {
                 const bool swap = t1 < t0;
                 cur = swap ? c1 : c0;

@@ -48,6 +48,16 @@ def test_missing_library_fails_loudly(abi, tmp_path):
     assert "no CPU fallback" in str(e.value).replace("NO", "no") or "fallback" in str(e.value)
 
 
+def test_group_context_argument_checks(abi):
+    """msk_gpu_init(ids, n): n < 1 and n > 8 are refused before any device is touched (no GPU needed)."""
+    with pytest.raises(abi.MskError) as e:
+        abi.Context([0] * 9)
+    assert e.value.code == abi.MSK_ERR_INVALID_ARG and "at most 8 devices" in str(e.value)
+    with pytest.raises(abi.MskError) as e:
+        abi.Context([])
+    assert e.value.code == abi.MSK_ERR_INVALID_ARG
+
+
 def test_flatten_cbox(hostmirror, golden_lookup):
     fs = hostmirror.cbox_scene(512, 512, coeff_lookup=golden_lookup)
     d = fs.desc
