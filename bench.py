@@ -172,7 +172,7 @@ def mesh_profile(tag):
 def other_configs(abi, hm, ctx):
     """BASELINE configs 3, 4 and 5 as one GPU sees them (N = 1 only, after the timed region): config 4 whole on this GPU,
     configs 3 / 5 on the bunny- / teapot-class stand-ins (the reference ships no meshes), config 5 at the 128-spp share
-    one GPU of eight renders.  Two renders each, the second is reported (the first one also allocates the workspace).
+    one GPU of eight renders.  Three renders each: the first allocates the workspace, the faster of the other two is reported.
     Every entry carries its own `roofline`: algorithmic bytes of the path state the two wavefront kernels move (DESIGN.md §5;
     the general shading variant carries 8 more bytes per segment in and out) over the render's device time against the HBM
     peak, and — for the mesh configs — the PMC-measured bytes and VALU instructions of the committed profile scaled to this
@@ -192,11 +192,16 @@ def other_configs(abi, hm, ctx):
             sc = abi.Scene(ctx, flat)
             t_scene = time.perf_counter() - t0
             prm = abi.render_params(spp=spp)
-            film = None
-            for _ in range(2):
+            import numpy as np
+            film = np.zeros((flat.desc.film.height, flat.desc.film.width, 5), np.float32)      # reused: its pages stay mapped
+            sc.render(prm, out=film)                              # allocates the workspace, uploads the plan
+            dt, st = None, None
+            for _ in range(2):                                    # the faster of two is reported (a host hiccup is not the GPU's)
                 t0 = time.perf_counter()
-                film, st = sc.render(prm)
-                dt = time.perf_counter() - t0
+                _, st_k = sc.render(prm, out=film)
+                dt_k = time.perf_counter() - t0
+                if dt is None or dt_k < dt:
+                    dt, st = dt_k, st_k
             general = tag is not None                         # non-diffuse BSDFs: the general shading variant (aux in the state)
             seg, smp, shd = int(st.segments), int(st.samples), int(st.shadow_rays)
             b_shade = seg * (176 + (16 if general else 0)) - smp * 64 + shd * 48 + smp * 20
