@@ -956,6 +956,11 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
             else { t.cur = DONE; }
         }
     }
+    // Measured and rejected on the 64-byte-node kernel (round 3, config-5-class render, 78.3 ms): the next triangle's loads issued
+    // before the current one is tested, a leaf of two triangles as one memory round trip (12 more live registers = 56 bytes of
+    // scratch at six waves: 85.6 ms; five waves without scratch: 87.7); postponed leaves — a lane that reaches a leaf parks it, goes
+    // on with its stack and tests the parked leaf at the end of the quantum, so that inner-node steps run fuller: 78.1 ms (config-3
+    // class 94.0 vs 96.2): the steps it fills are paid back by later culling.
     if (t.cur != DONE && (t.cur & MSK_LEAF_BIT)) {
         const uint32_t first = (t.cur & 0x7fffffffu) >> 5, cnt = t.cur & 31u;
         MSK_CNT(7, 1);
