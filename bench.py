@@ -476,7 +476,10 @@ def main():
                          "traffic_source": "NOT measured in this run: per-launch FETCH_SIZE/WRITE_SIZE of the committed rocprofv3 PMC "
                                            "passes (%s)" % pm.get("_source", "profiles/pmc_summary.json"),
                          "bytes_per_launch": round(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
-                         "per_kernel": per_kernel, "launches": iters, "timed_launches": nl, "timed": "launches of every %s-th sync group" % os.environ.get("MSK_TIMING_EVERY", "1"),
+                         "per_kernel": per_kernel, "launches": iters,
+                         "launches_note": "wavefront iterations as the library books them: an upper bound on kernel-pair launches (a k_wavefront "
+                                          "launch of the thin end of a pass is booked as 16 iterations even when its regions empty earlier)",
+                         "timed_launches": nl, "timed": "launches of every %s-th sync group" % os.environ.get("MSK_TIMING_EVERY", "1"),
                          "ms_trace_timed": round(ms_trace, 2), "ms_shade_timed": round(ms_shade, 2),
                          "ms_resolve": round(sum(s.ms_resolve for s in stats), 2),
                          "ms_total_device": round(sum(s.ms_total for s in stats), 2),

@@ -1,0 +1,67 @@
+// Host-side check of msk_bvh.h's quantised 4-wide nodes (Built::nodes4q), compiled and run by tests/test_bvh_host.py:
+// every decoded child box must contain the padded full-precision box of nodes4 (the traversal only ever culls), the grid must be
+// the finest that spans the node (area growth of a per cent or so), unused slots must be inverted boxes pointing at an empty leaf.
+// usage: bvh_quant_check <n_triangles> <seed> <scale>     prints "ok ..." or "FAIL ..."
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+#include "../../misaki-render_amd/csrc/msk_bvh.h"
+
+int main(int argc, char **argv) {
+    const uint32_t n = argc > 1 ? (uint32_t) atoi(argv[1]) : 20000;
+    const uint32_t seed = argc > 2 ? (uint32_t) atoi(argv[2]) : 1;
+    const float world = argc > 3 ? (float) atof(argv[3]) : 1.f;
+    std::mt19937 rng(seed);
+    std::uniform_real_distribution<float> u(-1.f, 1.f);
+    std::vector<float> pos((size_t) n * 9);
+    for (uint32_t t = 0; t < n; ++t) {
+        float c[3] = {u(rng) * 300.f, u(rng) * 300.f, u(rng) * 300.f};
+        const float size = std::pow(10.f, u(rng) * 1.2f);                     // sizes over more than two decades
+        const int kind = (int) (rng() % 10);
+        for (int v = 0; v < 3; ++v)
+            for (int a = 0; a < 3; ++a) {
+                float d = u(rng) * size;
+                if (kind == 0 && a == (int) (t % 3)) d = 0.f;                 // axis-aligned triangles: a degenerate box axis
+                if (kind == 1 && v == 2) d *= 1e-4f;                          // slivers
+                pos[(size_t) t * 9 + v * 3 + a] = (c[a] + d) * world;
+            }
+    }
+    mskbvh::Built b = mskbvh::build(pos.data(), n, 0.05f * world);
+    mskbvh::collapse4(b);
+    const size_t nn = b.nodes4.size() / 32;
+    if (b.nodes4q.size() != nn * 16) { printf("FAIL nodes4q has %zu dwords for %zu nodes\n", b.nodes4q.size(), nn); return 1; }
+    double area_ratio = 0; size_t children = 0, empty = 0;
+    for (size_t m = 0; m < nn; ++m) {
+        const float *f = &b.nodes4[m * 32];
+        const uint32_t *q = &b.nodes4q[m * 16];
+        float origin[3], scale[3];
+        memcpy(origin, q, 12); memcpy(&scale[0], &q[3], 4); memcpy(&scale[1], &q[4], 8);
+        uint32_t refs[4]; memcpy(refs, &f[24], 16);
+        for (int i = 0; i < 4; ++i) {
+            double e[3], eq[3];
+            for (int a = 0; a < 3; ++a) {
+                const double ql = (q[6 + a] >> (8 * i)) & 255u, qh = (q[9 + a] >> (8 * i)) & 255u;
+                if (refs[i] == mskbvh::kEmpty4) {
+                    if (!(ql == 255 && qh == 0) || q[12 + i] != 0x80000000u) { printf("FAIL node %zu slot %d: unused slot not inverted / not an empty leaf\n", m, i); return 1; }
+                    continue;
+                }
+                if (!(scale[a] > 0.f) || !std::isfinite(scale[a])) { printf("FAIL node %zu axis %d: scale %g\n", m, a, scale[a]); return 1; }
+                const double lo = f[a * 4 + i], hi = f[12 + a * 4 + i];
+                const double dlo = (double) origin[a] + ql * (double) scale[a], dhi = (double) origin[a] + qh * (double) scale[a];
+                if (dlo > lo || dhi < hi) { printf("FAIL node %zu child %d axis %d: [%.9g, %.9g] does not contain [%.9g, %.9g]\n", m, i, a, dlo, dhi, lo, hi); return 1; }
+                if (dlo < lo - 1.0000001 * scale[a] || dhi > hi + 1.0000001 * scale[a]) { printf("FAIL node %zu child %d axis %d: more than one grid cell of slack\n", m, i, a); return 1; }
+                e[a] = hi - lo; eq[a] = dhi - dlo;
+            }
+            if (refs[i] == mskbvh::kEmpty4) { ++empty; continue; }
+            if (q[12 + i] != refs[i]) { printf("FAIL node %zu child %d: reference differs\n", m, i); return 1; }
+            const double A = e[0] * e[1] + e[1] * e[2] + e[2] * e[0], Aq = eq[0] * eq[1] + eq[1] * eq[2] + eq[2] * eq[0];
+            if (A > 0) { area_ratio += Aq / A; ++children; }
+        }
+    }
+    printf("ok nodes %zu children %zu unused_slots %zu mean_area_ratio %.5f depth4 %d\n", nn, children, empty, children ? area_ratio / children : 1.0, b.max_depth4);
+    return 0;
+}
