@@ -237,8 +237,13 @@ typedef struct msk_ctx   msk_ctx;
 typedef struct msk_scene msk_scene;
 
 /* ---- lifetime ------------------------------------------------------------ */
-/* device_ids: HIP ordinals; n must be 1 in this version (one process per GPU,
-   multi-GPU is one msk_ctx per rank + a film reduce). */
+/* device_ids: n >= 1 HIP ordinals (at most 8).  n == 1: an ordinary context on that device.  n > 1: a GROUP context
+   (SURVEY §8b writes the entry point with a device list; csrc/msk_multi.h): one member context per entry — an ordinal may
+   repeat —, every scene created on it lives on every member, msk_gpu_render / _render_device / _render_aov shard the call's
+   samples over the members by index (member k: sample_first + (k + j n) sample_stride), one host thread each, and sum the
+   films on device_ids[0] over peer access in member order; d_film_xyzaw of msk_gpu_render_device is memory of device_ids[0];
+   the sub-stage entry points run on the first member.  (The one-process-per-GPU scheme — one single-device msk_ctx per
+   rank + an RCCL film reduce — sits above this ABI: DESIGN.md §7.) */
 int  msk_gpu_init(const int *device_ids, int n, msk_ctx **out_ctx);
 void msk_gpu_shutdown(msk_ctx *ctx);
 const char *msk_gpu_last_error(const msk_ctx *ctx); /* ctx may be NULL */
