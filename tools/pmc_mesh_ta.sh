@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/pmc_mesh_ta.sh c3|c5 [spp]: texture-addresser / L1 (TA, TCP, TD) counter passes of the mesh configs, single stream,
 # each pass its own run -> gpurun_out/pmta_<cfg>_<n>/ and a per-kernel sum table gpurun_out/pmta_<cfg>.txt
+# (no TD_* pass: rocprofv3 aborted with signal 6 on it on this pool and the run had to be killed)
 CFG=${1:-c5}; SPP=${2:-32}
 export TMPDIR=/tmp MSK_STREAMS=1
 OUT=$PWD/gpurun_out
@@ -13,8 +14,6 @@ PASSES=(
  "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum"
  "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum"
  "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum"
- "TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum"
- "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum"
 )
 i=0
 for P in "${PASSES[@]}"; do
