@@ -502,8 +502,8 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     const size_t table_bytes = ((size_t) ds.n_tris * 6 + ds.n_meshes + ds.n_bsdf_f4 + ds.n_emitters * 2 +
                                 (ds.n_emitters * 95 + 3) / 4 + (ds.cdf_len + 3) / 4 + 72) * 16;
     s->lds_tables = table_bytes <= 40 * 1024;
-    // + the waves' done-queues (k_shade_gen: 3 x MSK_DONE_Q float4 per wave)
-    s->shade_lds_bytes = (s->lds_tables ? table_bytes : 0) + (size_t) (MSK_BLOCK / MSK_WAVE) * 3 * MSK_DONE_Q * 16;
+    // + the waves' done-queues (k_shade_gen: MSK_DONE_Q_F4 float4 per wave)
+    s->shade_lds_bytes = (s->lds_tables ? table_bytes : 0) + (size_t) (MSK_BLOCK / MSK_WAVE) * MSK_DONE_Q_F4 * 16;
     if (s->trace_lds_bytes > ctx->prop.sharedMemPerBlock) {
         delete s;
         return fail(ctx, MSK_ERR_UNSUPPORTED, "BVH depth %d needs %zu B of traversal stack per block", bvh.max_depth, stack_bytes);
@@ -731,7 +731,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     // k_wavefront (iterations on the device): possible when tables and tree are LDS-resident and everything fits one block's LDS
     // next to each other, and there is no per-iteration AOV kernel.  MSK_FUSED=1: the whole pass; MSK_FUSED_TAIL_PCT=p: from
     // the point where every sample has been started and fewer than p % of the slots are live.
-    const uint32_t fused_queue_f4 = sc->lds_tables ? (uint32_t) ((sc->shade_lds_bytes - (size_t) (MSK_BLOCK / MSK_WAVE) * 3 * MSK_DONE_Q * 16) / 16) : 0u;
+    const uint32_t fused_queue_f4 = sc->lds_tables ? (uint32_t) ((sc->shade_lds_bytes - (size_t) (MSK_BLOCK / MSK_WAVE) * MSK_DONE_Q_F4 * 16) / 16) : 0u;
     const uint32_t fused_trace_f4 = (uint32_t) (sc->shade_lds_bytes / 16);
     const size_t fused_lds = sc->shade_lds_bytes + sc->trace_lds_bytes;
     const bool fused_ok = sc->trace_mode == 0 && sc->lds_tables && fused_lds <= 64 * 1024 && !(aov && aov->n_groups);

@@ -1444,6 +1444,7 @@ MSK_DEV void emit_record(const DeviceScene &sc, const SceneTables &tb, const Pas
 // fp64 cosh, twelve CIE lookups, one RNG draw — about a fifth of this kernel's instructions) then runs with all lanes
 // busy instead of once per chunk for the ~25 % of its lanes that happened to finish.
 #define MSK_DONE_Q 128                     /* entries per wave: up to 63 parked + 64 new */
+#define MSK_DONE_Q_F4 (MSK_DONE_Q * 5 / 2)  /* float4 of LDS per wave: wl and res (16 B per entry), id (8 B) */
 struct DoneQueue { float4 *wl, *res; uint2 *id; };      // id: {film pixel, sample index}
 
 // Material-sorted shading (general variant).  Before a region is shaded its live paths are ordered by the material class of
@@ -1507,7 +1508,10 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
     uint32_t n_done = 0;
 
     // A chunk's state as it is loaded.  (Measured and rejected: issuing the NEXT chunk's loads before this one is shaded — legal
-    // with two-half regions — costs 30 VGPRs = one wave per SIMD and is slower, 21.6 vs 20.7 ms of shading per bench step.)
+    // with two-half regions — costs 30 VGPRs = one wave per SIMD and is slower, 21.6 vs 20.7 ms of shading per bench step.  Round 3:
+    // the same through LDS-DMA (global_load_lds_dwordx4 of wl / thr / res into 3 KB of LDS per wave while the current chunk is
+    // shaded, read back before the chunk's stores): the 12 registers that carry the values across the loop edge push the kernel
+    // to 145 VGPRs, and held at 128 it spills 80 bytes: shading 21.8 vs 17.7 ms alone, step 39.4 vs 36.1 ms; films identical.)
     struct ChunkIn { uint2 id; float4 wl, thr, res, rd4, hit, contrib; float2 aux; };
     const uint32_t first_new = n_in - rc.n_new;      // live index of the first camera sample the last sweep started
     bool sorted = false;
@@ -1837,10 +1841,10 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
     return region_view(wave, pp.region_size, rc.count, rc.half_ns);
 }
 
-// this wave's done-queue: `base` + 3 x MSK_DONE_Q float4 per wave of the block
+// this wave's done-queue: `base` + MSK_DONE_Q_F4 float4 per wave of the block
 MSK_DEV DoneQueue done_queue(float4 *base) {
     DoneQueue dq;
-    float4 *qbase = base + (threadIdx.x / MSK_WAVE) * (3 * MSK_DONE_Q);
+    float4 *qbase = base + (threadIdx.x / MSK_WAVE) * MSK_DONE_Q_F4;
     dq.wl = qbase; dq.res = qbase + MSK_DONE_Q; dq.id = (uint2 *) (qbase + 2 * MSK_DONE_Q);
     return dq;
 }
@@ -1854,7 +1858,7 @@ MSK_DEV void shade_gen_body(const DeviceScene &sc, const PathState &st, const Pa
     const DoneQueue dq = done_queue(lds_dyn + queue_f4);
     SortScratch ss{nullptr, nullptr};
     if (!DIFFUSE_ONLY && pp.sort_scratch) {         // after the queues: per wave, 3 bytes per slot of a region (host: shade LDS plan)
-        uint8_t *p = (uint8_t *) (lds_dyn + queue_f4 + (MSK_BLOCK / MSK_WAVE) * 3 * MSK_DONE_Q) + (size_t) (threadIdx.x / MSK_WAVE) * 3u * pp.region_size;
+        uint8_t *p = (uint8_t *) (lds_dyn + queue_f4 + (MSK_BLOCK / MSK_WAVE) * MSK_DONE_Q_F4) + (size_t) (threadIdx.x / MSK_WAVE) * 3u * pp.region_size;
         ss.perm = (uint16_t *) p; ss.cls = p + 2u * pp.region_size;
     }
     if (lwave >= pp.region_count) return;
