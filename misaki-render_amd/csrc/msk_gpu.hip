@@ -33,7 +33,9 @@ struct msk_ctx {
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop;
     std::string last_error;
+#ifndef MSK_MAX_STREAMS
 #define MSK_MAX_STREAMS 4
+#endif
     hipStream_t more_streams[MSK_MAX_STREAMS - 1] = {};   // the other parts of the pool run here (run_wavefront)
     Ctrl *h_ctrl = nullptr;            // pinned, [MSK_MAX_STREAMS]: one per part
     std::vector<hipEvent_t> events, more_events[MSK_MAX_STREAMS - 1];
