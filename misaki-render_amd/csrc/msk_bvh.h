@@ -225,10 +225,60 @@ struct Collapser {
         a->lo[0] = n[0]; a->lo[1] = n[2]; a->lo[2] = n[4]; a->hi[0] = n[6]; a->hi[1] = n[8]; a->hi[2] = n[10];
         b->lo[0] = n[1]; b->lo[1] = n[3]; b->lo[2] = n[5]; b->hi[0] = n[7]; b->hi[1] = n[9]; b->hi[2] = n[11];
     }
+    // Which descendants of a binary node become the (up to four) children of its wide node.  Greedy (dp empty): open the child
+    // with the largest surface area until four slots are filled.  Optimal (plan() was run): the choice that minimises the summed
+    // surface area of the wide nodes — a visit tests four boxes, used or not, so a wide node costs its area whatever it holds,
+    // and the leaves are the binary tree's either way — by dynamic programming over the binary tree (the scheme of Ylitie,
+    // Karras, Laine 2017 for 8-wide trees): cost[i - 1] = the cheapest way to hang a subtree into at most i slots.  Greedy
+    // fills 2.97 of 4 slots on the 146 k-triangle mesh, the plan 3.54: 23 % fewer nodes, 5.5 % fewer node visits per ray
+    // (tools/micro/bvh_stats.cpp).
+    struct Plan { float cost[4]; uint8_t split[4]; uint8_t slots[4]; };    // index i - 1 for "at most i slots": slots = 0: n is one wide node (whose own
+                                                                           // four slots are split[0] : 4 - split[0]); else n's children share `slots` slots, split : slots - split
+    std::vector<Plan> dp;
+    void plan() {
+        const size_t nn = n2.size() / 16;
+        dp.assign(nn, Plan{});
+        auto cost_of = [&](const Slot &c, int i) {                        // T[c][i] of a child reference
+            if (c.ref & 0x80000000u) return 0.f;
+            return dp[c.ref].cost[i - 1];
+        };
+        for (size_t n = nn; n-- > 0;) {                                    // children have larger indices than their parent (build())
+            Slot l, r; children((uint32_t) n, &l, &r);
+            Plan &p = dp[n];
+            float lo[3], hi[3];
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(l.lo[a], r.lo[a]); hi[a] = std::max(l.hi[a], r.hi[a]); }
+            Slot me{0, {lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
+            float dist[5]; uint8_t dsplit[5] = {0, 0, 0, 0, 0};           // dist[j]: n's two children hung into at most j slots (j >= 2)
+            for (int j = 2; j <= 4; ++j) {
+                dist[j] = INFINITY;
+                for (int k = 1; k < j; ++k) {
+                    const float c = cost_of(l, k) + cost_of(r, j - k);
+                    if (c < dist[j]) { dist[j] = c; dsplit[j] = (uint8_t) k; }
+                }
+            }
+            p.cost[0] = area(me) + dist[4]; p.split[0] = dsplit[4]; p.slots[0] = 0;     // one slot: n is a wide node
+            for (int i = 2; i <= 4; ++i) {
+                if (dist[i] < p.cost[i - 2]) { p.cost[i - 1] = dist[i]; p.split[i - 1] = dsplit[i]; p.slots[i - 1] = (uint8_t) i; }
+                else { p.cost[i - 1] = p.cost[i - 2]; p.split[i - 1] = p.split[i - 2]; p.slots[i - 1] = p.slots[i - 2]; }
+            }
+        }
+    }
+    void hang(const Slot &c, int i, Slot *s, int &ns) const {             // c's subtree into at most i slots, as planned
+        if ((c.ref & 0x80000000u) || dp[c.ref].slots[i - 1] == 0) { s[ns++] = c; return; }
+        Slot l, r; children(c.ref, &l, &r);
+        const int j = dp[c.ref].slots[i - 1], k = dp[c.ref].split[i - 1];
+        hang(l, k, s, ns); hang(r, j - k, s, ns);
+    }
     uint32_t collapse(uint32_t node, int depth) {
         max_depth = std::max(max_depth, depth);
         Slot s[4]; int ns = 2;
         children(node, &s[0], &s[1]);
+        if (!dp.empty()) {
+            const int k = dp[node].split[0];
+            const Slot l = s[0], r = s[1];
+            ns = 0;
+            hang(l, k, s, ns); hang(r, 4 - k, s, ns);
+        } else
         while (ns < 4) {
             int best = -1; float best_area = -1.f;
             for (int i = 0; i < ns; ++i)
@@ -287,133 +337,15 @@ inline void Collapser::quantise(uint32_t me, const Slot *s, int ns, const uint32
     for (int a = 0; a < 3; ++a) { q[6 + a] = lo_b[a]; q[9 + a] = hi_b[a]; }
     for (int i = 0; i < 4; ++i) q[12 + i] = refs[i] == kEmpty4 ? 0x80000000u : refs[i];       // empty leaf: first 0, count 0
 }
-static inline void collapse4(Built &b) {
+static inline void collapse4(Built &b, bool optimal = true) {
     b.nodes4.clear(); b.nodes4q.clear(); b.root_ref4 = b.root_ref; b.max_depth4 = 0;
     if (b.root_ref & 0x80000000u) return;            // a single leaf: nothing to collapse
     Collapser c{b.nodes, {}, 0};
+    if (optimal) c.plan();
     b.root_ref4 = c.collapse(b.root_ref, 1);
     b.nodes4 = std::move(c.out);
     if (c.ok_q) b.nodes4q = std::move(c.out_q);
     b.max_depth4 = c.max_depth;
-}
-
-// Renumbers the 4-wide nodes (nodes4 and nodes4q alike) so that the TREETOP comes first: the `n_top` nodes a ray is most likely
-// to visit — grown from the root by always opening the pending inner node with the largest surface area, the SAH's visit
-// probability — take the indices [0, n_top) in the order they were opened; the others follow in their depth-first order.  The
-// traversal kernels keep nodes [0, n_top) in LDS (msk_kernels.h: node4q_step): on the mesh scenes two thirds of all node visits
-// fall on the first 128 nodes (tools/micro/bvh_stats.cpp).  Only the numbering changes: same boxes, same leaves, same hits.
-// Returns the number of treetop nodes (<= n_top).
-static inline uint32_t treetop_first(Built &b, uint32_t n_top) {
-    const uint32_t nn = (uint32_t) (b.nodes4.size() / 32);
-    if (nn == 0 || (b.root_ref4 & 0x80000000u)) return 0;
-    n_top = std::min(n_top, nn);
-    auto refs_of = [&](uint32_t node) { return (const uint32_t *) &b.nodes4[(size_t) node * 32 + 24]; };
-    auto slot_area = [&](uint32_t node, int i) {
-        const float *o = &b.nodes4[(size_t) node * 32];
-        const float dx = o[12 + i] - o[i], dy = o[16 + i] - o[4 + i], dz = o[20 + i] - o[8 + i];
-        return 2.f * (dx * dy + dy * dz + dz * dx);
-    };
-    std::vector<uint32_t> new_of(nn, 0xffffffffu);
-    std::vector<std::pair<float, uint32_t>> heap;        // (area, node), max-heap; ties by node index so that the order is reproducible
-    auto less = [](const std::pair<float, uint32_t> &x, const std::pair<float, uint32_t> &y) { return x.first < y.first || (x.first == y.first && x.second > y.second); };
-    heap.push_back({INFINITY, b.root_ref4});
-    uint32_t next = 0;
-    while (next < n_top && !heap.empty()) {
-        std::pop_heap(heap.begin(), heap.end(), less);
-        const uint32_t node = heap.back().second; heap.pop_back();
-        new_of[node] = next++;
-        const uint32_t *r = refs_of(node);
-        for (int i = 0; i < 4; ++i)
-            if (r[i] != kEmpty4 && !(r[i] & 0x80000000u)) { heap.push_back({slot_area(node, i), r[i]}); std::push_heap(heap.begin(), heap.end(), less); }
-    }
-    const uint32_t got = next;
-    for (uint32_t node = 0; node < nn; ++node) if (new_of[node] == 0xffffffffu) new_of[node] = next++;
-    std::vector<float> n4(b.nodes4.size());
-    std::vector<uint32_t> n4q(b.nodes4q.size());
-    for (uint32_t node = 0; node < nn; ++node) {
-        const uint32_t to = new_of[node];
-        std::memcpy(&n4[(size_t) to * 32], &b.nodes4[(size_t) node * 32], 128);
-        uint32_t *r = (uint32_t *) &n4[(size_t) to * 32 + 24];
-        for (int i = 0; i < 4; ++i) if (r[i] != kEmpty4 && !(r[i] & 0x80000000u)) r[i] = new_of[r[i]];
-        if (!n4q.empty()) {
-            std::memcpy(&n4q[(size_t) to * 16], &b.nodes4q[(size_t) node * 16], 64);
-            uint32_t *q = &n4q[(size_t) to * 16 + 12];
-            for (int i = 0; i < 4; ++i) if (!(q[i] & 0x80000000u)) q[i] = new_of[q[i]];
-        }
-    }
-    b.root_ref4 = new_of[b.root_ref4];
-    b.nodes4 = std::move(n4); b.nodes4q = std::move(n4q);
-    return got;
-}
-
-// The walked tree of trace mode 6 (msk_kernels.h: trav_quantum_u): ONE array of 64-byte records — the quantised 4-wide nodes
-// (Built::nodes4q, same numbering) followed by the LEAF RECORDS — so that a lane's next item, node or leaf, is four 16-byte loads
-// at `item << 6` whatever it is.  A leaf record holds one triangle in the tris3 form, or TWO triangles that share an edge the
-// way a fanned quad's do (f a b c d -> (a, b, c), (a, c, d): v0' = v0, v1' = v2, so e1' = v0' - v1' = 0 - (v2 - v0) = 0 - e2 exactly, and
-// the second triangle only adds its third vertex D: e2' = D - v0):
-//   dw 0-2 v0, dw 3 prim word | dw 4-6 e1, dw 7 e2.x | dw 8-9 e2.yz, dw 10-11 D.xy | dw 12 D.z, dw 13 prim word of the second
-//   triangle (MSK_NO_PRIM: none, and D = v0: a degenerate triangle, den = 0, which the test rejects), dw 14-15 unused
-// The two triangles of a leaf may be stored in either order (hit selection is by (t, prim), not by order).  A leaf that is not
-// such a pair takes one record per triangle.  Leaf references are rewritten in nodes4q (nodes4 keeps the old ones):
-//   0x80000000 | (n_nodes4 + first record) << 5 | number of records     (the empty leaf: record 0, a triangle pair no ray hits)
-// `tris` must hold the 64-byte triangle records of the leaf order (prim words with their class bits), pos the scene's triangles.
-// Returns false (and leaves b.tree empty) when the records do not fit the 26 index bits.
-static inline bool pack_tree6(Built &b, const float *pos, std::vector<uint32_t> *tree, uint32_t *n_records_out) {
-    tree->clear();
-    const uint32_t nn = (uint32_t) (b.nodes4q.size() / 16);
-    if (nn == 0) return false;
-    auto same = [](const float *x, const float *y) { return std::memcmp(x, y, 12) == 0; };
-    std::vector<uint32_t> rec;                    // 16 dwords per record
-    auto emit = [&](uint32_t k0, int64_t k1, const float *D) {
-        const float *t = &b.tris[(size_t) k0 * 16];
-        uint32_t r[16] = {0};
-        std::memcpy(&r[0], &t[0], 16);                                   // v0 | prim
-        std::memcpy(&r[4], &t[4], 12); std::memcpy(&r[7], &t[8], 4);     // e1 | e2.x
-        std::memcpy(&r[8], &t[9], 8);                                    // e2.yz
-        const float *d = D ? D : &t[0];
-        std::memcpy(&r[10], &d[0], 8); std::memcpy(&r[12], &d[2], 4);
-        uint32_t p1 = 0xffffffffu;
-        if (k1 >= 0) std::memcpy(&p1, &b.tris[(size_t) k1 * 16 + 3], 4);
-        r[13] = p1;
-        rec.insert(rec.end(), r, r + 16);
-    };
-    // tri (leaf-order index k) = (A, B, C); is tri j = (A, C, D) for some D?
-    auto fan_of = [&](uint32_t k, uint32_t j, const float **D) {
-        uint32_t pk, pj; std::memcpy(&pk, &b.tris[(size_t) k * 16 + 3], 4); std::memcpy(&pj, &b.tris[(size_t) j * 16 + 3], 4);
-        const float *a = pos + (size_t) (pk & 0x03ffffffu) * 9, *c = pos + (size_t) (pj & 0x03ffffffu) * 9;
-        if (!(same(c, a) && same(c + 3, a + 6))) return false;
-        // the kernel derives the second triangle's e1 = v0 - v1 as 0 - e2 of the first: that must be the same bits (signed zeros)
-        for (int x = 0; x < 3; ++x) {
-            const float e2 = a[6 + x] - a[x], direct = c[x] - c[3 + x], derived = 0.f - e2;
-            if (std::memcmp(&direct, &derived, 4) != 0) return false;
-        }
-        *D = c + 6;
-        return true;
-    };
-    std::vector<uint32_t> q = b.nodes4q;
-    // record 0: the empty leaf's (an unused slot's inverted box is never entered; should it be, this all-zero triangle pair — Ng =
-    // 0, den = 0 — rejects every ray)
-    rec.assign(16, 0u); rec[3] = rec[13] = 0xffffffffu;
-    for (uint32_t node = 0; node < nn; ++node)
-        for (int i = 0; i < 4; ++i) {
-            uint32_t &ref = q[(size_t) node * 16 + 12 + i];
-            if (!(ref & 0x80000000u)) continue;
-            if ((ref & 31u) == 0) { ref = 0x80000000u | (nn << 5) | 1u; continue; }
-            const uint32_t first = (ref & 0x7fffffffu) >> 5, cnt = ref & 31u;
-            const uint32_t r0 = (uint32_t) (rec.size() / 16);
-            const float *D = nullptr;
-            if (cnt == 2 && fan_of(first, first + 1, &D)) emit(first, first + 1, D);
-            else if (cnt == 2 && fan_of(first + 1, first, &D)) emit(first + 1, first, D);
-            else for (uint32_t k = 0; k < cnt; ++k) emit(first + k, -1, nullptr);
-            const uint32_t n_rec = (uint32_t) (rec.size() / 16) - r0;
-            if ((uint64_t) nn + r0 + n_rec >= (1ull << 26) || n_rec > 31u) return false;
-            ref = 0x80000000u | ((nn + r0) << 5) | n_rec;
-        }
-    *n_records_out = (uint32_t) (rec.size() / 16);
-    tree->reserve(q.size() + rec.size());
-    tree->insert(tree->end(), q.begin(), q.end());
-    tree->insert(tree->end(), rec.begin(), rec.end());
-    return true;
 }
 
 // Collapses the binary tree into 8-wide nodes with quantised child boxes (layout: Built::nodes8).

@@ -95,7 +95,7 @@ struct msk_scene {
     DevBuf part_films[MSK_MAX_GROUP], staged[MSK_MAX_GROUP], group_film;
     Workspace *ws = nullptr;           // render buffers, kept between calls (hipMalloc/hipFree of GBs costs milliseconds)
     DeviceScene dev;
-    DevBuf nodes, nodes4, nodes4q, tree6, nodes8, tris, tris3, tri_bounds, tri_verts, tri_frames, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
+    DevBuf nodes, nodes4, nodes4q, nodes8, tris, tris3, tri_bounds, tri_verts, tri_frames, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
     bool lds_scene = false, lds_tables = false, all_diffuse = true;
     int trace_mode = 0;                // 0 binary tree in LDS, 1 binary tree in HBM/L2, 2 4-wide tree in HBM/L2, 4 8-wide quantised tree in HBM/L2,
                                        // 5 4-wide tree with quantised boxes in HBM/L2 (64-byte nodes; the default for trees in HBM)
@@ -103,7 +103,6 @@ struct msk_scene {
     int bvh_depth = 0;
     uint32_t n_tris = 0;
     size_t tree_bytes = 0;             // node array the traversal walks
-    uint32_t pool_rays = 0, pool_stack = 0;   // trace mode 6: rays per wave in k_trace_p's LDS pool (0: k_trace_r / k_trace_v), stack entries per ray in LDS
 };
 
 #include "msk_multi.h"
@@ -459,10 +458,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         s->tree_bytes = bvh.nodes8.size() * 4;
     } else if (!s->lds_scene && env_u32("MSK_WIDE_BVH", MSK_WIDE_BVH_DEFAULT) && !(bvh.root_ref & MSK_LEAF_BIT)) {
         // the tree stays in HBM/L2: walk it four children at a time, one 128-byte line per visit
-        mskbvh::collapse4(bvh);
-        // the walked form keeps its treetop — the nodes a ray is most likely to visit — in LDS: they come first (msk_bvh.h: treetop_first)
-        const bool quant = env_u32("MSK_QUANT_BVH", 1) && !bvh.nodes4q.empty();
-        if (quant) ds.n_top4 = mskbvh::treetop_first(bvh, env_u32("MSK_TREETOP", 128));
+        mskbvh::collapse4(bvh, env_u32("MSK_COLLAPSE_OPTIMAL", 1) != 0);
         // the traversal addresses nodes and triangle records through buffer resources with 32-bit byte offsets
         if ((uint64_t) (bvh.nodes4.size() / 32) * 128u >= (1ull << 32) || (uint64_t) d->n_faces * 48u >= (1ull << 32)) {
             delete s;
@@ -476,30 +472,12 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         s->tree_bytes = bvh.nodes4.size() * 4;
         // the walked form: 64-byte nodes with quantised child boxes (MSK_QUANT_BVH=0: the full-precision 128-byte ones) and
         // three-load triangle records, packed on the device from `tris`
-        if (quant) {
+        if (env_u32("MSK_QUANT_BVH", 1) && !bvh.nodes4q.empty()) {
             hipError_t eq = s->nodes4q.upload(bvh.nodes4q);
             if (eq != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(eq)); }
             ds.nodes4q = s->nodes4q.as<float4>();
             s->trace_mode = 5;
             s->tree_bytes = bvh.nodes4q.size() * 4;
-            // the default walk reads nodes and leaf records from ONE array, one item per memory round trip (trace mode 6,
-            // msk_bvh.h: pack_tree6); MSK_UNIFIED_TREE=0 keeps the separate node and triangle arrays of mode 5
-            if (env_u32("MSK_UNIFIED_TREE", 1)) {
-                if (gpu_build) {            // the device builder's triangle records, for their order and prim words
-                    bvh.tris.resize((size_t) d->n_faces * 16);
-                    hipError_t ec = hipMemcpy(bvh.tris.data(), s->tris.p, (size_t) d->n_faces * 64, hipMemcpyDeviceToHost);
-                    if (ec != hipSuccess) { delete s; return fail(ctx, MSK_ERR_HIP, "device BVH build: %s", hipGetErrorString(ec)); }
-                }
-                std::vector<uint32_t> tree; uint32_t n_rec = 0;
-                if (mskbvh::pack_tree6(bvh, pos.data(), &tree, &n_rec)) {
-                    hipError_t e6 = s->tree6.upload(tree);
-                    if (e6 != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(e6)); }
-                    ds.tree6 = s->tree6.as<float4>(); ds.n_tree6 = (uint32_t) (tree.size() / 16);
-                    ds.n_top4 = 0;
-                    s->trace_mode = 6;
-                    s->tree_bytes = tree.size() * 4;
-                }
-            }
         }
         {
             hipError_t et = s->tris3.alloc(std::max<size_t>((size_t) d->n_faces * 48, 16));
@@ -511,7 +489,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     } else if (s->lds_scene && env_u32("MSK_WIDE_LDS", 0) && !(bvh.root_ref & MSK_LEAF_BIT)) {
         // experiment knob, off by default: the 4-wide tree staged in LDS (half the dependent LDS round trips per ray).
         // Measured on cbox: trace 12.45 vs 12.34 ms for the binary tree — no gain.
-        mskbvh::collapse4(bvh);
+        mskbvh::collapse4(bvh, env_u32("MSK_COLLAPSE_OPTIMAL", 1) != 0);
         hipError_t e4 = s->nodes4.upload(bvh.nodes4);
         if (e4 != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(e4)); }
         ds.nodes4 = s->nodes4.as<float4>(); ds.root_ref4 = bvh.root_ref4; ds.n_nodes4 = (uint32_t) (bvh.nodes4.size() / 32);
@@ -520,19 +498,12 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         s->trace_mode = 3;
     }
     ds.stack_total = ds.stack_entries;
-    if (s->trace_mode == 1 || s->trace_mode == 2 || s->trace_mode == 4 || s->trace_mode == 5 || s->trace_mode == 6) {
+    if (s->trace_mode == 1 || s->trace_mode == 2 || s->trace_mode == 4 || s->trace_mode == 5) {
         // trees in HBM: only the first MSK_STACK_CAP entries of a lane's stack live in LDS, the rest in an HBM overflow
         // array (LaneStack) — any tree depth works within a fixed 16 KB (+ 4 KB of node4_step scratch) of LDS per block, which
         // leaves room for six blocks per CU.  (Measured: the cap does not change the trace time between 8 and 40 entries.)
-        // Mode 5 adds its treetop (128 nodes = 8 KB) and keeps 12 entries: 24 KB, still six blocks per CU.
-        if (s->trace_mode == 6) {
-            s->pool_rays = std::min(MSK_POOL_RING, env_u32("MSK_TRACE_POOL", 96));
-            if (s->pool_rays && s->pool_rays < MSK_WAVE) s->pool_rays = MSK_WAVE;
-        }
-        ds.stack_entries = std::min(ds.stack_total, std::max(4u, env_u32("MSK_STACK_CAP", s->pool_rays ? 8 : s->trace_mode == 5 && ds.n_top4 ? 12 : 16) & ~3u));
-        s->pool_stack = ds.stack_entries;
-        s->trace_lds_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4 + (size_t) MSK_BLOCK * (s->trace_mode == 6 ? 32 : 16)   // + four (eight) words per lane
-                             + (s->trace_mode == 5 ? (size_t) ds.n_top4 * 64 : 0);
+        ds.stack_entries = std::min(ds.stack_total, std::max(4u, env_u32("MSK_STACK_CAP", 16) & ~3u));
+        s->trace_lds_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4 + (size_t) MSK_BLOCK * 16;       // + four words per lane (node4_step)
     }
     // LDS plan of k_shade_gen: the small lookup tables (tri_verts, mesh/bsdf/emitter records, cdf, d65, cie)
     const size_t table_bytes = ((size_t) ds.n_tris * 6 + ds.n_meshes + ds.n_bsdf_f4 + ds.n_emitters * 2 +
@@ -682,14 +653,6 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
         else if (sc->trace_mode == 0) hipExtLaunchKernelGGL(k_trace_r<0>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         else if (sc->trace_mode == 1) hipExtLaunchKernelGGL(k_trace_r<1>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         else if (sc->trace_mode == 5) hipExtLaunchKernelGGL(k_trace_r<5>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
-        else if (sc->trace_mode == 6 && sc->pool_rays) {
-            // k_trace_p: one wave per block, the wave's ray pool in LDS
-            const uint32_t P = sc->pool_rays; const int S = (int) sc->pool_stack;
-            const size_t lds_p = (size_t) P * 64 + 2 * MSK_POOL_RING * 8 + MSK_WAVE * 16 + (size_t) S * P * 4 + pp.region_size / 8;
-            hipExtLaunchKernelGGL(k_trace_p, dim3(pp.region_count), dim3(MSK_WAVE), lds_p, stream, t0, t1, 0, sc->dev, st, pp, P, S);
-        }
-        else if (sc->trace_mode == 6 && env_u32("MSK_TRACE_VOTE", 1)) hipExtLaunchKernelGGL(k_trace_v, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, (int) env_u32("MSK_TRACE_LEAF_PCT", 50));
-        else if (sc->trace_mode == 6) hipExtLaunchKernelGGL(k_trace_r<6>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         else hipExtLaunchKernelGGL(k_trace_r<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         return;
     }
@@ -711,7 +674,6 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
     else if (sc->trace_mode == 2) hipExtLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
     else if (sc->trace_mode == 4) hipExtLaunchKernelGGL(k_trace<4>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
     else if (sc->trace_mode == 5) hipExtLaunchKernelGGL(k_trace<5>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
-    else if (sc->trace_mode == 6) hipExtLaunchKernelGGL(k_trace<6>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
     else hipExtLaunchKernelGGL(k_trace<3>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
 }
 
@@ -886,8 +848,8 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
                              k ? EventPool{ctx, 0, &ctx->more_events[k - 1]} : EventPool{ctx, ev.next, ev.pool}, nullptr, msk_stats{}, MSK_OK,
                              share(first, last - first), std::string()});
         std::memset(&parts.back().st, 0, sizeof(msk_stats));
-        if (ovf_words) {                                // LaneStack overflow: one word per lane (k_trace_p: per pooled ray) per extra entry, per launch
-            const size_t lanes = std::max((size_t) (((last - first) * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK) * MSK_BLOCK, (size_t) (last - first) * sc->pool_rays);
+        if (ovf_words) {                                // LaneStack overflow: one word per lane per extra entry, per launch
+            const size_t lanes = (size_t) (((last - first) * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK) * MSK_BLOCK;
             HIP_TRY(ctx, sb.stack_ovf[k].reserve((size_t) ovf_words * lanes * 4));
             parts.back().stack_ovf = sb.stack_ovf[k].as<uint32_t>();
         }
@@ -950,7 +912,7 @@ static uint32_t owned_spp(const msk_render_params *p) {
 // wants many waves per launch).  Long rays (k_trace_r): 4096 regions of 2048 slots = 8 M, so that lane replacement has a long
 // list of rays to keep the lanes busy with.
 static void pool_shape(const msk_scene *sc, uint64_t total_samples, uint32_t *region_size, uint32_t *n_regions) {
-    const bool big = sc->trace_mode == 1 || sc->trace_mode == 2 || sc->trace_mode == 4 || sc->trace_mode == 5 || sc->trace_mode == 6;
+    const bool big = sc->trace_mode == 1 || sc->trace_mode == 2 || sc->trace_mode == 4 || sc->trace_mode == 5;
     // trees in HBM: one traversal wave per region at 5 waves per SIMD = 5120 resident waves; with 4096 regions the four loops'
     // launches never filled the GPU (8192 regions: config-5-class render 173 vs 191 ms, config-3-class 205 vs 227 ms)
     // LDS-resident scenes: 6144 x 1024 (with the state's cache policy in place — msk_kernels.h, MSK_NT — fewer, longer regions
@@ -1338,9 +1300,6 @@ static int trace_batch(msk_scene *scene, uint64_t n, const float *rays, float *o
                            d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
     else if (scene->trace_mode == 5)
         hipLaunchKernelGGL(k_trace_batch<5>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
-                           d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
-    else if (scene->trace_mode == 6)
-        hipLaunchKernelGGL(k_trace_batch<6>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
                            d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
     else
         hipLaunchKernelGGL(k_trace_batch<3>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,

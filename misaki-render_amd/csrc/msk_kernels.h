@@ -46,10 +46,6 @@ struct DeviceScene {
     const float4 *nodes;        // 4 x float4 per node (msk_bvh.h)
     const float4 *nodes4;       // 8 x float4 per 4-wide node, or nullptr (scenes whose BVH is staged in LDS use `nodes`)
     uint32_t root_ref4, n_nodes4;
-    uint32_t n_top4;            // trace mode 5: the nodes [0, n_top4) of nodes4q — the treetop, msk_bvh.h: treetop_first — are read from a
-                                // copy in LDS (stage_treetop), the others from HBM/L2
-    const float4 *tree6;        // trace mode 6: n_tree6 records of 64 bytes — the nodes of nodes4q (same numbering, leaf references rewritten),
-    uint32_t n_tree6;           // then the leaf records (msk_bvh.h: pack_tree6): a lane's next item is four loads at `item << 6`
     const float4 *nodes4q;      // 4 x float4 per 4-wide node with quantised child boxes (msk_bvh.h: Built::nodes4q; same numbering as
                                 // nodes4), or nullptr: what the traversal of a tree in HBM/L2 reads
     const float4 *tris3;        // 3 x float4 per triangle, leaf order: [v0 | prim] [e1 | e2.x] [e2.y e2.z - -] — `tris` without the
@@ -279,10 +275,7 @@ MSK_DEV bool box_test(float lox, float loy, float loz, float hix, float hiy, flo
 template <bool OVF>
 struct LaneStack {
     uint32_t *lds; uint32_t *ovf; int cap; size_t stride;
-    uint32_t *scratch = nullptr;        // OVF kernels: 4 words of LDS per lane (node4_step's child references; mode 6: + 4 words, the
-                                        // extension ray's direction and tmax while the slot's shadow ray is walked), else unused
-    const uint4 *top = nullptr;         // trace mode 5: the block's LDS copy of the treetop (nodes [0, n_top) of nodes4q), else unused
-    uint32_t n_top = 0;
+    uint32_t *scratch = nullptr;        // OVF kernels: 4 words of LDS per lane (node4_step's child references), else unused
     MSK_DEV void push(int &sp, uint32_t v) const {
         if (!OVF || sp < cap) lds[sp * MSK_BLOCK] = v; else ovf[(size_t) (sp - cap) * stride] = v;
         sp += 1;
@@ -434,12 +427,14 @@ MSK_DEV Sel4q make_sel4q(f3 idir) {
 MSK_DEV __amdgpu_buffer_rsrc_t nodes4q_rsrc(const DeviceScene &sc) {
     return __builtin_amdgcn_make_buffer_rsrc((void *) sc.nodes4q, 0, sc.n_nodes4 * 64u, 0x00020000);
 }
-// the visit proper, on the node's four quads (h0 = origin.xyz, scale.x   h1 = scale.y, scale.z, lo.x[4], lo.y[4]   h2 = lo.z[4], hi.x[4],
-// hi.y[4], hi.z[4]   rf = child references)
-template <class STK>
-MSK_DEV uint32_t node4q_visit(const msk_u4 h0, const msk_u4 h1, const msk_u4 h2, const msk_u4 rf, const Sel4q &sel, f3 idir, f3 oi, float tmin, float tcur,
-                              const STK &stack, int &sp) {
+template <bool OVF>
+MSK_DEV uint32_t node4q_step(__amdgpu_buffer_rsrc_t rsrc, uint32_t node, const Sel4q &sel, f3 idir, f3 oi, float tmin, float tcur,
+                             const LaneStack<OVF> &stack, int &sp) {
+    const uint32_t base = node << 6;
+    const msk_u4 h0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base, 0, 0), h1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 16u, 0, 0);
+    const msk_u4 h2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 32u, 0, 0), rf = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 48u, 0, 0);
     *(msk_u4 *) stack.scratch = rf;
+    // h0 = origin.xyz, scale.x   h1 = scale.y, scale.z, lo.x[4], lo.y[4]   h2 = lo.z[4], hi.x[4], hi.y[4], hi.z[4]
     const float ax = __uint_as_float(h0.w) * idir.x, ay = __uint_as_float(h1.x) * idir.y, az = __uint_as_float(h1.y) * idir.z;
     const float bx = __fmaf_rn(__uint_as_float(h0.x), idir.x, -oi.x), by = __fmaf_rn(__uint_as_float(h0.y), idir.y, -oi.y),
                 bz = __fmaf_rn(__uint_as_float(h0.z), idir.z, -oi.z);
@@ -470,20 +465,6 @@ MSK_DEV uint32_t node4q_visit(const msk_u4 h0, const msk_u4 h1, const msk_u4 h2,
         stack.push(sp, *(const uint32_t *) (sc4 + (key[1] & 12u)));
     }
     return *(const uint32_t *) (sc4 + (key[0] & 12u));
-}
-template <bool OVF>
-MSK_DEV uint32_t node4q_step(__amdgpu_buffer_rsrc_t rsrc, uint32_t node, const Sel4q &sel, f3 idir, f3 oi, float tmin, float tcur,
-                             const LaneStack<OVF> &stack, int &sp) {
-    const uint32_t base = node << 6;
-    msk_u4 h0, h1, h2, rf;
-    if (node < stack.n_top) {           // the treetop: four LDS reads (no texture-addresser cycles, a fifth of the latency)
-        const msk_u4 *p = (const msk_u4 *) ((const char *) stack.top + base);
-        h0 = p[0]; h1 = p[1]; h2 = p[2]; rf = p[3];
-    } else {
-        h0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base, 0, 0); h1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 16u, 0, 0);
-        h2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 32u, 0, 0); rf = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 48u, 0, 0);
-    }
-    return node4q_visit(h0, h1, h2, rf, sel, idir, oi, tmin, tcur, stack, sp);
 }
 
 // a triangle of a tree in HBM/L2: three loads (DeviceScene::tris3), the normal recomputed with the builder's operations
@@ -598,119 +579,6 @@ MSK_DEV bool traverse4h(const DeviceScene &sc, f3 o, f3 d, float tmin, float tma
     }
     *best_t = bt; *best_u = bu; *best_v = bv; *best_prim = bp;
     return false;
-}
-
-#ifdef MSK_COUNT
-// instrumented builds only (tools/build_variant.sh count -DMSK_COUNT; read through msk_gpu_debug_counts): traversal work of
-// k_trace_r.  [0] rays, [1] quanta (wave-level), [2] active lanes summed over quanta, [3] inner-node steps (wave-level),
-// [4] inner-node visits (lanes), [5] triangle steps (wave-level), [6] triangle tests (lanes), [7] leaf visits (lanes)
-__device__ unsigned long long msk_counts[16];
-MSK_DEV bool first_active_lane() {
-    const unsigned long long e = __builtin_amdgcn_read_exec();
-    return __builtin_amdgcn_mbcnt_hi((uint32_t) (e >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) e, 0u)) == 0u;
-}
-#define MSK_CNT(i, v) atomicAdd(&msk_counts[i], (unsigned long long) (v))
-#define MSK_CNT_WAVE(i) do { if (first_active_lane()) atomicAdd(&msk_counts[i], 1ull); } while (0)
-#else
-#define MSK_CNT(i, v) do {} while (0)
-#define MSK_CNT_WAVE(i) do {} while (0)
-#endif
-// ------------------------------------------------------------------------------------------
-// Trace mode 6: ONE ITEM, ONE ROUND TRIP.  The tree is one array of 64-byte records, nodes and leaf records alike
-// (DeviceScene::tree6, msk_bvh.h: pack_tree6), and a lane's current item — an inner node or a leaf — is fetched by the same four
-// loads at `item << 6`; the node lanes then run the box tests, the leaf lanes the triangle tests.  In the while-while quantum of
-// modes 2 / 5 a lane that holds a leaf sits through the other lanes' node round trips and the other way round (54 % / 48 % of
-// the ray-holding lanes active in a node / a triangle step): 37 wave-level memory round trips per ray for its 13.4 nodes and
-// 3.1 leaves.  Here every ray-holding lane advances in every step, 16.5 round trips per ray, for the same VALU work; with the
-// shading kernel's waves beside it a SIMD holds two or three traversal waves, so it is the round trips that count.
-// A leaf record holds one triangle or a fanned quad's two (v0' = v0, e1' = 0 - e2, e2' = D - v0: the bits the builder would
-// compute from the second triangle's own vertices — pack_tree6 checks it); a leaf of several records is walked by stepping the
-// reference.  Same arithmetic per triangle, hit selection by (t, prim): the same hits, bit for bit.
-// ------------------------------------------------------------------------------------------
-MSK_DEV __amdgpu_buffer_rsrc_t tree6_rsrc(const DeviceScene &sc) {
-    return __builtin_amdgcn_make_buffer_rsrc((void *) sc.tree6, 0, sc.n_tree6 * 64u, 0x00020000);
-}
-struct TravState {
-    Sel4 sel;           // trace mode 2
-    Sel4q selq;         // trace mode 5 (the unused one of the two is dead code in either instantiation)
-    f3 o, d, idir, oi;
-    float tmin, tmax, bt, bu, bv;
-    uint32_t bp, cur;
-    int sp;
-};
-MSK_DEV void trav_begin(TravState &t, uint32_t root_ref, uint32_t n_tris, f3 o, f3 d, float tmin, float tmax) {
-    t.o = o; t.d = d; t.tmin = tmin; t.tmax = tmax;
-    t.idir = slab_idir(d);
-    t.sel = make_sel4(t.idir); t.selq = make_sel4q(t.idir);
-    t.oi = mk3(o.x * t.idir.x, o.y * t.idir.y, o.z * t.idir.z);
-    t.bt = tmax; t.bu = 0.f; t.bv = 0.f; t.bp = MSK_NO_PRIM; t.sp = 0;
-    t.cur = n_tris ? root_ref : 0xffffffffu;
-}
-// the node item: four loads, the visit
-template <class STK>
-MSK_DEV void trav_node6(__amdgpu_buffer_rsrc_t rs, TravState &t, const STK &stack) {
-    const uint32_t off = t.cur << 6;
-    const msk_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16u, 0, 0);
-    const msk_u4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 32u, 0, 0), e = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 48u, 0, 0);
-    MSK_CNT_WAVE(3); MSK_CNT(4, 1);
-    t.cur = node4q_visit(a, b, c, e, t.selq, t.idir, t.oi, t.tmin, t.bt, stack, t.sp);
-}
-// the leaf item: one leaf record = one or two triangles.  Returns true when an any-hit query found its hit.
-template <class STK>
-MSK_DEV bool trav_leaf6(__amdgpu_buffer_rsrc_t rs, float tri_pad, TravState &t, const STK &stack, bool any) {
-    const uint32_t DONE = 0xffffffffu;
-    const uint32_t off = (t.cur & 0x7fffffe0u) << 1;
-    const msk_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16u, 0, 0);
-    const msk_u4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 32u, 0, 0), e = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 48u, 0, 0);
-    MSK_CNT_WAVE(5); MSK_CNT(7, 1); MSK_CNT(6, e.y != MSK_NO_PRIM ? 2 : 1);
-    bool found = false;
-    const float4 q0 = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), 0.f);
-    float tt, u, v;
-    {
-        const float4 q1 = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), 0.f);
-        const float4 q2 = make_float4(__uint_as_float(b.w), __uint_as_float(c.x), __uint_as_float(c.y), 0.f);
-        const float4 q3 = make_float4(q2.y * q1.z - q2.z * q1.y, q2.z * q1.x - q2.x * q1.z, q2.x * q1.y - q2.y * q1.x, 0.f);     // Ng = e2 x e1
-        if (tri_test(q0, q1, q2, q3, t.o, t.d, t.tmin, t.tmax, &tt, &u, &v, nullptr, tri_pad)) {
-            if (any) found = true;
-            else if (t.bp == MSK_NO_PRIM || tt < t.bt || (tt == t.bt && (a.w & MSK_PRIM_ID) < (t.bp & MSK_PRIM_ID))) { t.bt = tt; t.bu = u; t.bv = v; t.bp = a.w; }
-        }
-    }
-    if (!found) {        // the quad's second triangle (a record without one: D = v0, e2' = 0, Ng' = 0, den = 0: rejected)
-        const float4 q1 = make_float4(__fsub_rn(0.f, __uint_as_float(b.w)), __fsub_rn(0.f, __uint_as_float(c.x)), __fsub_rn(0.f, __uint_as_float(c.y)), 0.f);
-        const float4 q2 = make_float4(__uint_as_float(c.z) - q0.x, __uint_as_float(c.w) - q0.y, __uint_as_float(e.x) - q0.z, 0.f);
-        const float4 q3 = make_float4(q2.y * q1.z - q2.z * q1.y, q2.z * q1.x - q2.x * q1.z, q2.x * q1.y - q2.y * q1.x, 0.f);
-        if (tri_test(q0, q1, q2, q3, t.o, t.d, t.tmin, t.tmax, &tt, &u, &v, nullptr, tri_pad)) {
-            if (any) found = true;
-            else if (t.bp == MSK_NO_PRIM || tt < t.bt || (tt == t.bt && (e.y & MSK_PRIM_ID) < (t.bp & MSK_PRIM_ID))) { t.bt = tt; t.bu = u; t.bv = v; t.bp = e.y; }
-        }
-    }
-    if (found) t.cur = DONE;
-    else if ((t.cur & 31u) > 1u) t.cur += 31u;                  // the leaf's next record: index + 1, count - 1
-    else t.cur = t.sp > 0 ? stack.pop(t.sp) : DONE;
-    return found;
-}
-// one item of either kind
-MSK_DEV bool trav_item6(__amdgpu_buffer_rsrc_t rs, float tri_pad, TravState &t, const LaneStack<true> &stack, bool any) {
-    if (!(t.cur & MSK_LEAF_BIT)) { trav_node6(rs, t, stack); return false; }
-    return trav_leaf6(rs, tri_pad, t, stack, any);
-}
-template <bool ANY>
-MSK_DEV bool traverse6(const DeviceScene &sc, f3 o, f3 d, float tmin, float tmax, const LaneStack<true> &stack, float *best_t, float *best_u,
-                       float *best_v, uint32_t *best_prim) {
-    TravState t;
-    trav_begin(t, sc.root_ref4, sc.n_tris, o, d, tmin, tmax);
-    const __amdgpu_buffer_rsrc_t rs = tree6_rsrc(sc);
-    bool found = false;
-    while (t.cur != 0xffffffffu) found = trav_item6(rs, sc.tri_pad, t, stack, ANY);
-    *best_t = t.bt; *best_u = t.bu; *best_v = t.bv; *best_prim = t.bp;
-    return found;
-}
-// one work quantum of k_trace_r<6>: up to `max_items` items
-MSK_DEV bool trav_quantum6(const DeviceScene &sc, TravState &t, const LaneStack<true> &stack, int max_items, bool any) {
-    const __amdgpu_buffer_rsrc_t rs = tree6_rsrc(sc);
-    bool found = false;
-    for (int it = 0; it < max_items && t.cur != 0xffffffffu; ++it) found = trav_item6(rs, sc.tri_pad, t, stack, any);
-    return found;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -841,32 +709,15 @@ MSK_DEV float slot_tmax(float rd_w) {
 #define MSK_HIT_UNOCCLUDED 0x80000000u
 #define MSK_PRIM_MASK 0x7fffffffu
 // MODE 0: binary tree staged in LDS; 1: binary tree in HBM/L2; 2: 4-wide tree in HBM/L2; 3: 4-wide tree staged in LDS;
-// 4: 8-wide tree with quantised boxes in HBM/L2; 5: 4-wide tree with quantised boxes in HBM/L2 (64-byte nodes); 6: the same nodes and
-// the leaf records in one array, one item per round trip (the default for trees in HBM/L2)
-#define MSK_OVF(MODE) ((MODE) == 1 || (MODE) == 2 || (MODE) == 4 || (MODE) == 5 || (MODE) == 6)      /* the stack can overflow to HBM only when the tree lives there */
+// 4: 8-wide tree with quantised boxes in HBM/L2; 5: 4-wide tree with quantised boxes in HBM/L2 (64-byte nodes: the default)
+#define MSK_OVF(MODE) ((MODE) == 1 || (MODE) == 2 || (MODE) == 4 || (MODE) == 5)      /* the stack can overflow to HBM only when the tree lives there */
 template <int MODE, bool ANY>
 MSK_DEV bool traverse_scene(const DeviceScene &sc, const TraceLds &g, f3 o, f3 d, float tmin, float tmax, const LaneStack<MSK_OVF(MODE)> &stack,
                             float *bt, float *bu, float *bv, uint32_t *bp) {
-    if constexpr (MODE == 6) return traverse6<ANY>(sc, o, d, tmin, tmax, stack, bt, bu, bv, bp);
-    else if constexpr (MODE == 2 || MODE == 5) return traverse4h<ANY, MODE == 5>(sc, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+    if constexpr (MODE == 2 || MODE == 5) return traverse4h<ANY, MODE == 5>(sc, o, d, tmin, tmax, stack, bt, bu, bv, bp);
     else if constexpr (MODE == 4) return traverse8<ANY, true>(sc.nodes8, g.tris, sc.tri_pad, sc.root_ref8, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
     else if constexpr (MODE == 3) return traverse4<ANY, false>(g.nodes, g.tris, sc.tri_pad, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
     else return traverse<ANY, MSK_OVF(MODE)>(g.nodes, g.tris, sc.tri_pad, sc.root_ref, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
-}
-
-// A lane's stack for trace mode MODE (all threads of the block call this before any of them leaves).  Mode 5 also stages the
-// treetop: LDS layout [stacks: stack_entries x MSK_BLOCK words][node4_step scratch: 4 words per lane][treetop: n_top4 x 64 B].
-template <int MODE>
-MSK_DEV LaneStack<MSK_OVF(MODE)> lane_stack(const DeviceScene &sc, uint32_t *stack_base, uint32_t *ovf, size_t ovf_stride) {
-    LaneStack<MSK_OVF(MODE)> s{stack_base + threadIdx.x, ovf, (int) sc.stack_entries, ovf_stride,
-                               MSK_OVF(MODE) ? stack_base + sc.stack_entries * MSK_BLOCK + threadIdx.x * (MODE == 6 ? 8 : 4) : nullptr};
-    if constexpr (MODE == 5) {
-        uint4 *top = (uint4 *) (stack_base + sc.stack_entries * MSK_BLOCK + MSK_BLOCK * 4);
-        for (uint32_t i = threadIdx.x; i < sc.n_top4 * 4u; i += MSK_BLOCK) top[i] = ((const uint4 *) sc.nodes4q)[i];
-        __syncthreads();
-        s.top = top; s.n_top = sc.n_top4;
-    }
-    return s;
 }
 
 template <int MODE>
@@ -876,7 +727,9 @@ MSK_DEV void trace_chunks(const DeviceScene &sc, const PathState &st, const Pass
     uint32_t *stack_base = (uint32_t *) lds_dyn;                         // stack_entries * MSK_BLOCK words
     float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
     TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE, MODE == 3);
-    const LaneStack<MSK_OVF(MODE)> stack = lane_stack<MODE>(sc, stack_base, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x, (size_t) gridDim.x * MSK_BLOCK);
+    const LaneStack<MSK_OVF(MODE)> stack{stack_base + threadIdx.x, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
+                                     (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK,
+                                     MSK_OVF(MODE) ? stack_base + sc.stack_entries * MSK_BLOCK + threadIdx.x * 4 : nullptr};
     const uint32_t gwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
     const uint32_t lwave = gwave / pp.trace_split, sub = gwave % pp.trace_split;     // region of this launch, and which of its chunks
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
@@ -1032,6 +885,37 @@ k_trace_q(DeviceScene sc, PathState st, PassParams pp, uint32_t refill, uint32_t
 // (or nothing else is running), so a long ray no longer idles the 63 lanes that shared its chunk.  Each lane's
 // arithmetic is exactly traverse()'s: same hit, bit for bit.
 // ------------------------------------------------------------------------------------------
+#ifdef MSK_COUNT
+// instrumented builds only (tools/build_variant.sh count -DMSK_COUNT; read through msk_gpu_debug_counts): traversal work of
+// k_trace_r.  [0] rays, [1] quanta (wave-level), [2] active lanes summed over quanta, [3] inner-node steps (wave-level),
+// [4] inner-node visits (lanes), [5] triangle steps (wave-level), [6] triangle tests (lanes), [7] leaf visits (lanes)
+__device__ unsigned long long msk_counts[16];
+MSK_DEV bool first_active_lane() {
+    const unsigned long long e = __builtin_amdgcn_read_exec();
+    return __builtin_amdgcn_mbcnt_hi((uint32_t) (e >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) e, 0u)) == 0u;
+}
+#define MSK_CNT(i, v) atomicAdd(&msk_counts[i], (unsigned long long) (v))
+#define MSK_CNT_WAVE(i) do { if (first_active_lane()) atomicAdd(&msk_counts[i], 1ull); } while (0)
+#else
+#define MSK_CNT(i, v) do {} while (0)
+#define MSK_CNT_WAVE(i) do {} while (0)
+#endif
+struct TravState {
+    Sel4 sel;           // trace mode 2
+    Sel4q selq;         // trace mode 5 (the unused one of the two is dead code in either instantiation)
+    f3 o, d, idir, oi;
+    float tmin, tmax, bt, bu, bv;
+    uint32_t bp, cur;
+    int sp;
+};
+MSK_DEV void trav_begin(TravState &t, uint32_t root_ref, uint32_t n_tris, f3 o, f3 d, float tmin, float tmax) {
+    t.o = o; t.d = d; t.tmin = tmin; t.tmax = tmax;
+    t.idir = slab_idir(d);
+    t.sel = make_sel4(t.idir); t.selq = make_sel4q(t.idir);
+    t.oi = mk3(o.x * t.idir.x, o.y * t.idir.y, o.z * t.idir.z);
+    t.bt = tmax; t.bu = 0.f; t.bv = 0.f; t.bp = MSK_NO_PRIM; t.sp = 0;
+    t.cur = n_tris ? root_ref : 0xffffffffu;
+}
 // one work quantum: up to `max_inner` inner nodes, then (if the lane holds one) a leaf.  Returns true when an any-hit
 // query found its hit.  t.cur == 0xffffffff afterwards means the traversal is complete.
 // `any` is a per-lane run-time flag on purpose: lanes in the shadow phase and lanes in the closest-hit phase share one
@@ -1112,7 +996,9 @@ MSK_DEV void trace_replace(const DeviceScene &sc, const PathState &st, const Pas
     uint32_t *stack_base = (uint32_t *) lds_dyn;
     float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
     TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE, MODE == 3);
-    const LaneStack<MSK_OVF(MODE)> stack = lane_stack<MODE>(sc, stack_base, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x, (size_t) gridDim.x * MSK_BLOCK);
+    const LaneStack<MSK_OVF(MODE)> stack{stack_base + threadIdx.x, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
+                                     (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK,
+                                     MSK_OVF(MODE) ? stack_base + sc.stack_entries * MSK_BLOCK + threadIdx.x * 4 : nullptr};
     const uint32_t lwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
     const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
     if (lwave >= pp.region_count) return;
@@ -1139,10 +1025,9 @@ MSK_DEV void trace_replace(const DeviceScene &sc, const PathState &st, const Pas
                     unocc = 0; active = true;
                     if (shadow_phase) {
                         const float4 s = st.sh[slot];
-                        if constexpr (MODE == 6) *(float4 *) (stack.scratch + 4) = rd;        // parked in LDS while the shadow ray is walked
-                        trav_begin(t, MODE == 4 ? sc.root_ref8 : (MODE == 2 || MODE == 5 || MODE == 6) ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(s.x, s.y, s.z), ro.w, s.w);
+                        trav_begin(t, MODE == 4 ? sc.root_ref8 : (MODE == 2 || MODE == 5) ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(s.x, s.y, s.z), ro.w, s.w);
                     } else {
-                        trav_begin(t, MODE == 4 ? sc.root_ref8 : (MODE == 2 || MODE == 5 || MODE == 6) ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+                        trav_begin(t, MODE == 4 ? sc.root_ref8 : (MODE == 2 || MODE == 5) ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
                     }
                 }
             }
@@ -1152,21 +1037,15 @@ MSK_DEV void trace_replace(const DeviceScene &sc, const PathState &st, const Pas
         MSK_CNT_WAVE(1);
         if (active) {
             MSK_CNT(2, 1);
-            bool occ;
-            if constexpr (MODE == 6) occ = trav_quantum6(sc, t, stack, max_inner, shadow_phase);
-            else occ = trav_quantum<MODE>(sc, g, t, stack, max_inner, shadow_phase);
+            const bool occ = trav_quantum<MODE>(sc, g, t, stack, max_inner, shadow_phase);
             if (t.cur == 0xffffffffu) {
                 MSK_CNT(0, 1);
                 if (shadow_phase) {
                     unocc = occ ? 0u : MSK_HIT_UNOCCLUDED;
                     shadow_phase = false;
-                    if constexpr (MODE == 6) {
-                        const float4 e = *(const float4 *) (stack.scratch + 4);
-                        trav_begin(t, sc.root_ref4, sc.n_tris, t.o, mk3(e.x, e.y, e.z), t.tmin, e.w);
-                    } else
-                        trav_begin(t, MODE == 4 ? sc.root_ref8 : (MODE == 2 || MODE == 5) ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+                    trav_begin(t, MODE == 4 ? sc.root_ref8 : (MODE == 2 || MODE == 5) ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
                 } else {
-                    const bool valid = (t.bp != MSK_NO_PRIM) && (t.bt != t.tmax);          // scene.cpp:234 tfar != maxt
+                    const bool valid = (t.bp != MSK_NO_PRIM) && (t.bt != rd.w);
                     st.hit[slot] = make_float4(valid ? t.bt : MSK_INF_F, t.bu, t.bv, __uint_as_float((valid ? t.bp : MSK_PRIM_MASK) | unocc));
                     active = false;
                 }
@@ -1174,253 +1053,14 @@ MSK_DEV void trace_replace(const DeviceScene &sc, const PathState &st, const Pas
         }
     }
 }
-// the register cap is the measured optimum of the instantiations that are defaults (80 VGPRs, no scratch); the others are left
-// to the compiler
+// The register cap is the measured optimum of the instantiation that is a default (<5>: 80 VGPRs, no scratch); the others are
+// left to the compiler (the cap would cost <2> eight bytes of scratch).
 template <int MODE>
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner) { trace_replace<MODE>(sc, st, pp, refill, max_inner); }
 template <>
 __global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_TRACE_R_WAVES)))
 k_trace_r<5>(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner) { trace_replace<5>(sc, st, pp, refill, max_inner); }
-template <>
-__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_TRACE_R_WAVES)))
-k_trace_r<6>(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner) { trace_replace<6>(sc, st, pp, refill, max_inner); }
-
-// ------------------------------------------------------------------------------------------
-// k_trace_v: lane replacement over the mode-6 tree with VOTED steps.  Every iteration of the wave is one step of ONE kind — a
-// node visit or a leaf record — and the kind is the one more lanes are waiting for (a leaf step when at least `leaf_pct` per cent
-// of the ray-holding lanes hold a leaf): the fixed schedule of k_trace_r (up to four node steps, then the leaves) runs its node
-// steps with 54 % and its triangle steps with 48 % of the ray-holding lanes.  Refill and retirement are checked every step.
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_TRACE_R_WAVES)))
-k_trace_v(DeviceScene sc, PathState st, PassParams pp, int refill, int leaf_pct) {
-    extern __shared__ float4 lds_dyn[];
-    uint32_t *stack_base = (uint32_t *) lds_dyn;
-    const LaneStack<true> stack = lane_stack<6>(sc, stack_base, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x, (size_t) gridDim.x * MSK_BLOCK);
-    const uint32_t lwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
-    const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
-    if (lwave >= pp.region_count) return;
-    const uint32_t wave = pp.region_first + lwave;
-    const RegionView rv = region_view(wave, pp.region_size, pp.regions[wave].count, pp.regions[wave].half_ns);
-    const __amdgpu_buffer_rsrc_t rs = tree6_rsrc(sc);
-    const uint32_t n = rv.n;
-    uint32_t next = 0;
-    bool active = false, shadow_phase = false;
-    uint32_t slot = 0, unocc = 0;
-    TravState t;
-    t.cur = 0xffffffffu; t.sp = 0;
-    for (;;) {
-        const unsigned long long idle = __ballot(!active);
-        if (next < n && idle != 0ull && ((int) __popcll(idle) >= refill || idle == ~0ull)) {
-            if (!active) {
-                const uint32_t c = next + (uint32_t) __popcll(idle & ((1ull << lane) - 1ull));
-                if (c < n) {
-                    slot = rv.slot(c);
-                    const float4 ro = st.ray_o[slot];
-                    float4 rd = st.ray_d[slot];
-                    shadow_phase = c < rv.ns;
-                    rd.w = slot_tmax(rd.w);
-                    unocc = 0; active = true;
-                    if (shadow_phase) {
-                        const float4 s = st.sh[slot];
-                        *(float4 *) (stack.scratch + 4) = rd;
-                        trav_begin(t, sc.root_ref4, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(s.x, s.y, s.z), ro.w, s.w);
-                    } else {
-                        trav_begin(t, sc.root_ref4, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
-                    }
-                }
-            }
-            next += (uint32_t) __popcll(idle);
-        }
-        const unsigned long long act = __ballot(active);
-        if (act == 0ull) break;
-        MSK_CNT_WAVE(1);
-        if (active) MSK_CNT(2, 1);
-        const bool is_leaf = active && (t.cur & MSK_LEAF_BIT) != 0u && t.cur != 0xffffffffu;
-        const bool is_node = active && (t.cur & MSK_LEAF_BIT) == 0u;
-        const int n_leaf = __popcll(__ballot(is_leaf)), n_node = __popcll(__ballot(is_node));
-        bool occ = false;
-        if (n_leaf * 100 >= (n_leaf + n_node) * leaf_pct && n_leaf > 0) { if (is_leaf) occ = trav_leaf6(rs, sc.tri_pad, t, stack, shadow_phase); }
-        else if (is_node) trav_node6(rs, t, stack);
-        if (active && t.cur == 0xffffffffu) {
-            MSK_CNT(0, 1);
-            if (shadow_phase) {
-                unocc = occ ? 0u : MSK_HIT_UNOCCLUDED;
-                shadow_phase = false;
-                const float4 e = *(const float4 *) (stack.scratch + 4);
-                trav_begin(t, sc.root_ref4, sc.n_tris, t.o, mk3(e.x, e.y, e.z), t.tmin, e.w);
-            } else {
-                const bool valid = (t.bp != MSK_NO_PRIM) && (t.bt != t.tmax);
-                st.hit[slot] = make_float4(valid ? t.bt : MSK_INF_F, t.bu, t.bv, __uint_as_float((valid ? t.bp : MSK_PRIM_MASK) | unocc));
-                active = false;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_trace_p: the mode-6 tree walked by a wave out of a RAY POOL in LDS.  In k_trace_r a ray lives in a lane's registers, so
-// a step of the wave — a node visit or a triangle test — only occupies the lanes whose ray wants that kind of step next:
-// 54 % / 48 % of the ray-holding lanes on the mesh scenes, and the kernels are bound by VALU issue.  Here a
-// wave keeps P rays (96) in LDS — origin, direction, reciprocal direction, bounds, best hit, 64 bytes, and an S-entry stack —
-// and two ring buffers of work items {node or leaf reference, ray, stack pointer}; a step takes up to 64 items of ONE kind (the
-// kind with more items waiting), so that both kinds of step run nearly full, and sorts the items it produces back into the two
-// rings with ballots and prefix counts (no atomics).  A finished ray's slot in the pool is refilled by the same lane with the
-// region's next ray.  Shadow rays first (any-hit code, results in an LDS bit per slot), then the extension rays (closest hit),
-// as k_trace_q does.  The arithmetic of a ray's visits and tests — and their order — is k_trace_r<6>'s: same hits, bit for bit.
-// ------------------------------------------------------------------------------------------
-#define MSK_POOL_RING 128u             /* ring capacity (a power of two >= P) */
-struct PoolLds {
-    float4 *q0, *q1, *q2, *q3;         // [P]: {o, tmin} {d, tfar} {idir, t of the best hit (any-hit: tfar)} {u, v, prim, job index}
-    uint32_t *stk;                     // [S][P]
-    uint2 *qn, *ql;                    // rings of items {reference, ray | stack pointer << 8}: nodes, leaves
-    uint32_t *bits;                    // one bit per slot of the region: "the shadow ray was unoccluded"
-};
-struct PoolStack {
-    uint32_t *lds, *ovf; int cap; uint32_t stride; size_t ovf_stride;      // entry k of this ray: lds[k * stride] for k < cap, else ovf[(k - cap) * ovf_stride]
-    uint32_t *scratch;                 // 4 words of this LANE (node4q_visit's child references)
-    MSK_DEV void push(int &sp, uint32_t v) const {
-        if (sp < cap) lds[sp * stride] = v; else ovf[(size_t) (sp - cap) * ovf_stride] = v;
-        sp += 1;
-    }
-    MSK_DEV uint32_t pop(int &sp) const {
-        sp -= 1;
-        return sp < cap ? lds[sp * stride] : ovf[(size_t) (sp - cap) * ovf_stride];
-    }
-};
-template <bool ANY>
-MSK_DEV void pool_pass(const DeviceScene &sc, const PathState &st, const RegionView &rv, const PoolLds &L, uint32_t P, int S,
-                       uint32_t *ovf, size_t ovf_stride, uint32_t *scratch, uint32_t n_jobs, uint32_t lane) {
-    const uint32_t DONE = 0xffffffffu, RM = MSK_POOL_RING - 1u;
-    const __amdgpu_buffer_rsrc_t rs = tree6_rsrc(sc);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t next = 0, hn = 0, tn = 0, hl = 0, tl = 0;        // wave-uniform: jobs handed out; heads / tails of the rings (free-running)
-    int free_a = (int) lane, free_b = lane + 64u < P ? (int) (lane + 64u) : -1;       // pool entries of this lane that hold no ray
-    if (lane >= P) free_a = -1;
-    for (;;) {
-        wave_sync();                 // the items and ray records written by the last step, before anyone reads them
-        // ---- rays for the free entries
-        if (next < n_jobs) {
-            const bool want = free_a >= 0;
-            const unsigned long long m = __ballot(want);
-            if (m != 0ull) {
-                const uint32_t j = next + (uint32_t) __popcll(m & lt);
-                const bool got = want && j < n_jobs;
-                if (got) {
-                    const uint32_t slot = rv.slot(j);           // any-hit pass: jobs are the slots c < ns; closest-hit pass: every live slot
-                    const float4 ro = st.ray_o[slot];
-                    const float4 rd = ANY ? st.sh[slot] : st.ray_d[slot];
-                    const float tfar = ANY ? rd.w : slot_tmax(rd.w);
-                    const f3 idir = slab_idir(mk3(rd.x, rd.y, rd.z));
-                    L.q0[free_a] = ro;
-                    L.q1[free_a] = make_float4(rd.x, rd.y, rd.z, tfar);
-                    L.q2[free_a] = make_float4(idir.x, idir.y, idir.z, tfar);
-                    L.q3[free_a] = make_float4(0.f, 0.f, __uint_as_float(MSK_NO_PRIM), __uint_as_float(j));
-                }
-                const unsigned long long g = __ballot(got);
-                if (got) L.qn[(tn + (uint32_t) __popcll(g & lt)) & RM] = make_uint2(sc.root_ref4, (uint32_t) free_a);
-                if (got) free_a = -1;
-                tn += (uint32_t) __popcll(g);
-                next += (uint32_t) __popcll(m);
-                wave_sync();
-            }
-        }
-        if (free_a < 0 && free_b >= 0) { free_a = free_b; free_b = -1; }
-        const uint32_t cn = tn - hn, cl = tl - hl;
-        if (cn + cl == 0u) {
-            if (next < n_jobs && __ballot(free_a >= 0) != 0ull) continue;      // (the second initial entries)
-            break;
-        }
-        // ---- one step: up to 64 items of the kind with more items waiting
-        const bool leaf_step = cn == 0u || cl >= 64u || cl > cn;
-        MSK_CNT_WAVE(1);
-        uint32_t cur = DONE, tag = 0;
-        bool valid;
-        if (leaf_step) {
-            const uint32_t m = cl < 64u ? cl : 64u;
-            valid = lane < m;
-            if (valid) { const uint2 it = L.ql[(hl + lane) & RM]; cur = it.x; tag = it.y; }
-            hl += m;
-        } else {
-            const uint32_t m = cn < 64u ? cn : 64u;
-            valid = lane < m;
-            if (valid) { const uint2 it = L.qn[(hn + lane) & RM]; cur = it.x; tag = it.y; }
-            hn += m;
-        }
-        const uint32_t e = tag & 0xffu;
-        bool occluded = false;
-        TravState t;
-        t.cur = cur; t.sp = (int) (tag >> 8);
-        const PoolStack stack{L.stk + e, ovf + e, S, P, ovf_stride, scratch};
-        if (valid) {
-            MSK_CNT(2, 1);
-            const float4 a = L.q0[e], c = L.q2[e];
-            t.o = mk3(a.x, a.y, a.z); t.tmin = a.w; t.idir = mk3(c.x, c.y, c.z); t.bt = c.w;
-            if (!leaf_step) {
-                t.selq = make_sel4q(t.idir);
-                t.oi = mk3(t.o.x * t.idir.x, t.o.y * t.idir.y, t.o.z * t.idir.z);
-                trav_node6(rs, t, stack);
-            } else {
-                const float4 b = L.q1[e];
-                t.d = mk3(b.x, b.y, b.z); t.tmax = b.w;
-                t.bu = 0.f; t.bv = 0.f;
-                if (ANY) t.bp = MSK_NO_PRIM; else t.bp = __float_as_uint(L.q3[e].z);
-                const uint32_t bp0 = t.bp; const float bt0 = t.bt;
-                occluded = trav_leaf6(rs, sc.tri_pad, t, stack, ANY);
-                if (!ANY && (t.bp != bp0 || t.bt != bt0)) {          // a closer hit (or the first one)
-                    ((float *) &L.q2[e])[3] = t.bt;
-                    float *h = (float *) &L.q3[e];
-                    h[0] = t.bu; h[1] = t.bv; h[2] = __uint_as_float(t.bp);
-                }
-            }
-        }
-        // ---- the items this step produced, back into the rings
-        const bool fin = valid && t.cur == DONE;
-        const bool to_leaf = valid && !fin && (t.cur & MSK_LEAF_BIT) != 0u;
-        const bool to_node = valid && !fin && (t.cur & MSK_LEAF_BIT) == 0u;
-        const unsigned long long bn = __ballot(to_node), bl = __ballot(to_leaf);
-        const uint2 item = make_uint2(t.cur, e | ((uint32_t) t.sp << 8));
-        if (to_node) L.qn[(tn + (uint32_t) __popcll(bn & lt)) & RM] = item;
-        if (to_leaf) L.ql[(tl + (uint32_t) __popcll(bl & lt)) & RM] = item;
-        tn += (uint32_t) __popcll(bn); tl += (uint32_t) __popcll(bl);
-        // ---- finished rays
-        if (fin) {
-            MSK_CNT(0, 1);
-            const uint32_t j = __float_as_uint(L.q3[e].w);
-            if (ANY) { if (!occluded) atomicOr(&L.bits[j >> 5], 1u << (j & 31u)); }
-            else {
-                const float4 h = L.q3[e];
-                const float bt = L.q2[e].w, tfar = L.q1[e].w;
-                const uint32_t bp = __float_as_uint(h.z);
-                const bool hit = (bp != MSK_NO_PRIM) && (bt != tfar);                   // scene.cpp:234 tfar != maxt
-                const uint32_t unocc = ((L.bits[j >> 5] >> (j & 31u)) & 1u) ? MSK_HIT_UNOCCLUDED : 0u;
-                st.hit[rv.slot(j)] = make_float4(hit ? bt : MSK_INF_F, h.x, h.y, __uint_as_float((hit ? bp : MSK_PRIM_MASK) | unocc));
-            }
-            if (free_a >= 0) free_b = free_a;          // (a second initial entry still waiting for its first ray)
-            free_a = (int) e;
-        }
-    }
-}
-__global__ void __launch_bounds__(MSK_WAVE)
-k_trace_p(DeviceScene sc, PathState st, PassParams pp, uint32_t P, int S) {
-    extern __shared__ float4 lds_dyn[];
-    const uint32_t lwave = blockIdx.x, lane = threadIdx.x;
-    if (lwave >= pp.region_count) return;
-    PoolLds L;
-    L.q0 = lds_dyn; L.q1 = L.q0 + P; L.q2 = L.q1 + P; L.q3 = L.q2 + P;
-    L.qn = (uint2 *) (L.q3 + P); L.ql = L.qn + MSK_POOL_RING;
-    uint32_t *scratch = (uint32_t *) (L.ql + MSK_POOL_RING) + lane * 4u;
-    L.stk = (uint32_t *) (L.ql + MSK_POOL_RING) + MSK_WAVE * 4u;
-    L.bits = L.stk + (uint32_t) S * P;
-    const uint32_t wave = pp.region_first + lwave;
-    const RegionView rv = region_view(wave, pp.region_size, pp.regions[wave].count, pp.regions[wave].half_ns);
-    for (uint32_t i = lane; i < pp.region_size / 32u; i += MSK_WAVE) L.bits[i] = 0u;
-    uint32_t *ovf = pp.stack_ovf + (size_t) lwave * P;
-    const size_t ovf_stride = (size_t) gridDim.x * P;
-    pool_pass<true>(sc, st, rv, L, P, S, ovf, ovf_stride, scratch, rv.ns, lane);
-    wave_sync();
-    pool_pass<false>(sc, st, rv, L, P, S, ovf, ovf_stride, scratch, rv.n, lane);
-}
 
 // tris (4 x float4: v0|prim, e1, e2, Ng) -> tris3 (3 x float4: v0|prim, e1|e2.x, e2.y e2.z - -), at scene creation
 __global__ void __launch_bounds__(MSK_BLOCK) k_pack_tris3(const float4 *tris, uint32_t n, float4 *out) {
@@ -1439,7 +1079,9 @@ k_trace_batch(DeviceScene sc, const float4 *rays, uint64_t n, float4 *out_hit, u
     uint32_t *stack_base = (uint32_t *) lds_dyn;
     float4 *scene_lds = lds_dyn + (sc.stack_entries * MSK_BLOCK) / 4;
     TraceLds g = stage_scene(sc, scene_lds, LDS_SCENE, MODE == 3);
-    const LaneStack<MSK_OVF(MODE)> stack = lane_stack<MODE>(sc, stack_base, stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x, (size_t) gridDim.x * MSK_BLOCK);
+    const LaneStack<MSK_OVF(MODE)> stack{stack_base + threadIdx.x, stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
+                                     (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK,
+                                     MSK_OVF(MODE) ? stack_base + sc.stack_entries * MSK_BLOCK + threadIdx.x * 4 : nullptr};
     for (uint64_t i = (uint64_t) blockIdx.x * MSK_BLOCK + threadIdx.x; i < n; i += (uint64_t) gridDim.x * MSK_BLOCK) {
         const float4 ro = rays[2 * i], rd = rays[2 * i + 1];
         float bt, bu, bv; uint32_t bp;

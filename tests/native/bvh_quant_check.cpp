@@ -8,8 +8,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
-#include <algorithm>
-#include <utility>
 #include <vector>
 #include "../../misaki-render_amd/csrc/msk_bvh.h"
 
@@ -62,35 +60,6 @@ int main(int argc, char **argv) {
             if (q[12 + i] != refs[i]) { printf("FAIL node %zu child %d: reference differs\n", m, i); return 1; }
             const double A = e[0] * e[1] + e[1] * e[2] + e[2] * e[0], Aq = eq[0] * eq[1] + eq[1] * eq[2] + eq[2] * eq[0];
             if (A > 0) { area_ratio += Aq / A; ++children; }
-        }
-    }
-    // treetop_first: a renumbering only — the same tree (boxes, quantised twins, leaf references) with the treetop at [0, got)
-    {
-        const uint32_t n_top = argc > 4 ? (uint32_t) atoi(argv[4]) : 128u;
-        mskbvh::Built c = b;
-        const uint32_t got = mskbvh::treetop_first(c, n_top);
-        if (nn && !(b.root_ref4 & 0x80000000u)) {
-            if (got != std::min<size_t>(n_top, nn) || (got && c.root_ref4 != 0)) { printf("FAIL treetop_first: %u of %u nodes, root %u\n", got, n_top, c.root_ref4); return 1; }
-            std::vector<uint32_t> image(nn, 0xffffffffu); std::vector<char> seen(nn, 0);
-            std::vector<std::pair<uint32_t, uint32_t>> todo{{b.root_ref4, c.root_ref4}};
-            size_t visited = 0;
-            while (!todo.empty()) {
-                const auto [x, y] = todo.back(); todo.pop_back();
-                if (y >= nn || seen[y]) { printf("FAIL treetop_first: node %u reached twice / out of range\n", y); return 1; }
-                seen[y] = 1; image[x] = y; ++visited;
-                if (memcmp(&b.nodes4[(size_t) x * 32], &c.nodes4[(size_t) y * 32], 96) || memcmp(&b.nodes4q[(size_t) x * 16], &c.nodes4q[(size_t) y * 16], 48)) {
-                    printf("FAIL treetop_first: boxes of node %u -> %u differ\n", x, y); return 1; }
-                const uint32_t *rx = (const uint32_t *) &b.nodes4[(size_t) x * 32 + 24], *ry = (const uint32_t *) &c.nodes4[(size_t) y * 32 + 24];
-                const uint32_t *qy = &c.nodes4q[(size_t) y * 16 + 12];
-                for (int i = 0; i < 4; ++i) {
-                    const bool inner = rx[i] != mskbvh::kEmpty4 && !(rx[i] & 0x80000000u);
-                    if (!inner) { if (ry[i] != rx[i]) { printf("FAIL treetop_first: leaf reference of node %u slot %d changed\n", x, i); return 1; } continue; }
-                    if ((ry[i] & 0x80000000u) || qy[i] != ry[i]) { printf("FAIL treetop_first: node %u slot %d\n", y, i); return 1; }
-                    if (y >= got && ry[i] < got) { printf("FAIL treetop_first: treetop node %u below node %u\n", ry[i], y); return 1; }     // the treetop is connected
-                    todo.push_back({rx[i], ry[i]});
-                }
-            }
-            if (visited != nn) { printf("FAIL treetop_first: %zu of %zu nodes reachable\n", visited, nn); return 1; }
         }
     }
     printf("ok nodes %zu children %zu unused_slots %zu mean_area_ratio %.5f depth4 %d\n", nn, children, empty, children ? area_ratio / children : 1.0, b.max_depth4);

@@ -187,10 +187,7 @@ def test_large_mesh_uses_hbm_bvh(gpu_ctx, abi, hostmirror, oracle, golden_lookup
 @pytest.mark.parametrize("env", [dict(MSK_TRACE_REFILL="0"), dict(MSK_WIDE_BVH="0"), dict(MSK_WIDE_BVH="0", MSK_TRACE_REFILL="0"),
                                  dict(MSK_TRACE_REFILL="48", MSK_TRACE_QUANTUM="1"), dict(MSK_LDS_SCENE_KB="0", MSK_WIDE_BVH="0"),
                                  dict(MSK_STACK_CAP="4"), dict(MSK_STACK_CAP="4", MSK_TRACE_REFILL="0", MSK_WIDE_BVH="0"),
-                                 dict(MSK_UNIFIED_TREE="0"), dict(MSK_UNIFIED_TREE="0", MSK_TRACE_REFILL="0"), dict(MSK_TRACE_QUANTUM="1", MSK_STACK_CAP="4"),
-                                 dict(MSK_BVH_LEAF="1"), dict(MSK_BVH_LEAF="4", MSK_TRACE_QUANTUM="7"),
-                                 dict(MSK_UNIFIED_TREE="0", MSK_TREETOP="0"), dict(MSK_UNIFIED_TREE="0", MSK_TREETOP="1"), dict(MSK_UNIFIED_TREE="0", MSK_TREETOP="37", MSK_TRACE_REFILL="0"),
-                                 dict(MSK_UNIFIED_TREE="0", MSK_TREETOP="100000", MSK_STACK_CAP="4"), dict(MSK_UNIFIED_TREE="0", MSK_TREETOP="300", MSK_BVH_BUILD="gpu"),
+                                 dict(MSK_COLLAPSE_OPTIMAL="0"), dict(MSK_COLLAPSE_OPTIMAL="0", MSK_QUANT_BVH="0", MSK_TRACE_REFILL="0"),
                                  dict(MSK_WIDE_LDS="1", MSK_TRACE_REFILL="0"),
                                  dict(MSK_QUANT_BVH="0"), dict(MSK_QUANT_BVH="0", MSK_TRACE_REFILL="0"), dict(MSK_QUANT_BVH="0", MSK_STACK_CAP="4"),
                                  dict(MSK_BVH_BUILD="gpu", MSK_QUANT_BVH="0"),

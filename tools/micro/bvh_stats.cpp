@@ -1,6 +1,6 @@
 // Host-side traversal statistics of the 4-wide quantised tree (msk_bvh.h), used to plan the layout the traversal kernel reads:
 //   g++ -O2 -std=c++17 -ffp-contract=off -I misaki-render_amd/csrc tools/micro/bvh_stats.cpp -o gpurun_scratch/bvh_stats
-//   gpurun_scratch/bvh_stats positions.bin [n_rays] [n_top]
+//   gpurun_scratch/bvh_stats positions.bin [n_rays]
 // positions.bin: 9 floats per triangle (tools/dump_positions.py).  Rays: area-weighted surface points, cosine-distributed
 // directions (the bounce rays of a path tracer), closest-hit traversal with the kernel's visiting order.
 // Prints: node visits / leaf visits / triangle tests per ray, the share of node visits that fall on the first N nodes in
@@ -63,9 +63,7 @@ int main(int argc, char **argv) {
     Box all; for (uint32_t i = 0; i < n * 3; ++i) all.grow(V3{pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]});
     const float diag = std::sqrt((all.hi.x - all.lo.x) * (all.hi.x - all.lo.x) + (all.hi.y - all.lo.y) * (all.hi.y - all.lo.y) + (all.hi.z - all.lo.z) * (all.hi.z - all.lo.z));
     Built b = build(pos.data(), n, 0.5e-4f * diag);
-    collapse4(b);
-    const uint32_t n_top = argc > 3 ? (uint32_t) atol(argv[3]) : 0u;          // > 0: msk_bvh.h's treetop_first numbering, and rank = index
-    if (n_top) std::printf("treetop_first(%u) -> %u\n", n_top, treetop_first(b, n_top));
+    collapse4(b, !getenv("GREEDY"));
     const uint32_t nn = (uint32_t) (b.nodes4.size() / 32);
     std::printf("%u triangles, %u 4-wide nodes (%.2f MB as 64-byte nodes), depth %d, triangles %.2f MB as 48-byte records\n", n, nn, nn * 64 / 1e6, b.max_depth4, n * 48 / 1e6);
     // breadth-first rank of every node
@@ -73,7 +71,7 @@ int main(int argc, char **argv) {
     {
         std::queue<uint32_t> q; q.push(b.root_ref4); uint32_t r = 0;
         while (!q.empty()) {
-            const uint32_t u = q.front(); q.pop(); rank[u] = n_top ? u : r++;
+            const uint32_t u = q.front(); q.pop(); rank[u] = r++;
             const uint32_t *refs = (const uint32_t *) &b.nodes4[(size_t) u * 32 + 24];
             for (int i = 0; i < 4; ++i) if (refs[i] != kEmpty4 && !(refs[i] & 0x80000000u)) { depth[refs[i]] = depth[u] + 1; q.push(refs[i]); }
         }
