@@ -60,95 +60,125 @@ MSK_DEV bool any_nonzero(spec a) { return a.v[0] != 0.f || a.v[1] != 0.f || a.v[
 #define MSK_INF_F       __builtin_inff()
 
 // ------------------------------------------------------------------ det_* transcendentals
-MSK_DEV double det_sin_poly(double y) {
-    double z = y * y;
-    double p = -1.0 / 355687428096000.0;
-    p = p * z + 1.0 / 1307674368000.0;
-    p = p * z - 1.0 / 6227020800.0;
-    p = p * z + 1.0 / 39916800.0;
-    p = p * z - 1.0 / 362880.0;
-    p = p * z + 1.0 / 5040.0;
-    p = p * z - 1.0 / 120.0;
-    p = p * z + 1.0 / 6.0;
-    return y - y * z * p;
+// (oracle/oracle_math.h holds the same functions, operation for operation: rule R3 of the numerics contract)
+MSK_DEV uint64_t msk_bits(double x) { return (uint64_t) __double_as_longlong(x); }
+MSK_DEV double msk_from_bits(uint64_t b) { return __longlong_as_double((long long) b); }
+// The polynomial coefficients live in constant memory and are fetched by scalar loads next to their use: as immediates they sit
+// in ~90 SGPRs across the whole shading sweep (a v_fma_f64 takes its constant from an SGPR pair), which spills SGPRs into VGPR
+// lanes and costs the shading kernel a wave per SIMD.  Same values as oracle_math.h's literals (both are the compiler's
+// correctly rounded quotients).
+__constant__ double msk_det_sin[8] = {-1.0 / 355687428096000.0, 1.0 / 1307674368000.0, -1.0 / 6227020800.0, 1.0 / 39916800.0,
+                                      -1.0 / 362880.0, 1.0 / 5040.0, -1.0 / 120.0, 1.0 / 6.0};
+__constant__ double msk_det_cos[8] = {1.0 / 20922789888000.0, -1.0 / 87178291200.0, 1.0 / 479001600.0, -1.0 / 3628800.0,
+                                      1.0 / 40320.0, -1.0 / 720.0, 1.0 / 24.0, -0.5};
+__constant__ double msk_det_ath[9] = {1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0, 1.0 / 5.0, 1.0 / 3.0};
+__constant__ double msk_det_che[6] = {1.0 / 479001600.0, 1.0 / 3628800.0, 1.0 / 40320.0, 1.0 / 720.0, 1.0 / 24.0, 0.5};
+__constant__ double msk_det_cho[6] = {1.0 / 6227020800.0, 1.0 / 39916800.0, 1.0 / 362880.0, 1.0 / 5040.0, 1.0 / 120.0, 1.0 / 6.0};
+// Every polynomial step is ONE fused multiply-add (IEEE fma: one rounding, the same bits from std::fma on the host and
+// v_fma_f64 on the device, whatever -ffp-contract says); the series are cut where the next term is below 2e-16 of the result on
+// the reduced range, i.e. the fp64 value is accurate to a few ulps of a double before its single rounding to fp32.
+MSK_DEV double det_sin_poly(double y) {   // |y| <= pi/4 (+ulps): y - y z (1/3! - z/5! + ... ), z = y^2; next term (pi/4)^19/19! = 8e-20
+    const double z = y * y;
+    double p = msk_det_sin[0];                    // -1/17!
+    p = __builtin_fma(p, z, msk_det_sin[1]);                 //  1/15!
+    p = __builtin_fma(p, z, msk_det_sin[2]);                   // -1/13!
+    p = __builtin_fma(p, z, msk_det_sin[3]);                      //  1/11!
+    p = __builtin_fma(p, z, msk_det_sin[4]);                       // -1/9!
+    p = __builtin_fma(p, z, msk_det_sin[5]);                          //  1/7!
+    p = __builtin_fma(p, z, msk_det_sin[6]);                          // -1/5!
+    p = __builtin_fma(p, z, msk_det_sin[7]);                             //  1/3!   (sign folded below)
+    return __builtin_fma(-(y * z), p, y);
 }
-MSK_DEV double det_cos_poly(double y) {
-    double z = y * y;
-    double p = 1.0 / 20922789888000.0;
-    p = p * z - 1.0 / 87178291200.0;
-    p = p * z + 1.0 / 479001600.0;
-    p = p * z - 1.0 / 3628800.0;
-    p = p * z + 1.0 / 40320.0;
-    p = p * z - 1.0 / 720.0;
-    p = p * z + 1.0 / 24.0;
-    p = p * z - 0.5;
-    return 1.0 + z * p;
+MSK_DEV double det_cos_poly(double y) {   // next term (pi/4)^18/18! = 2e-18
+    const double z = y * y;
+    double p = msk_det_cos[0];                      //  1/16!
+    p = __builtin_fma(p, z, msk_det_cos[1]);                  // -1/14!
+    p = __builtin_fma(p, z, msk_det_cos[2]);                     //  1/12!
+    p = __builtin_fma(p, z, msk_det_cos[3]);                      // -1/10!
+    p = __builtin_fma(p, z, msk_det_cos[4]);                         //  1/8!
+    p = __builtin_fma(p, z, msk_det_cos[5]);                          // -1/6!
+    p = __builtin_fma(p, z, msk_det_cos[6]);                            //  1/4!
+    p = __builtin_fma(p, z, msk_det_cos[7]);                                  // -1/2!
+    return __builtin_fma(z, p, 1.0);
+}
+// quadrant reduction of an fp32 angle (|phi| < 2^20 pi/2): phi = k pi/2 + y, |y| <= pi/4
+MSK_DEV double det_reduce_pio2(float phi, long long *k_out) {
+    const double two_over_pi = 0.63661977236758134308;
+    const double pio2_hi = 1.57079632679489655800e+00;   // pi/2 rounded to double
+    const double pio2_lo = 6.12323399573676603587e-17;   // pi/2 - pio2_hi
+    const double x = (double) phi;
+    const double k = __builtin_rint(x * two_over_pi);
+    *k_out = (long long) k;
+    return __builtin_fma(-k, pio2_lo, __builtin_fma(-k, pio2_hi, x));
 }
 MSK_DEV void det_sincos(float phi, float *s, float *c) {
-    const double two_over_pi = 0.63661977236758134308;
-    const double pio2_hi = 1.57079632679489655800e+00;
-    const double pio2_lo = 6.12323399573676603587e-17;
-    double x = (double) phi;
-    double k = __builtin_rint(x * two_over_pi);
-    double y = (x - k * pio2_hi) - k * pio2_lo;
-    int q = (int) ((long long) k & 3);
-    double sy = det_sin_poly(y), cy = det_cos_poly(y);
+    long long k;
+    const double y = det_reduce_pio2(phi, &k);
+    const int q = (int) (k & 3);
+    const double sy = det_sin_poly(y);
+    __builtin_amdgcn_sched_barrier(0);          // one polynomial at a time: interleaved, the two fma chains cost the shading kernel 24 VGPRs (a wave per SIMD)
+    const double cy = det_cos_poly(y);
     double sv = (q & 1) ? cy : sy, cv = (q & 1) ? sy : cy;
     if (q == 1 || q == 2) cv = -cv;
     if (q >= 2) sv = -sv;
     *s = (float) sv; *c = (float) cv;
 }
-MSK_DEV double det_log(double x) {
-    uint64_t b = (uint64_t) __double_as_longlong(x);
-    int e = (int) ((b >> 52) & 0x7ff) - 1023;
-    b = (b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
-    double m = __longlong_as_double((long long) b);
-    if (m > 1.41421356237309514547) { m = m * 0.5; e += 1; }
-    double s = (m - 1.0) / (m + 1.0), z = s * s;
-    double p = 1.0 / 21.0;
-    p = p * z + 1.0 / 19.0;
-    p = p * z + 1.0 / 17.0;
-    p = p * z + 1.0 / 15.0;
-    p = p * z + 1.0 / 13.0;
-    p = p * z + 1.0 / 11.0;
-    p = p * z + 1.0 / 9.0;
-    p = p * z + 1.0 / 7.0;
-    p = p * z + 1.0 / 5.0;
-    p = p * z + 1.0 / 3.0;
-    p = p * z + 1.0;
-    return (double) e * 0.69314718055994528623 + 2.0 * s * p;
+// atanh of an fp32 x in (-1, 1): 1/2 ln((1 + x) / (1 - x)) with ONE division — N = 1 + x and D = 1 - x are exact in fp64; with
+// N = 2^a n, D = 2^b d (n, d in [1, 2), one of them halved when n / d leaves [1/sqrt 2, sqrt 2]) it is
+// (a - b) ln2 / 2 + s (1 + z/3 + z^2/5 + ... + z^9/19), s = (n - d) / (n + d) (numerator and denominator exact), z = s^2 <= 0.0295:
+// the next term, z^10 / 21, is below 3e-17.
+MSK_DEV double det_atanh_d(double xd) {
+    const double N = 1.0 + xd, D = 1.0 - xd;
+    uint64_t bn = msk_bits(N), bd = msk_bits(D);
+    int e = (int) ((bn >> 52) & 0x7ff) - (int) ((bd >> 52) & 0x7ff);
+    double n = msk_from_bits((bn & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+    double d = msk_from_bits((bd & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+    const double r2 = 1.41421356237309514547;
+    if (n > r2 * d) { n = n * 0.5; e += 1; }
+    else if (d > r2 * n) { d = d * 0.5; e -= 1; }
+    const double s = (n - d) / (n + d), z = s * s;
+    double p = msk_det_ath[0];
+    p = __builtin_fma(p, z, msk_det_ath[1]);
+    p = __builtin_fma(p, z, msk_det_ath[2]);
+    p = __builtin_fma(p, z, msk_det_ath[3]);
+    p = __builtin_fma(p, z, msk_det_ath[4]);
+    p = __builtin_fma(p, z, msk_det_ath[5]);
+    p = __builtin_fma(p, z, msk_det_ath[6]);
+    p = __builtin_fma(p, z, msk_det_ath[7]);
+    p = __builtin_fma(p, z, msk_det_ath[8]);
+    p = __builtin_fma(p, z, 1.0);
+    return __builtin_fma((double) e, 0.5 * 0.69314718055994528623, s * p);
 }
-MSK_DEV double det_exp(double y) {
+// cosh of an fp32 x (|x| < 700) without a division: x = k ln2 + r, |r| <= ln2 / 2; e^(+-r) = E(r^2) +- r O(r^2) with the even and
+// the odd half of the exponential series (through r^12 / 12! and r^13 / 13!: the next terms are below 5e-18), and
+// cosh x = (2^k (E + r O) + 2^-k (E - r O)) / 2, the powers of two applied exactly.
+MSK_DEV double det_cosh_d(double xd) {
     const double inv_ln2 = 1.44269504088896338700;
-    const double ln2_hi = 6.93147180369123816490e-01;
-    const double ln2_lo = 1.90821492927058770002e-10;
-    double k = __builtin_rint(y * inv_ln2);
-    double r = (y - k * ln2_hi) - k * ln2_lo;
-    double p = 1.0 / 6227020800.0;
-    p = p * r + 1.0 / 479001600.0;
-    p = p * r + 1.0 / 39916800.0;
-    p = p * r + 1.0 / 3628800.0;
-    p = p * r + 1.0 / 362880.0;
-    p = p * r + 1.0 / 40320.0;
-    p = p * r + 1.0 / 5040.0;
-    p = p * r + 1.0 / 720.0;
-    p = p * r + 1.0 / 120.0;
-    p = p * r + 1.0 / 24.0;
-    p = p * r + 1.0 / 6.0;
-    p = p * r + 0.5;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
-    uint64_t b = (uint64_t) ((long long) k + 1023) << 52;
-    return p * __longlong_as_double((long long) b);
+    const double ln2_hi  = 6.93147180369123816490e-01;
+    const double ln2_lo  = 1.90821492927058770002e-10;
+    const double k = __builtin_rint(xd * inv_ln2);
+    const double r = __builtin_fma(-k, ln2_lo, __builtin_fma(-k, ln2_hi, xd)), w = r * r;
+    double E = msk_det_che[0];             // 1/12!
+    E = __builtin_fma(E, w, msk_det_che[1]);
+    E = __builtin_fma(E, w, msk_det_che[2]);
+    E = __builtin_fma(E, w, msk_det_che[3]);
+    E = __builtin_fma(E, w, msk_det_che[4]);
+    E = __builtin_fma(E, w, msk_det_che[5]);
+    E = __builtin_fma(E, w, 1.0);
+    double O = msk_det_cho[0];            // 1/13!
+    O = __builtin_fma(O, w, msk_det_cho[1]);
+    O = __builtin_fma(O, w, msk_det_cho[2]);
+    O = __builtin_fma(O, w, msk_det_cho[3]);
+    O = __builtin_fma(O, w, msk_det_cho[4]);
+    O = __builtin_fma(O, w, msk_det_cho[5]);
+    O = __builtin_fma(O, w, 1.0);
+    const double ro = r * O;
+    const long long ki = (long long) k;
+    const double up = msk_from_bits((uint64_t) (ki + 1023) << 52), dn = msk_from_bits((uint64_t) (1023 - ki) << 52);
+    return 0.5 * ((E + ro) * up + (E - ro) * dn);
 }
-MSK_DEV float det_atanh(float x) {
-    double xd = (double) x;
-    return (float) (0.5 * det_log((1.0 + xd) / (1.0 - xd)));
-}
-MSK_DEV float det_cosh(float x) {
-    double e = det_exp((double) x);
-    return (float) (0.5 * (e + 1.0 / e));
-}
+MSK_DEV float det_atanh(float x) { return (float) det_atanh_d((double) x); }
+MSK_DEV float det_cosh(float x) { return (float) det_cosh_d((double) x); }
 
 // arctangent / tangent for the GGX azimuth (render/microfacet.h:23-26)
 MSK_DEV double det_atan_d(double z) {
@@ -173,15 +203,10 @@ MSK_DEV double det_atan_d(double z) {
 }
 MSK_DEV float det_atan(float z) { return (float) det_atan_d((double) z); }
 MSK_DEV float det_tan(float phi) {
-    const double two_over_pi = 0.63661977236758134308;
-    const double pio2_hi = 1.57079632679489655800e+00;
-    const double pio2_lo = 6.12323399573676603587e-17;
-    double x = (double) phi;
-    double k = __builtin_rint(x * two_over_pi);
-    double y = (x - k * pio2_hi) - k * pio2_lo;
-    int q = (int) ((long long) k & 1);
-    double sy = det_sin_poly(y), cy = det_cos_poly(y);
-    return (float) (q ? -cy / sy : sy / cy);
+    long long k;
+    const double y = det_reduce_pio2(phi, &k);
+    const double sy = det_sin_poly(y), cy = det_cos_poly(y);
+    return (float) ((k & 1) ? -cy / sy : sy / cy);
 }
 
 // ------------------------------------------------------------------ counter RNG

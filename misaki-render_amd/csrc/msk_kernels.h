@@ -1421,7 +1421,7 @@ MSK_DEV void emit_record(const DeviceScene &sc, const SceneTables &tb, const Pas
     const uint32_t j = pp.pix_to_j[pix];
     spec wgt;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) wgt.v[k] = wavelength_weight(wl.v[k]);
+    for (int k = 0; k < 4; ++k) { wgt.v[k] = wavelength_weight(wl.v[k]); __builtin_amdgcn_sched_barrier(0); }
     const spec result = res * wgt;
     float X, Y, Z;
     spectrum_to_xyz(tb.cie, result, wl, &X, &Y, &Z);
@@ -1813,7 +1813,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
         const float px = (float) pixel_x(sc, pt) + jit.x, py = (float) pixel_y(sc, pt) + jit.y;
         spec wl;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wl.v[q] = wavelength_of(wsample, q);
+        for (int q = 0; q < 4; ++q) { wl.v[q] = wavelength_of(wsample, q); __builtin_amdgcn_sched_barrier(0); }   // one fp64 chain at a time: interleaved they cost 28 VGPRs
         // PerspectiveCamera::sample_ray (perspective.cpp:22-42), Transform4f::apply_point/apply_vector
         float r4[4];
 #pragma unroll
@@ -1882,6 +1882,16 @@ k_shade_gen<false, false>(DeviceScene sc, PathState st, PassParams pp) { shade_g
 template <>
 __global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_shade_gen<true, false>(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<true, false>(sc, st, pp); }
+// The diffuse-only variants fit four waves per SIMD (128 VGPRs, no scratch); left alone, the allocator spends 24 more registers
+// on the explicit fp64 fma chains of det_sincos and lands at three.
+#ifndef MSK_NO_SHADE4
+template <>
+__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_shade_gen<false, true>(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<false, true>(sc, st, pp); }
+template <>
+__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_shade_gen<true, true>(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<true, true>(sc, st, pp); }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // k_wavefront: the iteration loop itself on the device, for scenes whose tree is staged in LDS.  A region is private to
