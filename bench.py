@@ -4,22 +4,30 @@ Cornell box at 512x512, 512 spp per GPU (BASELINE.json configs[1]), diffuse BSDF
 
     python bench.py --gpus N --steps K --warmup W
 
-A step = one complete render through the C ABI (msk_gpu_render_device): wavefront path tracing
-of every sample + the ordered film replay, film left in HBM.  Inputs (scene, BVH) are resident
-in HBM before the timed region.
+A step = one complete render through the C ABI: wavefront path tracing of every sample, the ordered film
+replay, and the film's copy-back to the host (SURVEY §8d: t_render "incl. final film copy-back";
+integrator.cpp:43-78 is the reference's timer scope).  Inputs (scene, BVH, tables) are resident in HBM
+before the timed region.  N = 1: the step is msk_gpu_render; the same K steps with the film left in HBM
+(msk_gpu_render_device) ride along as `value_film_in_hbm`.
 
-N > 1: one process per GPU.  Under torch.distributed.run (WORLD_SIZE set) this process is one rank;
-from a bare shell (`python bench.py --gpus 8`) this process only spawns the N ranks — before anything
-touches a GPU — waits for them and passes rank 0's JSON line on.  Rank r renders every tile for the
-sample indices s = r (mod N) of 512*N spp (`--shard samples`, the default; speed-proportional contiguous
-ranges when the GPUs differ) or the spiral blocks id = r (mod N) (`--shard tiles`): per-GPU work is
-constant (weak scaling), and the films are summed onto rank 0 with one RCCL reduce inside the timed region.
-Rank 0 prints ONE JSON line.
+N > 1: one process per GPU.  Under torch.distributed.run (WORLD_SIZE set) this process is one rank; from
+a bare shell (`python bench.py --gpus 8`) this process only spawns the N ranks — before anything touches
+a GPU — waits for them and passes rank 0's JSON line on.  Rank r renders every tile for the sample
+indices s = r (mod N) of 512*N spp (`--shard samples`, the default: per-GPU work is constant, weak
+scaling) or the spiral blocks id = r (mod N) (`--shard tiles`); the films are summed onto rank 0 with ONE
+RCCL reduce and rank 0 copies the sum to the host, all inside the timed region.  `--balance` re-splits
+the samples by measured speed after the warm-up (an extra, reported under config.balance; the equal split
+is the default).  A node with fewer than N visible GPUs ends the run with one line on stderr before any
+rendezvous.  Rank 0 prints ONE JSON line.
+
+`--in-process N`: the other multi-GPU path — ONE process, N devices behind one context of the C ABI
+(msk_gpu_init(ids, N): sample shards on member contexts, films summed over peer access by k_film_sum).
 
 `--dry-run` exercises the launch / rendezvous / reduce / timing plumbing without a GPU (gloo backend, a
 host tensor as the film, no render): what tests/test_bench_launch.py runs on CPU.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -49,14 +57,34 @@ def parse_args():
                     help="skip the config 3 / 4 / 5 class renders that N = 1 adds under `other_configs`")
     ap.add_argument("--shard", choices=("samples", "tiles"), default="samples",
                     help="N > 1: which axis the ranks split (misaki-render_amd/multigpu.py); both end in one film reduce")
-    ap.add_argument("--no-balance", action="store_true",
-                    help="N > 1: keep the equal interleaved sample split even when the GPUs differ in speed")
+    ap.add_argument("--balance", action="store_true",
+                    help="N > 1: after the warm-up, re-split the samples in proportion to the ranks' measured speed (default: equal split)")
+    ap.add_argument("--in-process", type=int, default=0, metavar="N",
+                    help="one process, N devices behind one msk_ctx (msk_gpu_init(ids, N) + k_film_sum) instead of one process per GPU")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: launch, rendezvous (gloo), reduce and timing only")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="N > 1 ranks that ALL render on cuda:0 and reduce over gloo through host copies of the film: the whole "
-                         "multi-process path but the RCCL call, on a one-GPU box (tests/test_bench_launch.py); its line says "
-                         "\"rehearsal\": true and is not a measurement")
+                    help="N > 1 ranks (or --in-process members) that ALL render on cuda:0, the ranks reducing over gloo through host "
+                         "copies of the film: the whole multi-GPU path but the RCCL call / the peer reads, on a one-GPU box "
+                         "(tests/test_bench_launch.py); its line says \"rehearsal\": true and is not a measurement")
     return ap.parse_args()
+
+
+def build_id():
+    """What the committed profiles are matched against: a hash of the sources the GPU library is built from."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "misaki-render_amd", "csrc")
+    for f in sorted(os.listdir(csrc)) + ["../../include/msk_gpu.h"]:
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def devices_seen():
+    """torch.cuda.device_count() does not initialise a GPU on this image (so the launcher may call it before it spawns)."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
 
 
 def launch_ranks(args):
@@ -65,6 +93,9 @@ def launch_ranks(args):
     error ends the others (a rank that dies before or inside the rendezvous would otherwise leave the rest waiting for the
     process-group timeout), and that rank's code is the exit code.  Returns the exit code for the shell."""
     import threading
+    if not args.dry_run and not args.rehearse_on_one_gpu and devices_seen() < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but this node shows {devices_seen()} GPU(s); nothing was launched", file=sys.stderr)
+        return 2
     # the port stays bound (SO_REUSEADDR on both sides) until just before the children start, which narrows the window in
     # which another process can take it; a rendezvous failure ends every rank through the watch loop below
     sock = socket.socket()
@@ -109,15 +140,26 @@ def launch_ranks(args):
     return rc
 
 
-def cpu_baseline(abi, hm, flat, threads, seconds_target=12.0):
-    """The CPU oracle (a port of the reference's Embree3+TBB loop, see oracle/oracle.cpp) timed on
-    this box's host cores on a bounded sample of the same workload.  Reported, never the target."""
+def _cgroup_cpu_quota():
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if quota[0] == "max" else round(int(quota[0]) / int(quota[1]), 2)
+    except Exception:
+        return None
+
+
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding
-    orc = oracle_binding.load()
-    sc = orc.scene(flat)
-    spp = 1
-    prm = abi.render_params(spp=spp, rng_mode=abi.MSK_RNG_PCG_BLOCK)
+    return oracle_binding.load()
+
+
+def cpu_baseline(abi, hm, flat, threads, seconds_target=12.0):
+    """The CPU oracle (a port of the reference's Embree3+TBB loop, see oracle/oracle.cpp) timed on this box's host cores on a
+    bounded sample of the headline workload, plus BASELINE config 1 (cbox 256x256 @ 16 spp, the reference's own CPU-runnable
+    case) in full.  Reported, never the target."""
+    sc = _oracle().scene(flat)
+    prm = abi.render_params(spp=1, rng_mode=abi.MSK_RNG_PCG_BLOCK)
     t0 = time.perf_counter()
     sc.render(prm, threads)
     dt = time.perf_counter() - t0
@@ -127,15 +169,23 @@ def cpu_baseline(abi, hm, flat, threads, seconds_target=12.0):
     _, st = sc.render(prm, threads)
     dt = time.perf_counter() - t0
     sc.close()
-    try:
-        quota = open("/sys/fs/cgroup/cpu.max").read().split()
-        quota = None if quota[0] == "max" else round(int(quota[0]) / int(quota[1]), 2)
-    except Exception:
-        quota = None
-    return {"value": round(st.samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "affinity_cpus": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": quota,
-            "sample": f"cbox {WIDTH}x{HEIGHT} @ {spp} spp ({st.samples} samples, {dt:.1f} s), pcg_block sampler, "
-                      f"own BVH instead of Embree, one 32x32 tile per task", "host_cpus": os.cpu_count()}
+    out = {"value": round(st.samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+           "affinity_cpus": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": _cgroup_cpu_quota(),
+           "sample": f"cbox {WIDTH}x{HEIGHT} @ {spp} spp ({st.samples} samples, {dt:.1f} s), pcg_block sampler, "
+                     f"own BVH instead of Embree, one 32x32 tile per task", "host_cpus": os.cpu_count()}
+    # config 1: the whole job (1 M samples), the faster of two runs
+    c1 = _oracle().scene(hm.cbox_scene(256, 256))
+    p1 = abi.render_params(spp=16, rng_mode=abi.MSK_RNG_PCG_BLOCK)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        _, s1 = c1.render(p1, threads)
+        d1 = time.perf_counter() - t0
+        best = d1 if best is None else min(best, d1)
+    c1.close()
+    out["config1"] = {"value": round(s1.samples / best / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+                      "sample": f"BASELINE config 1 in full: cbox 256x256 @ 16 spp ({s1.samples} samples, {best:.2f} s), pcg_block sampler"}
+    return out
 
 
 def l2_vs_cpu(abi, hm, flat, film_gpu, prm):
@@ -143,9 +193,7 @@ def l2_vs_cpu(abi, hm, flat, film_gpu, prm):
     the SAME workload (full size, same counter RNG, same seed) on every host thread, both films are developed as
     HDRFilm::image() does (films/hdrfilm.cpp:48-90: rgb = xyz_to_srgb(XYZ) / W) and compared per pixel."""
     import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_binding
-    sc = oracle_binding.load().scene(flat)
+    sc = _oracle().scene(flat)
     threads = len(os.sched_getaffinity(0))
     t0 = time.perf_counter()
     film_cpu, st = sc.render(prm, threads)
@@ -161,10 +209,12 @@ def l2_vs_cpu(abi, hm, flat, film_gpu, prm):
 
 
 def mesh_profile(tag):
-    """profiles/r03_<tag>.json (tools/profile_mesh.sh + summarize_mesh_profiles.py on one MI355X): per-kernel PMC figures of the
-    mesh configs — HBM bytes per segment / per ray and wave64 VALU instructions per ray of the committed profile."""
+    """The newest committed profiles/rNN_<tag>.json (tools/profile_mesh.sh + summarize_mesh_profiles.py on one MI355X): per-kernel
+    PMC figures of the mesh configs — HBM bytes per segment / per ray and wave64 VALU instructions per ray."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{tag}.json")))
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", f"r03_{tag}.json")))
+        return json.load(open(files[-1])) if files else None
     except Exception:
         return None
 
@@ -177,6 +227,7 @@ def other_configs(abi, hm, ctx):
     the general shading variant carries 8 more bytes per segment in and out) over the render's device time against the HBM
     peak, and — for the mesh configs — the PMC-measured bytes and VALU instructions of the committed profile scaled to this
     run's segments and rays (labelled as coming from the profile)."""
+    import numpy as np
     out = []
     jobs = [
         ("config 3 class: 70 k-triangle rough-conductor mesh in the Cornell room, 1024x1024 @ 256 spp",
@@ -192,7 +243,6 @@ def other_configs(abi, hm, ctx):
             sc = abi.Scene(ctx, flat)
             t_scene = time.perf_counter() - t0
             prm = abi.render_params(spp=spp)
-            import numpy as np
             film = np.zeros((flat.desc.film.height, flat.desc.film.width, 5), np.float32)      # reused: its pages stay mapped
             sc.render(prm, out=film)                              # allocates the workspace, uploads the plan
             dt, st = None, None
@@ -211,7 +261,7 @@ def other_configs(abi, hm, ctx):
             roof = {"bound": "hbm", "kernel": "k_shade_gen || k_trace", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_sample": round((b_shade + b_trace) / max(smp, 1), 1),
                     "note": "state bytes of both wavefront kernels over the wavefront phase's device time; the traversal of a tree in "
-                            "HBM/L2 is bound by load issue and latency, not by these bytes (DESIGN.md §9)"}
+                            "HBM/L2 is bound by VALU issue and load latency, not by these bytes (DESIGN.md §9)"}
             prof = mesh_profile(tag) if tag else None
             if prof:
                 k = prof.get("kernels", {})
@@ -231,39 +281,40 @@ def other_configs(abi, hm, ctx):
                 if tr.get("l2_hit_rate") is not None:
                     roof["l2_hit_rate_trace_from_profile"] = tr["l2_hit_rate"]
                 roof["profile_source"] = prof.get("_source")
-            out.append({"workload": name, "triangles": int(flat.desc.n_faces), "samples": smp,
+                roof["profile_stale"] = prof.get("_build_id") != build_id()
+            out.append({"workload": name, "tag": tag or "c4_1gpu", "triangles": int(flat.desc.n_faces), "samples": smp,
                         "value": round(st.samples / dt / 1e6, 1), "unit": "Msamples/s", "ms": round(dt * 1e3, 1),
                         "ms_device": round(st.ms_total, 1), "segments_per_sample": round(st.segments / max(st.samples, 1), 3),
                         "iterations": int(st.iterations), "passes": int(st.passes), "ms_resolve": round(st.ms_resolve, 1),
-                        "scene_create_s": round(t_scene, 2), "finite": bool(__import__("numpy").isfinite(film).all()),
+                        "scene_create_s": round(t_scene, 2), "finite": bool(np.isfinite(film).all()),
                         "timing": "wall time of msk_gpu_render incl. the film copy-back (PCIe)", "roofline": roof})
             sc.close()
         except Exception as e:                                       # reported, never fatal for the headline line
-            out.append({"workload": name, "error": str(e)[:300]})
+            out.append({"workload": name, "tag": tag or "c4_1gpu", "error": str(e)[:300]})
     return out
 
 
 def profile_counters():
-    """Per-launch counters of the committed rocprofv3 PMC passes (profiles/pmc_summary.json, profiles/*_sq.json):
-    NOT measured in this run — they describe the build and configuration the profile was taken on."""
+    """Per-launch counters of the committed rocprofv3 PMC passes (profiles/pmc_summary.json): NOT measured in this run — they
+    describe the build the profile was taken on (`_build_id`; bench.py flags `profile_stale` when that is not this build)."""
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
     except Exception:
-        pm = {}
-    return pm
+        return {}
 
 
-def profile_single_stream():
+def profile_single_stream(pm):
     """Achieved HBM-side GB/s of the two wavefront kernels when each launch has the GPU to itself, from the COMMITTED profiles:
     PMC bytes per launch (profiles/pmc_summary.json) over the average launch duration of the MSK_STREAMS=1 kernel trace
-    (profiles/r03_kernel_stats_1stream.csv).  Not measured in this run; labelled as such in the line."""
+    (the newest profiles/rNN_kernel_stats_1stream.csv).  Not measured in this run; labelled as such in the line."""
     import csv
-    pm = profile_counters()
-    out = {}
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernel_stats_1stream.csv")))
     try:
-        rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_kernel_stats_1stream.csv"))))
+        rows = list(csv.DictReader(open(files[-1])))
     except Exception:
         return None
+    out = {}
     for key in ("k_shade_gen", "k_trace"):
         b = next((v.get("hbm_bytes_per_launch") for k, v in pm.items() if k.startswith(key) and isinstance(v, dict)), None)
         r = next((r for r in rows if ("msk::" + key) in r["Name"]), None)
@@ -273,12 +324,102 @@ def profile_single_stream():
         gbs = b / (us * 1e-6) / 1e9
         out[key] = {"hbm_bytes_per_launch": round(b), "avg_launch_us": round(us, 1), "achieved": round(gbs, 1), "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4)}
-    out["source"] = "committed profiles (rocprofv3 PMC + MSK_STREAMS=1 kernel trace), not this run"
+    out["source"] = "committed profiles (%s + rocprofv3 PMC), not this run" % os.path.basename(files[-1])
     return out
+
+
+def roofline(stats, args):
+    """`roofline` of the JSON line from the HIP events the library records around its launches on its own streams.
+    Algorithmic bytes of the SoA path state each kernel must move; a "segment" is a slot that is live after a
+    shading sweep (written by it, traced, read by the next sweep), a "shadow ray" one that carries a shadow ray:
+      k_trace_q    48 B/segment (ray_o, ray_d in; hit out) + 32 B/shadow ray (ray_o, sh in: the shadow queue reads the origin too)
+      k_shade_gen  176 B/segment (id 8 B, wl, thr, res, ray_d, hit in; id 8 B, wl, thr, res, ray_o, ray_d out)
+                   - 64 B/sample (a new camera sample's thr = 1 and res = 0 are neither written nor read)
+                   + 48 B/shadow ray (contrib in; sh, contrib out) + 20 B/sample (record out)"""
+    seg = sum(s.segments for s in stats)
+    smp = sum(s.samples for s in stats)
+    shd = sum(s.shadow_rays for s in stats)
+    ms_trace = sum(s.ms_trace for s in stats)
+    ms_shade = sum(s.ms_shade for s in stats)
+    n_trace = sum(s.n_trace_launches for s in stats)                 # launches that carried timing events
+    n_shade = sum(s.n_shade_launches for s in stats)
+    l_trace = sum(s.launches_trace for s in stats)                   # launches actually made
+    l_shade = sum(s.launches_shade for s in stats)
+    l_wave = sum(s.launches_wavefront for s in stats)
+    bytes_trace = seg * 48 + shd * 32
+    bytes_shade = seg * 176 - smp * 64 + shd * 48 + smp * 20
+    # the two kernels take nearly the same time on this workload and which one is ahead depends on the box; the shading
+    # kernel (five times the bytes) is reported unless the traversal kernel is clearly the longer one
+    if ms_trace > 1.03 * ms_shade:
+        name, b, ms, nt, nl = "k_trace", bytes_trace, ms_trace, n_trace, l_trace
+    else:
+        name, b, ms, nt, nl = "k_shade_gen", bytes_shade, ms_shade, n_shade, l_shade
+    # per launch: the kernel's bytes over the launches that moved them (its own + the k_wavefront launches of the thin end of
+    # a pass, which run both kernels' code); the average duration is over the timed launches
+    bytes_per_launch = b / max(nl + l_wave, 1)
+    avg_launch_ms = ms / max(nt, 1)
+    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    ms_wavefront = sum(s.ms_total - s.ms_resolve for s in stats)
+    pm = profile_counters()
+    stale = pm.get("_build_id") != build_id()
+
+    def prof(prefix, key):
+        return next((v.get(key) for k, v in pm.items() if k.startswith(prefix) and isinstance(v, dict)), None)
+    n_streams = int(os.environ.get("MSK_STREAMS", "4"))
+    per_kernel = {"kernel": name, "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+                  "bytes_per_launch": round(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
+                  "launches": {"k_shade_gen": l_shade, "k_trace": l_trace, "k_wavefront": l_wave},
+                  "avg_launch_ms_shade": round(ms_shade / max(n_shade, 1), 4), "avg_launch_ms_trace": round(ms_trace / max(n_trace, 1), 4)}
+    if n_streams > 1:
+        # The wavefront loop runs on several streams at once (DESIGN.md §6): at any moment a few launches of BOTH kernels
+        # share the GPU, a launch's wall duration says how long it shared, not how fast it could go, and the unit that
+        # has a bandwidth is the phase: both kernels' algorithmic bytes of one whole-pool iteration over the wall time
+        # such an iteration takes (every stream launches its own part of the pool: n_streams kernel pairs = one iteration).
+        name = "k_shade_gen || k_trace (%d streams)" % n_streams
+        per_iter = max((l_shade + l_wave) / n_streams, 1.0)
+        bytes_per_launch = (bytes_trace + bytes_shade) / per_iter
+        avg_launch_ms = ms_wavefront / per_iter
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        ts, tt = prof("k_shade_gen", "hbm_bytes_per_launch"), prof("k_trace", "hbm_bytes_per_launch")
+        # the PMC passes run single-stream (tools/profile_all.sh): one launch of each kernel there IS one whole-pool iteration
+        traffic = round(ts + tt) if ts is not None and tt is not None else None
+    else:
+        t = prof(name, "hbm_bytes_per_launch")
+        traffic = round(t) if t is not None else None
+    # VALU side (the kernels are issue-bound, not HBM-bound — DESIGN.md §8): wave-level VALU instructions per path
+    # segment from the committed SQ counter pass, times this run's segments, over the wavefront phase's wall time
+    valu = None
+    vs, vt = prof("k_shade_gen", "valu_insts_per_segment"), prof("k_trace", "valu_insts_per_segment")
+    if vs is not None and vt is not None and ms_wavefront > 0:
+        ginst = (vs + vt) * seg / (ms_wavefront * 1e-3) / 1e9
+        valu = {"bound": "valu", "achieved": round(ginst, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instr/s",
+                "frac": round(ginst / VALU_PEAK_GINST, 4), "insts_per_segment": {"k_shade_gen": vs, "k_trace": vt},
+                "source": pm.get("_source", "profiles/pmc_summary.json"),
+                "note": "wave64 VALU instructions (SQ_INSTS_VALU of the committed profile / its segments) x this run's segments "
+                        "/ wavefront-phase wall time; peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction — the rate of "
+                        "the v_fma / v_add / v_mul / v_and class only: v_min / v_max / v_cmp / v_cndmask / shifts / conversions / "
+                        "packed and fp64 operations issue at 4 cycles, transcendentals at 8 (measured: tools/micro/valu_ops.hip, "
+                        "profiles/r03_valu_ops.txt), so an instruction stream of this mix saturates issue at a frac of about 0.6"}
+    return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "profile_stale": bool(stale), "profile_build_id": pm.get("_build_id"), "build_id": build_id(),
+            "traffic_source": "NOT measured in this run: per-launch FETCH_SIZE/WRITE_SIZE of the committed rocprofv3 PMC "
+                              "passes (%s)" % pm.get("_source", "profiles/pmc_summary.json"),
+            "bytes_per_launch": round(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
+            "per_kernel": per_kernel,
+            "timed_launches": nt, "timed": "launches of every %s-th sync group" % os.environ.get("MSK_TIMING_EVERY", "1"),
+            "ms_trace_timed": round(ms_trace, 2), "ms_shade_timed": round(ms_shade, 2),
+            "ms_resolve": round(sum(s.ms_resolve for s in stats), 2),
+            "ms_total_device": round(sum(s.ms_total for s in stats), 2),
+            "segments_per_sample": round(seg / max(smp, 1), 3),
+            "valu": valu, "per_kernel_single_stream_profile": profile_single_stream(pm)}
 
 
 def main():
     args = parse_args()
+    if args.in_process and args.gpus > 1:
+        print("bench.py: --in-process N and --gpus N are two different multi-GPU paths; give one", file=sys.stderr)
+        sys.exit(2)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
 
@@ -293,11 +434,17 @@ def main():
     if os.environ.get("MSK_BENCH_TEST_FAIL_RANK") == str(rank):      # tests/test_bench_launch.py: a rank that dies before the rendezvous
         sys.exit(3)
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the launcher's world size wins", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the launcher's world size wins", file=sys.stderr)
     dev = "cpu" if args.dry_run else "cuda"
     rehearsal = bool(args.rehearse_on_one_gpu) and not args.dry_run
+    members = max(args.in_process, 1)                    # devices behind this process's ONE context
+    n_dev = devices_seen()
+    need = max(world, members)
+    if not args.dry_run and not rehearsal and n_dev < need:
+        # before any rendezvous and before anything touches a GPU: the other ranks find the same and leave the same way
+        print(f"bench.py: {need} GPU(s) asked for but this node shows {n_dev}; rank {rank} stops", file=sys.stderr)
+        sys.exit(2)
     if rehearsal:
         local_rank = 0                                   # every rank on the one GPU there is
     if not args.dry_run:
@@ -312,7 +459,8 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    spp_total = mg.weak_scaling_spp(args.spp, world)
+    spp_total = mg.weak_scaling_spp(args.spp, max(world, members))
+    host_film = None
     if args.dry_run:
         film = torch.ones((8, 8, 5), dtype=torch.float32)
         abi = hm = scene = ctx = flat = None
@@ -321,26 +469,41 @@ def main():
             film.fill_(1.0)
             mg.reduce_film(film, dist)
             return None
+        step_hbm = None
     else:
+        import numpy as np
         abi = importlib.import_module("misaki-render_amd.abi")
         hm = importlib.import_module("misaki-render_amd.hostmirror")
         flat = hm.cbox_scene(WIDTH, HEIGHT)
-        ctx = abi.Context(local_rank)
+        ctx = abi.Context([0] * members if rehearsal and members > 1 else list(range(members)) if members > 1 else local_rank)
         scene = abi.Scene(ctx, flat)
-        prm = mg.shard_params(abi, spp_total, rank, world, mode=args.shard, seed=0)
+        # --in-process: the library itself shards the call's samples over the members
+        prm = mg.shard_params(abi, spp_total, rank, world, mode=args.shard, seed=0) if world > 1 else abi.render_params(spp=spp_total, seed=0)
         film = torch.zeros((HEIGHT, WIDTH, 5), dtype=torch.float32, device="cuda")
+        host_film = np.zeros((HEIGHT, WIDTH, 5), np.float32)          # rank 0's copy-back target (msk_gpu_render stages through pinned memory)
+        host_t = torch.from_numpy(host_film)
 
-        def step():
-            # render_device returns when the film is complete on the library's stream; reduce_film returns when the
-            # reduce has finished reading it (multigpu.reduce_film synchronises): the next render may overwrite it
-            st = scene.render_device(prm, film.data_ptr())
-            if rehearsal and dist is not None:           # gloo has no device reduce: through the host (rehearsal only)
-                host = film.cpu()
-                mg.reduce_film(host, dist)
-                film.copy_(host)
-            else:
-                mg.reduce_film(film, dist)
-            return st
+        def step_hbm():
+            return scene.render_device(prm, film.data_ptr())
+
+        if world == 1:
+            def step():
+                return scene.render(prm, out=host_film)[1]           # msk_gpu_render: the render + the film's copy-back
+        else:
+            def step():
+                # render_device returns when the film is complete on the library's stream; reduce_film returns when the
+                # reduce has finished reading it (multigpu.reduce_film synchronises): the next render may overwrite it
+                st = scene.render_device(prm, film.data_ptr())
+                if rehearsal:                                # gloo has no device reduce: through the host (rehearsal only)
+                    host = film.cpu()
+                    mg.reduce_film(host, dist)
+                    if rank == 0:
+                        host_t.copy_(host)
+                else:
+                    mg.reduce_film(film, dist)
+                    if rank == 0:
+                        host_t.copy_(film)                   # the reduced film's copy-back (synchronous)
+                return st
 
     def fence():
         if not args.dry_run:
@@ -350,173 +513,100 @@ def main():
             if not args.dry_run:
                 torch.cuda.synchronize()
 
+    def timed(fn, k):
+        fence()
+        t0 = time.perf_counter()
+        sts = [fn() for _ in range(k)]
+        fence()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if (rehearsal or args.dry_run) else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, sts
+
     warm = [step() for _ in range(args.warmup)]
     balance = None
-    if dist is not None and args.shard == "samples" and not args.no_balance and warm and not args.dry_run:
-        # The GPUs of a node are not equally fast on this workload (the shading kernel differs by up to 20 %
-        # between boxes of the pool) and an equal split waits for the slowest.  Every rank's device time of the last
-        # warm-up step decides speed-proportional contiguous sample ranges; the per-GPU average stays args.spp.
-        # (kernel time of the wavefront launches that carried events — the same sync groups on every rank — not the step's
-        # wall or device total, which on a first step also holds the one-off uploads of the render plan)
+    if dist is not None and args.shard == "samples" and args.balance and warm and not args.dry_run:
+        # Opt-in extra: the GPUs of a node are not equally fast on this workload and an equal split waits for
+        # the slowest.  Every rank's kernel time of the last warm-up step decides speed-proportional contiguous sample ranges;
+        # the per-GPU average stays args.spp.  Not the constant-work weak scaling the default reports.
         shares, times = mg.speed_proportional_shares(dist, warm[-1].ms_trace + warm[-1].ms_shade, spp_total,
                                                      device="cpu" if rehearsal else "cuda")
         if shares is not None:
             prm = mg.shard_params(abi, spp_total, rank, world, mode="range", shares=shares, seed=0)
             step()                       # untimed: the new shares' plan and record buffers are set up here
             balance = {"equal_split_kernel_ms": [round(t, 2) for t in times], "spp_shares": shares}
-    fence()
-    t0 = time.perf_counter()
-    stats = []
-    for _ in range(args.steps):
-        stats.append(step())
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, stats = timed(step, args.steps)
 
     if rank == 0 and args.dry_run:
         ok = bool((film == float(world)).all())
         print(json.dumps({"metric": "Msamples/s (paths x spp) on cbox@512spp", "value": None, "unit": "Msamples/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "dry_run": True, "reduce_ok": ok,
-                          "config": {"workload": "none (launch / rendezvous / reduce only)", "samples_per_step": WIDTH * HEIGHT * spp_total}}),
+                          "config": {"workload": "none (launch / rendezvous / reduce only)", "samples_per_step": WIDTH * HEIGHT * spp_total,
+                                     "rccl_ranks": dist.get_world_size() if dist is not None else 1, "devices_seen": n_dev,
+                                     "balance": balance}}),
               flush=True)
-    elif rank == 0:
-        samples_step = WIDTH * HEIGHT * spp_total              # all ranks together
+    elif not args.dry_run:
+        # the same K steps with the film left in HBM (every rank takes part: the steps hold collectives)
+        dt_hbm, _ = timed(step_hbm, args.steps) if world == 1 else (None, None)
+    if rank == 0 and not args.dry_run:
+        import numpy as np
+        n_gpus = max(world, members)
+        samples_step = WIDTH * HEIGHT * spp_total              # all GPUs together
         value = samples_step * args.steps / dt / 1e6
-        # ---- roofline of the dominant kernel, from the HIP events the library records around every
-        #      launch on its own stream (rank 0's launches)
-        seg = sum(s.segments for s in stats)
-        smp = sum(s.samples for s in stats)
-        shd = sum(s.shadow_rays for s in stats)
-        ms_trace = sum(s.ms_trace for s in stats)
-        ms_shade = sum(s.ms_shade for s in stats)
-        n_trace = sum(s.n_trace_launches for s in stats)
-        n_shade = sum(s.n_shade_launches for s in stats)
-        # algorithmic bytes of the SoA path state each kernel must move; a "segment" is a slot that is live
-        # after a shading sweep (written by it, traced, read by the next sweep), a "shadow ray" one that carries a shadow ray:
-        #   k_trace_q    48 B/segment (ray_o, ray_d in; hit out) + 32 B/shadow ray (ray_o, sh in: the shadow queue reads the origin too)
-        #   k_shade_gen  176 B/segment (id 8 B, wl, thr, res, ray_d, hit in; id 8 B, wl, thr, res, ray_o, ray_d out)
-        #                - 64 B/sample (a new camera sample's thr = 1 and res = 0 are neither written nor read)
-        #                + 48 B/shadow ray (contrib in; sh, contrib out) + 20 B/sample (record out)
-        bytes_trace = seg * 48 + shd * 32
-        bytes_shade = seg * 176 - smp * 64 + shd * 48 + smp * 20
-        # the two kernels take nearly the same time on this workload and which one is ahead depends on the box; the shading
-        # kernel (five times the bytes) is reported unless the traversal kernel is clearly the longer one
-        if ms_trace > 1.03 * ms_shade:
-            name, b, ms, nl = "k_trace", bytes_trace, ms_trace, n_trace
-        else:
-            name, b, ms, nl = "k_shade_gen", bytes_shade, ms_shade, n_shade
-        iters = sum(s.iterations for s in stats)               # one launch of each kernel per wavefront iteration
-        bytes_per_launch = b / max(iters, 1)
-        avg_launch_ms = ms / max(nl, 1)                        # over the timed launches (nl of iters)
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        ms_wavefront = sum(s.ms_total - s.ms_resolve for s in stats)
-        pair_achieved = (bytes_trace + bytes_shade) / (ms_wavefront * 1e-3) / 1e9 if ms_wavefront > 0 else 0.0
-        pm = profile_counters()
-
-        def prof(prefix, key):
-            return next((v.get(key) for k, v in pm.items() if k.startswith(prefix) and isinstance(v, dict)), None)
-        n_streams = int(os.environ.get("MSK_STREAMS", "4"))
-        per_kernel = {"kernel": name, "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
-                      "bytes_per_launch": round(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
-                      "avg_launch_ms_shade": round(ms_shade / max(n_shade, 1), 4), "avg_launch_ms_trace": round(ms_trace / max(n_trace, 1), 4)}
-        if n_streams > 1:
-            # The wavefront loop runs on several streams at once: at any moment a few launches of BOTH kernels
-            # share the GPU, a launch's wall duration says how long it shared, not how fast it could go, and the unit that
-            # has a bandwidth is the phase: both kernels' algorithmic bytes of one iteration over the wall time an iteration
-            # takes.  The per-launch figures (what a rocprofv3 kernel trace of this command shows) stay under `per_kernel`.
-            name = "k_shade_gen || k_trace (%d streams)" % n_streams
-            achieved = pair_achieved
-            per_iter = max(iters // n_streams, 1)            # iterations of the whole pool (every stream launches its own)
-            # (the thin end of a pass runs as k_wavefront launches that are booked as 16 iterations each: where the committed
-            # single-stream profile of this workload says how many whole-pool launches a step is, that count is used, so that
-            # `bytes_per_launch` and `traffic` describe the same unit)
-            prof_launches = prof("k_shade_gen", "launches")
-            if prof_launches and args.spp == SPP_PER_GPU:
-                per_iter = int(prof_launches) * args.steps
-            bytes_per_launch = (bytes_trace + bytes_shade) / per_iter
-            avg_launch_ms = ms_wavefront / per_iter
-            ts, tt = prof("k_shade_gen", "hbm_bytes_per_launch"), prof("k_trace", "hbm_bytes_per_launch")
-            # the PMC passes run single-stream (tools/profile_all.sh): one launch of each kernel there IS one whole-pool iteration
-            traffic = round(ts + tt) if ts is not None and tt is not None else None
-        else:
-            t = prof(name, "hbm_bytes_per_launch")
-            traffic = round(t) if t is not None else None
-        # VALU side (the kernels are issue-bound, not HBM-bound — DESIGN.md §8): wave-level VALU instructions per path
-        # segment from the committed SQ counter pass, times this run's segments, over the wavefront phase's wall time
-        valu = None
-        vs, vt = prof("k_shade_gen", "valu_insts_per_segment"), prof("k_trace", "valu_insts_per_segment")
-        if vs is not None and vt is not None and ms_wavefront > 0:
-            ginst = (vs + vt) * seg / (ms_wavefront * 1e-3) / 1e9
-            valu = {"bound": "valu", "achieved": round(ginst, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instr/s",
-                    "frac": round(ginst / VALU_PEAK_GINST, 4), "insts_per_segment": {"k_shade_gen": vs, "k_trace": vt},
-                    "source": pm.get("_source", "profiles/pmc_summary.json"),
-                    "note": "wave64 VALU instructions (SQ_INSTS_VALU of the committed profile / its segments) x this run's segments "
-                            "/ wavefront-phase wall time; peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction — the rate of "
-                            "the v_fma / v_add / v_mul / v_and class only: v_min / v_max / v_cmp / v_cndmask / shifts / conversions / "
-                            "packed and fp64 operations issue at 4 cycles, transcendentals at 8 (measured: tools/micro/valu_ops.hip, "
-                            "profiles/r03_valu_ops.txt), so an instruction stream of this mix saturates issue at a frac of about 0.6"}
+        par = "single GPU"
+        if world > 1:
+            par = f"{args.shard[:-1]}-shard x{world}, one process per GPU + RCCL film reduce"
+        elif members > 1:
+            par = f"sample-shard x{members} behind one context (msk_gpu_init(ids, {members})), films summed by k_film_sum over peer access"
         out = {
             "metric": "Msamples/s (paths x spp) on cbox@512spp", "value": round(value, 2), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            **({"rehearsal": True, "film_finite": bool(torch.isfinite(film).all()), "film_weight_sum": float(film[..., 4].double().sum())} if rehearsal else {}),
+            **({"rehearsal": True, "film_finite": bool(np.isfinite(host_film).all()), "film_weight_sum": float(host_film[..., 4].astype(np.float64).sum())} if rehearsal else {}),
             "config": {"workload": f"cbox {WIDTH}x{HEIGHT} @ {args.spp} spp per GPU ({spp_total} spp total), diffuse BSDFs, "
                                    f"path integrator (NEE+MIS, RR from depth 4), counter RNG, Gaussian filter, "
-                                   f"ordered film resolve included",
-                       "parallelism": f"{args.shard[:-1]}-shard x{world} + RCCL film reduce" if world > 1 else "single GPU",
-                       "samples_per_step": samples_step, "balance": balance,
-                       "segments_per_sample": round(seg / max(smp, 1), 3)},
-            "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic,
-                         "traffic_source": "NOT measured in this run: per-launch FETCH_SIZE/WRITE_SIZE of the committed rocprofv3 PMC "
-                                           "passes (%s)" % pm.get("_source", "profiles/pmc_summary.json"),
-                         "bytes_per_launch": round(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
-                         "per_kernel": per_kernel, "launches": iters,
-                         "launches_note": "wavefront iterations as the library books them: an upper bound on kernel-pair launches (a k_wavefront "
-                                          "launch of the thin end of a pass is booked as 16 iterations even when its regions empty earlier)",
-                         "timed_launches": nl, "timed": "launches of every %s-th sync group" % os.environ.get("MSK_TIMING_EVERY", "1"),
-                         "ms_trace_timed": round(ms_trace, 2), "ms_shade_timed": round(ms_shade, 2),
-                         "ms_resolve": round(sum(s.ms_resolve for s in stats), 2),
-                         "ms_total_device": round(sum(s.ms_total for s in stats), 2),
-                         "valu": valu, "per_kernel_single_stream_profile": profile_single_stream()},
+                                   f"ordered film resolve and the film's copy-back to the host included",
+                       "parallelism": par, "samples_per_step": samples_step,
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "in_process_members": members,
+                       "devices_seen": n_dev, "balance": balance},
+            "roofline": roofline(stats, args),
         }
-        if world == 1:
-            # SURVEY 8(d) defines t_render "incl. final film copy-back": the same K steps through msk_gpu_render (host film,
-            # 5 MB over PCIe per step); `value` above keeps the film in HBM, as the multi-GPU reduce needs it
-            import numpy as np
-            film_host = np.zeros((HEIGHT, WIDTH, 5), np.float32)
-            scene.render(prm, out=film_host)                  # (maps the array's pages, allocates the library's pinned staging buffer)
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                scene.render(prm, out=film_host)
-            dt_host = time.perf_counter() - t1
-            out["ms_per_step_incl_copyback"] = round(dt_host / args.steps * 1e3, 3)
-            out["value_incl_copyback"] = round(samples_step * args.steps / dt_host / 1e6, 2)
+        if dt_hbm is not None:
+            out["ms_per_step_film_in_hbm"] = round(dt_hbm / args.steps * 1e3, 3)
+            out["value_film_in_hbm"] = round(samples_step * args.steps / dt_hbm / 1e6, 2)
         # the measured headline is safe on stderr before anything slower or riskier runs (CPU baselines, other configs)
         print("bench.py headline (extras follow on stdout): " + json.dumps(out), file=sys.stderr, flush=True)
-        if not args.no_cpu_baseline and world == 1:
+        compact = {}
+        if not args.no_cpu_baseline and n_gpus == 1:
             try:
-                out["l2_vs_cpu"] = l2_vs_cpu(abi, hm, flat, film_host, prm)
+                out["l2_vs_cpu"] = l2_vs_cpu(abi, hm, flat, host_film, prm)
+                compact["l2_max"] = out["l2_vs_cpu"]["max"]
             except Exception as e:
                 out["l2_vs_cpu"] = {"error": str(e)[:300]}
-            # the reference CLI caps TBB at 8 threads (main.cpp:43-44): that run is `cpu_baseline`; the same port on every
-            # hardware thread of this host rides along (SURVEY §8d asks for both)
+            # the reference CLI caps TBB at 8 threads (main.cpp:43-44): that run is `cpu_baseline` (+ config 1 under `config1`);
+            # the same port on every hardware thread of this host rides along (SURVEY §8d asks for both)
             out["cpu_baseline"] = cpu_baseline(abi, hm, flat, min(8, os.cpu_count() or 1))
             # every hardware thread of this host: the full-size counter-RNG render l2_vs_cpu just timed (same port, same work
-            # per sample but for the sampler; rendering it a second time with the PCG sampler would add 20 s for the same figure)
+            # per sample but for the sampler).  The cores that can actually run are the cgroup's quota, not the thread count.
             l2 = out.get("l2_vs_cpu") or {}
             if l2.get("cpu_msamples_per_s"):
-                out["cpu_baseline_all_threads"] = {"value": l2["cpu_msamples_per_s"], "unit": "Msamples/s", "cores": l2["cpu_threads"], "kind": "port",
+                quota = _cgroup_cpu_quota()
+                out["cpu_baseline_all_threads"] = {"value": l2["cpu_msamples_per_s"], "unit": "Msamples/s",
+                                                   "cores": min(l2["cpu_threads"], int(quota)) if quota else l2["cpu_threads"],
+                                                   "threads": l2["cpu_threads"], "cgroup_cpu_quota": quota, "kind": "port",
                                                    "sample": l2["cpu"], "host_cpus": os.cpu_count()}
         else:
             out["cpu_baseline"] = None
-        if world == 1 and not args.no_other_configs:
+        if n_gpus == 1 and not args.no_other_configs:
             out["other_configs"] = other_configs(abi, hm, ctx)
+            for e in out["other_configs"]:
+                if "value" in e:
+                    compact[e["tag"] + "_msamples_per_s"] = e["value"]
+        # the driver's parser keeps `config`, `roofline` and `cpu_baseline`: the other configs' throughputs and the L2 ride there too
+        out["config"]["other"] = compact or None
         print(json.dumps(out), flush=True)
     if scene is not None:
         scene.close()

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MSK_ABI_VERSION 4
+#define MSK_ABI_VERSION 5
 
 /* ---- status codes ------------------------------------------------------- */
 #define MSK_OK                 0
@@ -165,11 +165,20 @@ typedef struct msk_camera_desc {
     float near_clip, far_clip;
 } msk_camera_desc;
 
-/* Film::size() (film.cpp:10) + ReconstructionFilter discretisation (rfilter.cpp:12-27). */
+/* Film::size() (film.cpp:10) + ReconstructionFilter discretisation (rfilter.cpp:12-27) + the crop window
+ * (film.cpp:12-21,51-63: crop_offset_x / _y, crop_width / _height; HDRFilm's storage is an ImageBlock of the
+ * crop size placed at the crop offset, films/hdrfilm.cpp:37-38).  The sensor — sample_to_camera, the pixel
+ * grid, the spiral block ids — is that of the FULL film (integrator.cpp:45: BlockGenerator(film->size(), 0,
+ * block_size)); the film the render calls write is the crop window, crop_size[1] x crop_size[0] pixels, and
+ * holds exactly what Film::put leaves there: every block's contribution clipped to the window
+ * (imageblock.cpp:36-53,133-173).  Blocks whose bordered area misses the window add nothing and are not
+ * rendered (and not counted in msk_stats).  crop_size = {0, 0} means the whole film. */
 typedef struct msk_film_desc {
     int32_t width, height;
     float   filter_radius;                       /* m_radius                    */
     float   filter_lut[MSK_FILTER_RESOLUTION + 1]; /* m_values, [32] == 0       */
+    int32_t crop_offset[2];                      /* m_crop_offset (x, y)        */
+    int32_t crop_size[2];                        /* m_crop_size (width, height) */
 } msk_film_desc;
 
 typedef struct msk_scene_desc {
@@ -231,6 +240,9 @@ typedef struct msk_stats {
        exceed ms_total.  ms_resolve (film replay + Film::put) is always complete. */
     float    ms_trace, ms_shade, ms_resolve;
     uint32_t n_trace_launches, n_shade_launches;
+    /* kernel launches the call actually made (timed or not): traversal kernels, k_shade_gen, k_wavefront (the device-side
+       loop of the thin end of a pass, booked as up to 16 `iterations` each) */
+    uint32_t launches_trace, launches_shade, launches_wavefront;
 } msk_stats;
 
 typedef struct msk_ctx   msk_ctx;
@@ -242,7 +254,10 @@ typedef struct msk_scene msk_scene;
    repeat —, every scene created on it lives on every member, msk_gpu_render / _render_device / _render_aov shard the call's
    samples over the members by index (member k: sample_first + (k + j n) sample_stride), one host thread each, and sum the
    films on device_ids[0] over peer access in member order; d_film_xyzaw of msk_gpu_render_device is memory of device_ids[0];
-   the sub-stage entry points run on the first member.  (The one-process-per-GPU scheme — one single-device msk_ctx per
+   the sub-stage entry points run on the first member.  msk_stats of a group call: samples / segments / shadow_rays / launches_* and
+   the kernel-time samples ms_trace / ms_shade / n_*_launches are SUMS over the members (device time of n devices: not comparable
+   with ms_total), iterations / passes / ms_resolve the members' maxima, ms_total the HOST WALL TIME of the whole call (the members'
+   renders side by side + the film sum).  (The one-process-per-GPU scheme — one single-device msk_ctx per
    rank + an RCCL film reduce — sits above this ABI: DESIGN.md §7.) */
 int  msk_gpu_init(const int *device_ids, int n, msk_ctx **out_ctx);
 void msk_gpu_shutdown(msk_ctx *ctx);
@@ -257,8 +272,9 @@ void msk_gpu_scene_destroy(msk_scene *scene);
 /*
  * Replaces the body of SamplingIntegrator::render between film->prepare() and
  * the last film->put() (integrator.cpp:48-76).  Writes the film's weighted sums
- * {X,Y,Z,A,W} per pixel, row-major height*width*5 floats, exactly what
- * HDRFilm's storage ImageBlock holds after the last put (hdrfilm.cpp:43-46).
+ * {X,Y,Z,A,W} per pixel of the crop window (the whole film by default), row-major
+ * crop_height*crop_width*5 floats, exactly what HDRFilm's storage ImageBlock holds
+ * after the last put (hdrfilm.cpp:37-38,43-46).
  * film_xyzaw: host memory, caller-owned.  stats may be NULL.
  */
 int  msk_gpu_render(msk_scene *scene, const msk_render_params *params,
@@ -277,7 +293,7 @@ int  msk_gpu_render_device(msk_scene *scene, const msk_render_params *params,
  * m_aov_types; at most one MSK_AOV_PATH_RGBA (the nested "path" integrator whose sample also becomes the
  * XYZ result, aov.cpp:138-139; without one XYZ is 0 — the reference returns an uninitialised Spectrum there).
  * Every AOV value of a camera ray that misses the scene is 0 (the reference reads an uninitialised
- * SceneInteraction for all but depth).  film: height*width*(5 + msk_gpu_aov_channels()) floats, host,
+ * SceneInteraction for all but depth).  film: crop_height*crop_width*(5 + msk_gpu_aov_channels()) floats, host,
  * the weighted sums HDRFilm's storage holds (channels X,Y,Z,A,W, then the AOV channels in order).
  */
 uint32_t msk_gpu_aov_channels(const int32_t *aov_types, uint32_t n_aovs);   /* 0 if a type is invalid */

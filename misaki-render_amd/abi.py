@@ -6,11 +6,12 @@ library is loaded from misaki-render_amd/lib/libmsk_gpu.so and there is NO
 fallback: if the HIP extension is missing, loading raises.
 """
 import ctypes as C
+import operator
 import os
 
 import numpy as np
 
-MSK_ABI_VERSION = 4
+MSK_ABI_VERSION = 5
 MSK_OK = 0
 MSK_ERR_INVALID_ARG, MSK_ERR_NO_DEVICE, MSK_ERR_HIP, MSK_ERR_OOM, MSK_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 MSK_BSDF_DIFFUSE, MSK_BSDF_ROUGHCONDUCTOR, MSK_BSDF_ROUGHDIELECTRIC = 0, 1, 2
@@ -58,7 +59,8 @@ class CameraDesc(C.Structure):
 
 class FilmDesc(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("filter_radius", C.c_float),
-                ("filter_lut", C.c_float * (MSK_FILTER_RESOLUTION + 1))]
+                ("filter_lut", C.c_float * (MSK_FILTER_RESOLUTION + 1)),
+                ("crop_offset", C.c_int32 * 2), ("crop_size", C.c_int32 * 2)]     # {0, 0} size = the whole film
 
 
 class SceneDesc(C.Structure):
@@ -85,7 +87,8 @@ class Stats(C.Structure):
                 ("iterations", C.c_uint32), ("passes", C.c_uint32), ("ms_total", C.c_float),
                 ("ms_generate", C.c_float), ("ms_trace", C.c_float), ("ms_shade", C.c_float),
                 ("ms_resolve", C.c_float), ("n_trace_launches", C.c_uint32),
-                ("n_shade_launches", C.c_uint32)]
+                ("n_shade_launches", C.c_uint32), ("launches_trace", C.c_uint32), ("launches_shade", C.c_uint32),
+                ("launches_wavefront", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -175,7 +178,10 @@ class Context:
     def __init__(self, device=0):
         self.lib = load_library()
         self.handle = C.c_void_p()
-        devs = [int(device)] if isinstance(device, int) else [int(d) for d in device]
+        try:
+            devs = [operator.index(device)]               # any integer type (a numpy rank value included)
+        except TypeError:
+            devs = [operator.index(d) for d in device]
         self.devices = devs
         ids = (C.c_int * len(devs))(*devs)
         rc = self.lib.msk_gpu_init(ids, len(devs), C.byref(self.handle))
@@ -214,17 +220,21 @@ class Scene:
 
     @property
     def width(self):
-        return self.flat.desc.film.width
+        """of the film the render calls write: the crop window (the whole film by default)"""
+        f = self.flat.desc.film
+        return f.crop_size[0] if (f.crop_size[0] or f.crop_size[1]) else f.width
 
     @property
     def height(self):
-        return self.flat.desc.film.height
+        f = self.flat.desc.film
+        return f.crop_size[1] if (f.crop_size[0] or f.crop_size[1]) else f.height
 
     def render(self, params, out=None):
         """-> (film float32[H,W,5] of weighted sums {X,Y,Z,A,W}, Stats).  out: an array to fill instead of a new one (a
         caller that renders repeatedly keeps its pages mapped: a fresh 5 MB array costs more in page faults than the copy)."""
         film = out if out is not None else np.empty((self.height, self.width, 5), np.float32)
-        assert film.dtype == np.float32 and film.flags.c_contiguous and film.shape == (self.height, self.width, 5)
+        if not (isinstance(film, np.ndarray) and film.dtype == np.float32 and film.flags.c_contiguous and film.shape == (self.height, self.width, 5)):
+            raise ValueError(f"out must be a C-contiguous float32 array of shape {(self.height, self.width, 5)}")      # the library writes that many bytes
         st = Stats()
         self.ctx.check(self.ctx.lib.msk_gpu_render(self.handle, C.byref(params), _ptr(film), C.byref(st)))
         return film, st

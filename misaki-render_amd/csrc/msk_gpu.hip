@@ -41,6 +41,8 @@ struct msk_ctx {
     std::vector<hipEvent_t> events, more_events[MSK_MAX_STREAMS - 1];
     uint32_t timing_phase = 0;         // which sync groups carry timing events rotates from render to render (MSK_TIMING_EVERY);
                                        // a context is used by one host thread at a time (msk_gpu.h), so a plain counter
+    uint32_t device_sharers = 1;       // member contexts of a group that sit on this context's device (repeated ordinals): their
+                                       // renders run side by side, each plans its record buffers within 1 / device_sharers of the free HBM
 };
 
 static int fail(msk_ctx *ctx, int code, const char *fmt, ...) {
@@ -198,6 +200,13 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     if (d->film.width <= 0 || d->film.height <= 0 || !(d->film.filter_radius > 0.f))
         return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: invalid film %dx%d radius %g", d->film.width,
                     d->film.height, d->film.filter_radius);
+    {   // Film::set_crop_window (film.cpp:51-63); {0, 0} = the whole film
+        const int32_t cx = d->film.crop_offset[0], cy = d->film.crop_offset[1], cw = d->film.crop_size[0], ch = d->film.crop_size[1];
+        const bool whole = cw == 0 && ch == 0 && cx == 0 && cy == 0;
+        if (!whole && (cx < 0 || cy < 0 || cw <= 0 || ch <= 0 || (int64_t) cx + cw > d->film.width || (int64_t) cy + ch > d->film.height))
+            return fail(ctx, MSK_ERR_INVALID_ARG, "Invalid crop window specification! offset (%d, %d) + crop size (%d, %d) vs full size (%d, %d)",
+                        cx, cy, cw, ch, d->film.width, d->film.height);
+    }
     if (!d->cie1931_xyz || !d->d65) return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: spectral tables missing");
     if ((d->n_faces && (!d->vertices || !d->faces)) || (d->n_meshes && !d->meshes))
         return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: geometry arrays missing");
@@ -423,6 +432,9 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     std::memcpy(ds.s2c, d->camera.sample_to_camera, 64); std::memcpy(ds.to_world, d->camera.to_world, 64);
     ds.near_clip = d->camera.near_clip; ds.far_clip = d->camera.far_clip;
     ds.width = d->film.width; ds.height = d->film.height;
+    ds.crop_x = d->film.crop_offset[0]; ds.crop_y = d->film.crop_offset[1];
+    ds.crop_w = d->film.crop_size[0]; ds.crop_h = d->film.crop_size[1];
+    if (ds.crop_w == 0 && ds.crop_h == 0) { ds.crop_x = ds.crop_y = 0; ds.crop_w = ds.width; ds.crop_h = ds.height; }      // the whole film
     ds.filter_radius = d->film.filter_radius;
     ds.filter_scale = float(MSK_FILTER_RESOLUTION) / d->film.filter_radius;           // rfilter.cpp:21
     ds.filter_border = (int) std::ceil(d->film.filter_radius - .5f);                  // rfilter.cpp:22
@@ -784,6 +796,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
                 if (diffuse_only) hipExtLaunchKernelGGL((k_wavefront<true>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
                 else hipExtLaunchKernelGGL((k_wavefront<false>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
                 it += fused_iters;
+                st->launches_wavefront += 1;
             } else
             for (uint32_t g = 0; g < group; ++g, ++it) {
                 hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
@@ -794,6 +807,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
                 else { if (diffuse_only) MSK_SHADE(false, true); else MSK_SHADE(false, false); }
 #undef MSK_SHADE
                 launch_trace(sc, stream_h, sb.st, pp, c, d);
+                st->launches_shade += 1; st->launches_trace += 1;
                 if (aov && aov->n_groups) hipLaunchKernelGGL(k_aov_primary, dim3(grid), dim3(MSK_BLOCK), 0, stream_h, sc->dev, sb.st, pp, *aov);
                 if (timed && have_ev) { cur_shade.push_back({a, b}); cur_trace.push_back({c, d}); }
             }
@@ -870,6 +884,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
             stats->iterations += hf.st.iterations;
             stats->ms_trace += hf.st.ms_trace; stats->ms_shade += hf.st.ms_shade;
             stats->n_trace_launches += hf.st.n_trace_launches; stats->n_shade_launches += hf.st.n_shade_launches;
+            stats->launches_trace += hf.st.launches_trace; stats->launches_shade += hf.st.launches_shade; stats->launches_wavefront += hf.st.launches_wavefront;
         }
     }
     (void) ev_trace; (void) ev_shade;
@@ -951,6 +966,10 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     for (size_t id = 0; id < all.size(); ++id) {
         spiral_id[(size_t) all[id].by * nbx + all[id].bx] = (uint32_t) id;
         if (id % bstride != prm->block_first || spp_owned == 0) continue;
+        // a block whose bordered area misses the crop window adds nothing to the film (accumulate_2d clips it to nothing,
+        // imageblock.cpp:133-150): it is not rendered
+        if (all[id].off_x - border >= sc->dev.crop_x + sc->dev.crop_w || all[id].off_x + all[id].size_x + border <= sc->dev.crop_x ||
+            all[id].off_y - border >= sc->dev.crop_y + sc->dev.crop_h || all[id].off_y + all[id].size_y + border <= sc->dev.crop_y) continue;
         block_of[(size_t) all[id].by * nbx + all[id].bx] = (int32_t) owned.size();
         owned.push_back(BlockInfo{all[id].off_x, all[id].off_y, all[id].size_x, all[id].size_y, 0u, (uint32_t) owned.size()});
         owned_all_index.push_back(id);
@@ -978,6 +997,7 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     const size_t state_bytes = 2 * n_slots * 144 + 4096;                              // two halves per region (StateBufs::alloc)
     const size_t held = ws.rec_a.bytes + ws.rec_b.bytes + ws.sb.id.bytes * 144 / 8;     // reusable: counts as free
     free_b += held;
+    free_b /= std::max(1u, ctx->device_sharers);
     size_t budget = getenv("MSK_RECORD_BUDGET_MB") ? (size_t) atoll(getenv("MSK_RECORD_BUDGET_MB")) << 20
                                                    : (free_b > state_bytes ? (size_t) ((free_b - state_bytes) * 0.8) : 0);
     const size_t rec_bytes_per_block_max = (size_t) bs * bs * spp_owned * rec_bytes;
@@ -1106,7 +1126,7 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
             FilmOut fo;
             fo.film = d_film; fo.stride = 5 + (int32_t) (aov ? aov->n_channels : 0u);
             for (int c = 0; c < 5; ++c) fo.ch[c] = g == 0 ? c : aov->out_ch[g - 1 < aov->n_groups ? g - 1 : MSK_MAX_AOV_GROUPS][c];
-            hipLaunchKernelGGL(k_film_put, dim3((uint32_t) (((size_t) W * H + MSK_BLOCK - 1) / MSK_BLOCK)), dim3(MSK_BLOCK), 0, stream,
+            hipLaunchKernelGGL(k_film_put, dim3((uint32_t) (((size_t) sc->dev.crop_w * sc->dev.crop_h + MSK_BLOCK - 1) / MSK_BLOCK)), dim3(MSK_BLOCK), 0, stream,
                                sc->dev, d_blocks.as<BlockInfo>(), d_block_of.as<int32_t>(), d_spiral.as<uint32_t>(), nbx, nby, bs,
                                g == 0 ? d_block_buf.as<float>() : ws.aov_block_buf[slot].as<float>(), buf_stride, fo);
         }
@@ -1137,7 +1157,7 @@ extern "C" int msk_gpu_render(msk_scene *scene, const msk_render_params *params,
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!scene->ws) scene->ws = new Workspace();
     DevBuf &film = scene->ws->film;
-    const size_t bytes = (size_t) scene->dev.width * scene->dev.height * 5 * 4;
+    const size_t bytes = (size_t) scene->dev.crop_w * scene->dev.crop_h * 5 * 4;
     HIP_TRY(ctx, film.reserve(bytes));
     int rc = render_impl(scene, params, film.as<float>(), nullptr, stats);
     if (rc) return rc;
@@ -1207,7 +1227,7 @@ extern "C" int msk_gpu_render_aov(msk_scene *scene, const msk_render_params *par
     if (!plan.rgba) p.max_depth = 0;      // no nested integrator: only the camera ray is traced and XYZ stays 0 (aov.cpp:91)
     if (!scene->ws) scene->ws = new Workspace();
     DevBuf &d_film = scene->ws->film;
-    const size_t bytes = (size_t) scene->dev.width * scene->dev.height * (5 + plan.n_channels) * 4;
+    const size_t bytes = (size_t) scene->dev.crop_w * scene->dev.crop_h * (5 + plan.n_channels) * 4;
     HIP_TRY(ctx, d_film.reserve(bytes));
     HIP_TRY(ctx, hipMemsetAsync(d_film.p, 0, bytes, ctx->stream));
     int rc = render_impl(scene, &p, d_film.as<float>(), nullptr, stats, &plan);

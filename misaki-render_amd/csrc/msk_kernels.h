@@ -78,6 +78,7 @@ struct DeviceScene {
     float s2c[16], to_world[16];
     float near_clip, far_clip;
     int32_t width, height;
+    int32_t crop_x, crop_y, crop_w, crop_h;     // the window of the film the render calls write (msk_film_desc: the whole film by default)
     float filter_radius, filter_scale;
     int32_t filter_border;
     float lut[33];
@@ -2299,14 +2300,14 @@ k_resolve_rows(DeviceScene sc, const BlockInfo *blocks, const RowBand *bands, ui
 }
 
 // Film::put for every block in spiral order (imageblock.cpp:36-53,133-173; D6: ascending block id).
-// One thread per film pixel; block_of[by*nbx+bx] = slot of that block's buffer or -1 (not rendered
+// One thread per pixel of the film's crop window; block_of[by*nbx+bx] = slot of that block's buffer or -1 (not rendered
 // by this rank), spiral_id gives the order.
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_film_put(DeviceScene sc, const BlockInfo *blocks, const int32_t *block_of, const uint32_t *spiral_id, int nbx, int nby,
            int block_size, const float *block_buf, uint32_t buf_stride, FilmOut out) {
-    const uint32_t gid = blockIdx.x * MSK_BLOCK + threadIdx.x;
-    if (gid >= (uint32_t) (sc.width * sc.height)) return;
-    const int x = (int) (gid % (uint32_t) sc.width), y = (int) (gid / (uint32_t) sc.width);
+    const uint32_t gid = blockIdx.x * MSK_BLOCK + threadIdx.x;            // a pixel of the crop window (the film that is written)
+    if (gid >= (uint32_t) (sc.crop_w * sc.crop_h)) return;
+    const int x = sc.crop_x + (int) (gid % (uint32_t) sc.crop_w), y = sc.crop_y + (int) (gid / (uint32_t) sc.crop_w);
     const int border = sc.filter_border;
     int cand[9]; uint32_t cid[9]; int nc = 0;
     const int bx0 = x / block_size, by0 = y / block_size;

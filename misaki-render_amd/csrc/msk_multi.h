@@ -35,6 +35,11 @@ static int group_init(const int *ids, int n, msk_ctx **out) {
         if (rc != MSK_OK) { msk_gpu_shutdown(g); return rc; }       // g_last_error holds the member's message
         g->group->ctxs.push_back(c);
     }
+    for (int k = 0; k < n; ++k) {
+        uint32_t same = 0;
+        for (int j = 0; j < n; ++j) same += ids[j] == ids[k];
+        g->group->ctxs[k]->device_sharers = same;
+    }
     g->device = ids[0];
     g->prop = g->group->ctxs[0]->prop;
     g->group->peer.assign(n, 1);
@@ -84,6 +89,7 @@ static int group_scene_create(msk_ctx *g, const msk_scene_desc *d, msk_scene **o
             return rc;
         }
     s->dev.width = s->parts[0]->dev.width; s->dev.height = s->parts[0]->dev.height;
+    s->dev.crop_w = s->parts[0]->dev.crop_w; s->dev.crop_h = s->parts[0]->dev.crop_h;
     *out = s;
     return MSK_OK;
 }
@@ -111,6 +117,7 @@ static void group_merge_stats(msk_stats *out, const std::vector<msk_stats> &st, 
         out->iterations = std::max(out->iterations, s.iterations); out->passes = std::max(out->passes, s.passes);
         out->ms_trace += s.ms_trace; out->ms_shade += s.ms_shade; out->ms_resolve = std::max(out->ms_resolve, s.ms_resolve);
         out->n_trace_launches += s.n_trace_launches; out->n_shade_launches += s.n_shade_launches;
+        out->launches_trace += s.launches_trace; out->launches_shade += s.launches_shade; out->launches_wavefront += s.launches_wavefront;
     }
     out->ms_total = ms_wall;                 // host wall time of the whole call: the members' renders side by side + the film sum
 }
@@ -120,7 +127,7 @@ static int group_render_device(msk_scene *s, const msk_render_params *params, fl
     msk_ctx *g = s->ctx;
     if (!params) return fail(g, MSK_ERR_INVALID_ARG, "render params are NULL");
     const size_t n = s->parts.size();
-    const size_t count = (size_t) s->dev.width * s->dev.height * 5, bytes = count * 4;
+    const size_t count = (size_t) s->dev.crop_w * s->dev.crop_h * 5, bytes = count * 4;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<int> rcs(n, MSK_OK);
     std::vector<msk_stats> st(n);
@@ -161,7 +168,7 @@ static int group_render_device(msk_scene *s, const msk_render_params *params, fl
 
 static int group_render(msk_scene *s, const msk_render_params *params, float *film_xyzaw, msk_stats *stats) {
     msk_ctx *g = s->ctx;
-    const size_t bytes = (size_t) s->dev.width * s->dev.height * 5 * 4;
+    const size_t bytes = (size_t) s->dev.crop_w * s->dev.crop_h * 5 * 4;
     HIP_TRY(g, hipSetDevice(g->device));
     HIP_TRY(g, s->group_film.reserve(bytes));
     const int rc = group_render_device(s, params, s->group_film.as<float>(), nullptr, stats);
@@ -176,7 +183,7 @@ static int group_render_aov(msk_scene *s, const msk_render_params *params, const
     msk_ctx *g = s->ctx;
     const size_t n = s->parts.size();
     const uint32_t ch = 5 + msk_gpu_aov_channels(aov_types, n_aovs);
-    const size_t count = (size_t) s->dev.width * s->dev.height * ch;
+    const size_t count = (size_t) s->dev.crop_w * s->dev.crop_h * ch;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::vector<float>> films(n);
     std::vector<int> rcs(n, MSK_OK);

@@ -101,6 +101,15 @@ int msk_host_film_size(msk_host_scene *h, int *w, int *hgt, int *spp) {
     } catch (const std::exception &e) { return fail(e); }
 }
 
+// the film's crop window {offset x, y, width, height}: the size of the storage msk_host_render copies out (film.cpp:12-21)
+int msk_host_film_crop(msk_host_scene *h, int *xywh) {
+    try {
+        const Film *f = h->scene->sensor()->film();
+        xywh[0] = f->crop_offset().x; xywh[1] = f->crop_offset().y; xywh[2] = f->crop_size().x; xywh[3] = f->crop_size().y;
+        return 0;
+    } catch (const std::exception &e) { return fail(e); }
+}
+
 int msk_host_srgb_model_fetch(const float *rgb, float *out) {
     try { Color3 c = srgb_model_fetch(Color3{rgb[0], rgb[1], rgb[2]}); out[0] = c.r; out[1] = c.g; out[2] = c.b; return 0; }
     catch (const std::exception &e) { return fail(e); }

@@ -804,9 +804,10 @@ void flatten_scene(const Scene *scene, const Sensor *sensor, FlatScene &out) {
     d.vertices = out.vertices.data(); d.faces = out.faces.data(); d.n_vertices = nv; d.n_faces = nf;
     if (!sensor->flatten(d.camera)) Throw("Sensor \"{}\" is not supported by the GPU path integrator", sensor->clazz()->name());
     const Film *film = sensor->film();
-    if (film->crop_size().x != film->size().x || film->crop_size().y != film->size().y)
-        Throw("Crop windows are not supported by the GPU path integrator");
     d.film.width = film->size().x; d.film.height = film->size().y;
+    // film.cpp:12-21: the window HDRFilm's storage covers (hdrfilm.cpp:37-38) — what the render calls write
+    d.film.crop_offset[0] = film->crop_offset().x; d.film.crop_offset[1] = film->crop_offset().y;
+    d.film.crop_size[0] = film->crop_size().x; d.film.crop_size[1] = film->crop_size().y;
     d.film.filter_radius = film->filter()->radius();
     std::memcpy(d.film.filter_lut, film->filter()->values().data(), sizeof d.film.filter_lut);
     d.cie1931_xyz = cie1931_xyz_table(); d.d65 = d65_table();
@@ -866,7 +867,8 @@ public:
         if (!m_ctx && msk_gpu_init(m_devices.data(), (int) m_devices.size(), &m_ctx) != MSK_OK) Throw("{}", msk_gpu_last_error(nullptr));
         msk_scene *gs = nullptr;
         if (msk_gpu_scene_create(m_ctx, &flat.desc, &gs) != MSK_OK) Throw("{}", msk_gpu_last_error(m_ctx));
-        ref<ImageBlock> whole = new ImageBlock(size, 5);
+        ref<ImageBlock> whole = new ImageBlock(film->crop_size(), 5);        // the crop window (the whole film by default), as the storage holds it
+        whole->set_offset(film->crop_offset());
         msk_stats st;
         const int rc = msk_gpu_render(gs, &flat.params, whole->data().data(), &st);
         msk_gpu_scene_destroy(gs);

@@ -2,8 +2,11 @@
 // (render/srgb.h:8-19), read trilinearly from the res-64 sRGB table exactly as ext/rgb2spec/rgb2spec.c:77-119 does.
 // The reference loads "data/srgb.coeff", written at build time by its rgb2spec_opt tool; this library looks for the same
 // file (same layout) and, if there is none, computes the table with its own optimiser (rgb2spec_table.cpp, a few seconds
-// on the host's cores) and caches it beside the shared library.  Search order:
-//   $MSK_SRGB_COEFF, <directory of libmisaki-render.so>/srgb.coeff, file resolver "data/srgb.coeff".
+// on the host's cores) and caches it.  Search order:
+//   $MSK_SRGB_COEFF (must load if set), the file resolver's "data/srgb.coeff" (the reference's one location, srgb.cpp:13: a
+//   scene or an install that ships its own table is honoured), <directory of libmisaki-render.so>/srgb.coeff, and the per-user
+//   cache ($XDG_CACHE_HOME or ~/.cache)/misaki-render/srgb.coeff.  A computed table is written beside the library when that
+//   directory is writable (the in-tree build), else into the per-user cache — never into a read-only install.
 // One deliberate deviation: pure black.  rgb2spec_fetch computes (res - 1) / 0 * 0 = NaN for it and returns NaN
 // coefficients; here black is the constant-zero spectrum (0, 0, -inf) that srgb_model_eval (render/srgb.h:13-14) knows.
 #include <misaki/render.h>
@@ -11,6 +14,7 @@
 #include <dlfcn.h>
 
 #include <cmath>
+#include <filesystem>
 #include <mutex>
 
 namespace misaki {
@@ -36,8 +40,12 @@ const Model &model() {
     std::vector<std::string> candidates;
     if (const char *e = getenv("MSK_SRGB_COEFF")) candidates.push_back(e);
     const std::string beside = library_dir() + "/srgb.coeff";
-    candidates.push_back(beside);
+    std::string cache;
+    if (const char *x = getenv("XDG_CACHE_HOME")) cache = std::string(x) + "/misaki-render";
+    else if (const char *h = getenv("HOME")) cache = std::string(h) + "/.cache/misaki-render";
     candidates.push_back(get_file_resolver()->resolve("data/srgb.coeff"));
+    candidates.push_back(beside);
+    if (!cache.empty()) candidates.push_back(cache + "/srgb.coeff");
     for (const auto &c : candidates)
         if (rgb2spec_read_table(c, m->scale, m->data)) { m->source = c; break; }
     if (m->source.empty()) {
@@ -46,7 +54,12 @@ const Model &model() {
         rgb2spec_build_table(64, m->scale, m->data, 0);
         m->source = "(computed)";
         try { rgb2spec_write_table(beside, m->scale, m->data); m->source = beside; }
-        catch (const std::exception &) { /* read-only install: keep the in-memory table */ }
+        catch (const std::exception &) {                 // read-only install: the per-user cache, or just the in-memory table
+            if (!cache.empty()) {
+                try { std::filesystem::create_directories(cache); rgb2spec_write_table(cache + "/srgb.coeff", m->scale, m->data); m->source = cache + "/srgb.coeff"; }
+                catch (const std::exception &) {}
+            }
+        }
     } else {
         Log(Info, "Loading spectral upsampling model \"{}\" .. ", m->source);
     }

@@ -16,6 +16,9 @@
 // values are rounded to float once.
 #include <misaki/render.h>
 
+#include <stdlib.h>
+#include <unistd.h>
+
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -189,10 +192,14 @@ void rgb2spec_build_table(int res, std::vector<float> &scale, std::vector<float>
     if (failed) Throw("rgb2spec_build_table: singular Jacobian");
 }
 
+// Written to a temporary file this PROCESS created exclusively (mkstemp: several ranks that find no table each compute it and
+// write at the same time), then renamed over `path`: a reader sees either no file or a complete one.
 void rgb2spec_write_table(const std::string &path, const std::vector<float> &scale, const std::vector<float> &data) {
-    const std::string tmp = path + ".tmp" + std::to_string((unsigned long) std::hash<std::thread::id>()(std::this_thread::get_id()));
-    FILE *f = std::fopen(tmp.c_str(), "wb");
-    if (!f) Throw("Could not create \"{}\"", tmp);
+    std::string tmp = path + ".tmp.XXXXXX";
+    const int fd = mkstemp(&tmp[0]);
+    if (fd < 0) Throw("Could not create \"{}\"", tmp);
+    FILE *f = fdopen(fd, "wb");
+    if (!f) { close(fd); std::remove(tmp.c_str()); Throw("Could not create \"{}\"", tmp); }
     const uint32_t res = (uint32_t) scale.size();
     bool ok = std::fwrite("SPEC", 4, 1, f) == 1 && std::fwrite(&res, 4, 1, f) == 1 &&
               std::fwrite(scale.data(), sizeof(float), scale.size(), f) == scale.size() &&
@@ -214,6 +221,15 @@ bool rgb2spec_read_table(const std::string &path, std::vector<float> &scale, std
              std::fread(data.data(), sizeof(float), data.size(), f) == data.size();
     }
     std::fclose(f);
+    // a table is finite numbers throughout (a torn or zero-filled file is not taken for one: all-zero coefficients, or scale
+    // values that do not rise from 0 to 1, mean "no table here")
+    if (ok) {
+        ok = scale.front() == 0.f && scale.back() == 1.f;
+        for (size_t i = 1; ok && i < scale.size(); ++i) ok = scale[i] > scale[i - 1];
+        bool any = false;
+        for (size_t i = 0; ok && i < data.size(); ++i) { ok = std::isfinite(data[i]); any = any || data[i] != 0.f; }
+        ok = ok && any;
+    }
     return ok;
 }
 

@@ -30,6 +30,7 @@ def load():
         lib.msk_host_flatten.argtypes = [vp, C.POINTER(abi.SceneDesc), C.POINTER(abi.RenderParams)]
         lib.msk_host_render.argtypes = [vp, vp, vp, C.c_char_p, C.POINTER(abi.Stats)]
         lib.msk_host_film_size.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.msk_host_film_crop.argtypes = [vp, C.POINTER(C.c_int * 4)]
         lib.msk_host_aov_names.argtypes = [vp, C.c_char_p, C.c_size_t]
         lib.msk_host_aov_types.argtypes = [vp, vp, C.c_size_t]
         lib.msk_host_srgb_model_fetch.argtypes = [vp, vp]
@@ -68,6 +69,12 @@ class HostScene:
         _check(self.lib.msk_host_film_size(self.h, C.byref(w), C.byref(h), C.byref(s)))
         return w.value, h.value, s.value
 
+    def film_crop(self):
+        """(offset_x, offset_y, width, height) of the film's crop window = the storage a render fills"""
+        a = (C.c_int * 4)()
+        _check(self.lib.msk_host_film_crop(self.h, C.byref(a)))
+        return tuple(a)
+
     def flatten(self):
         """The flatten step of the "path" plugin -> (msk_scene_desc, msk_render_params)."""
         d, p = abi.SceneDesc(), abi.RenderParams()
@@ -89,9 +96,9 @@ class HostScene:
         return [int(x) for x in buf[:n]]
 
     def render(self, develop_to=None):
-        """scene->integrator()->render(scene, sensor) on the GPU -> (film[H,W,5+C], image[H,W,4+C], Stats);
+        """scene->integrator()->render(scene, sensor) on the GPU -> (film[H,W,5+C], image[H,W,4+C], Stats), H x W the film's crop window;
         C = the integrator's AOV channel count (0 for "path")."""
-        w, h, _ = self.film_size()
+        _, _, w, h = self.film_crop()
         c = len(self.aov_names())
         film, rgba, st = np.zeros((h, w, 5 + c), np.float32), np.zeros((h, w, 4 + c), np.float32), abi.Stats()
         _check(self.lib.msk_host_render(self.h, film.ctypes.data_as(C.c_void_p), rgba.ctypes.data_as(C.c_void_p),

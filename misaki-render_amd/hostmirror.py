@@ -180,7 +180,7 @@ def _bsdf_xml(m, v3):
 
 
 def write_scene_xml(meshes, directory, width, height, spp, camera=None, integrator_props=None, film_type="hdrfilm",
-                    filename="scene.xml", env=None):
+                    filename="scene.xml", env=None, film_props=None):
     """Writes <directory>/meshes/*.obj and a Mitsuba-style scene XML the C++ host (and the reference's
     loader) understands; same structure as results/Figure_1_Pathtrace/scene.xml, $-parameters for spp/size."""
     camera = camera or CBOX_CAMERA
@@ -197,7 +197,8 @@ def write_scene_xml(meshes, directory, width, height, spp, camera=None, integrat
             '            <lookat origin="%s" target="%s" up="%s"/>' % (v3(camera["origin"]), v3(camera["target"]), v3(camera["up"])),
             '        </transform>', '        <sampler type="independent">', '            <integer name="sample_count" value="$spp"/>',
             '        </sampler>', '        <film type="%s">' % film_type, '            <integer name="width" value="$width"/>',
-            '            <integer name="height" value="$height"/>', '        </film>', '    </sensor>']
+            '            <integer name="height" value="$height"/>'] + \
+           ['            <integer name="%s" value="%d"/>' % (k, int(v)) for k, v in (film_props or {}).items()] + ['        </film>', '    </sensor>']
 
     def env_xml():
         rad = env.get("radiance")
@@ -383,12 +384,13 @@ def _radiance_desc(radiance, fetch, scale_in=1.0):
     return ce, float(np.float32(np.float32(scale_in) * scale) * (np.float32(1.0) / np.float32(10568.0)))
 
 
-def flatten(meshes, width, height, camera=None, filter_stddev=0.5, coeff_lookup=None, env=None):
+def flatten(meshes, width, height, camera=None, filter_stddev=0.5, coeff_lookup=None, env=None, crop=None):
     """Scene -> msk_scene_desc, the step the `"path"` plugin's render() performs before calling
     the C ABI.  coeff_lookup(rgb)->(c0,c1,c2) overrides the spectral upsampling
     (tests pass the reference's own rgb2spec_fetch results); default = this package's rgb2spec.
     env: None, or {"radiance": rgb | None (= D65), "scale": 1.0, "first": False} = a top-level
-    <emitter type="constant"> placed after (or, with first=True, before) the shapes in the XML."""
+    <emitter type="constant"> placed after (or, with first=True, before) the shapes in the XML.
+    crop: None, or (offset_x, offset_y, width, height) = the film's crop_offset_x/_y, crop_width/_height (film.cpp:12-21)."""
     from . import rgb2spec
     fetch = coeff_lookup or rgb2spec.srgb_model_fetch
     camera = camera or CBOX_CAMERA
@@ -440,14 +442,17 @@ def flatten(meshes, width, height, camera=None, filter_stddev=0.5, coeff_lookup=
     radius, lut = gaussian_filter(filter_stddev)
     d.film.width, d.film.height, d.film.filter_radius = width, height, radius
     d.film.filter_lut[:] = lut.tolist()
+    if crop is not None:
+        d.film.crop_offset[:] = [int(crop[0]), int(crop[1])]
+        d.film.crop_size[:] = [int(crop[2]), int(crop[3])]
     d.cie1931_xyz = cie.ctypes.data_as(C.POINTER(C.c_float))
     d.d65 = d65.ctypes.data_as(C.POINTER(C.c_float))
     fs.vertices, fs.faces = verts, faces
     return fs
 
 
-def cbox_scene(width, height, coeff_lookup=None, extra_meshes=()):
-    return flatten(cbox_meshes() + list(extra_meshes), width, height, coeff_lookup=coeff_lookup)
+def cbox_scene(width, height, coeff_lookup=None, extra_meshes=(), crop=None):
+    return flatten(cbox_meshes() + list(extra_meshes), width, height, coeff_lookup=coeff_lookup, crop=crop)
 
 
 # BASELINE configs 3 and 5 name assets/bunny and assets/teapot-full, whose meshes the reference does not ship

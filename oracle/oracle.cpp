@@ -279,6 +279,18 @@ static Scene *scene_from_desc(const msk_scene_desc *d) {
 struct Ray { V3 o, d; float mint, maxt; };
 struct Hit { float t, u, v; uint32_t prim; bool valid; };
 
+// How far the two oracle-side rules are from a plain Moeller-Trumbore / first-found intersector: per-thread
+// tallies, summed into g_isect by isect_flush() (the render workers and the ray batches call it), read and cleared through
+// msk_oracle_isect_counters().  [0] closest-hit rays  [1] any-hit rays  [2] triangle tests Moeller-Trumbore accepts
+// [3] of those, rejected by the D10 bounds predicate  [4] closest-hit rays that met a D10-rejected hit NEARER than the hit
+// they report (or report none): the rays whose answer D10 can have changed, as this tree's traversal meets them
+// [5] any-hit rays reported unoccluded that met a D10-rejected hit  [6] closest-hit rays whose reported t is shared by
+// a second triangle (the "smallest prim" rule decided)  [7] accepted-hit pairs with equal t met on the way
+static std::atomic<uint64_t> g_isect[8];
+struct IsectTally { uint64_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0}; float rej_t = kInf; bool rej = false; };
+static thread_local IsectTally tl_isect;
+static void isect_flush() { for (int i = 0; i < 8; ++i) { g_isect[i].fetch_add(tl_isect.v[i], std::memory_order_relaxed); tl_isect.v[i] = 0; } }
+
 static inline float xor_sign(float a, uint32_t sgn) {
     uint32_t b; std::memcpy(&b, &a, 4); b ^= sgn; std::memcpy(&a, &b, 4); return a;
 }
@@ -313,9 +325,13 @@ static inline bool intersect_triangle(const Tri &tr, const Ray &ray, float *t, f
     // holds it (v0, v0 - e1, v0 + e2), grown by `pad`
     const V3 q1 = tr.p0 - e1, q2 = tr.p0 + e2;
     const float px = ray.o.x + *t * ray.d.x, py = ray.o.y + *t * ray.d.y, pz = ray.o.z + *t * ray.d.z;
-    return px >= std::min(tr.p0.x, std::min(q1.x, q2.x)) - pad && px <= std::max(tr.p0.x, std::max(q1.x, q2.x)) + pad &&
+    const bool inside =
+           px >= std::min(tr.p0.x, std::min(q1.x, q2.x)) - pad && px <= std::max(tr.p0.x, std::max(q1.x, q2.x)) + pad &&
            py >= std::min(tr.p0.y, std::min(q1.y, q2.y)) - pad && py <= std::max(tr.p0.y, std::max(q1.y, q2.y)) + pad &&
            pz >= std::min(tr.p0.z, std::min(q1.z, q2.z)) - pad && pz <= std::max(tr.p0.z, std::max(q1.z, q2.z)) + pad;
+    tl_isect.v[2] += 1;
+    if (!inside) { tl_isect.v[3] += 1; tl_isect.rej = true; tl_isect.rej_t = std::min(tl_isect.rej_t, *t); }
+    return inside;
 }
 
 static inline bool box_hit(const BVHNode &n, const Ray &r, V3 inv, float tbest) {
@@ -332,9 +348,13 @@ static inline bool box_hit(const BVHNode &n, const Ray &r, V3 inv, float tbest) 
 
 static Hit closest_hit(const Scene &sc, const Ray &ray) {
     Hit best{kInf, 0, 0, 0xffffffffu, false};
+    bool tied = false;
+    tl_isect.v[0] += 1; tl_isect.rej = false; tl_isect.rej_t = kInf;
     auto consider = [&](uint32_t prim) {
         float t, u, v;
         if (intersect_triangle(sc.tris[prim], ray, &t, &u, &v, sc.tri_pad)) {
+            if (best.valid && t == best.t) { tl_isect.v[7] += 1; tied = true; }
+            else if (!best.valid || t < best.t) tied = false;
             if (!best.valid || t < best.t || (t == best.t && prim < best.prim))
                 best = Hit{t, u, v, prim, true};
         }
@@ -353,10 +373,19 @@ static Hit closest_hit(const Scene &sc, const Ray &ray) {
     }
     // scene.cpp:234  `if (rh.ray.tfar != ray.maxt)`
     if (best.valid && best.t == ray.maxt) best.valid = false;
+    if (tl_isect.rej && (!best.valid || tl_isect.rej_t < best.t)) tl_isect.v[4] += 1;
+    if (best.valid && tied) tl_isect.v[6] += 1;
     return best;
 }
 
+static bool any_hit_walk(const Scene &sc, const Ray &ray);
 static bool any_hit(const Scene &sc, const Ray &ray) {   // scene.cpp:255-273
+    tl_isect.v[1] += 1; tl_isect.rej = false;
+    const bool occluded = any_hit_walk(sc, ray);
+    if (!occluded && tl_isect.rej) tl_isect.v[5] += 1;
+    return occluded;
+}
+static bool any_hit_walk(const Scene &sc, const Ray &ray) {
     float t, u, v;
     if (!sc.use_bvh || sc.nodes.empty()) {
         for (uint32_t p = 0; p < sc.tris.size(); ++p)
@@ -997,9 +1026,10 @@ struct ImageBlock {
 };
 // imageblock.cpp:36-53 put(block) -> accumulate_2d (:133-173): source block with
 // border into a borderless target at offset (0,0)
-static void film_put(float *film, int fw, int fh, const ImageBlock &b) {
+// film = HDRFilm's storage: a borderless ImageBlock of the crop size at the crop offset (hdrfilm.cpp:37-38; the whole film by default)
+static void film_put(float *film, int fw, int fh, const ImageBlock &b, int crop_x = 0, int crop_y = 0) {
     int ssx = b.size_x + 2 * b.border, ssy = b.size_y + 2 * b.border;
-    int tox = b.off_x - b.border, toy = b.off_y - b.border;   // source_offset - target_offset
+    int tox = b.off_x - b.border - crop_x, toy = b.off_y - b.border - crop_y;   // source_offset - target_offset
     int sox = 0, soy = 0, szx = ssx, szy = ssy;
     int incx = std::max(0, std::max(-sox, -tox)), incy = std::max(0, std::max(-soy, -toy));
     sox += incx; soy += incy; tox += incx; toy += incy; szx -= incx; szy -= incy;
@@ -1095,6 +1125,11 @@ static void render(const Scene &sc, const msk_render_params &prm, float *film, C
                    const AovSpec *aov = nullptr) {
     const int n_ch = 5 + (aov ? aov->channels : 0);
     const int W = sc.film.width, H = sc.film.height;
+    // film.cpp:12-21: the crop window; the block schedule and the sensor stay those of the full film (integrator.cpp:45)
+    const bool whole = sc.film.crop_size[0] == 0 && sc.film.crop_size[1] == 0;
+    const int CX = whole ? 0 : sc.film.crop_offset[0], CY = whole ? 0 : sc.film.crop_offset[1];
+    const int CW = whole ? W : sc.film.crop_size[0], CH = whole ? H : sc.film.crop_size[1];
+    const int border = (int) std::ceil(sc.film.filter_radius - .5f);      // rfilter.cpp:22
     std::vector<BlockDesc> blocks = spiral_blocks(W, H, prm.block_size);
     std::vector<ImageBlock> done(blocks.size());
     std::atomic<size_t> next{0};
@@ -1107,6 +1142,10 @@ static void render(const Scene &sc, const msk_render_params &prm, float *film, C
             if (id >= blocks.size()) break;
             if (id % bstride != prm.block_first) continue;
             const BlockDesc &bd = blocks[id];
+            // The reference renders every block of the full film and lets accumulate_2d clip it against the storage
+            // (imageblock.cpp:133-150); a block whose bordered area misses the crop window is clipped to nothing there, so it is
+            // skipped here (and by the GPU side, msk_gpu.h: msk_film_desc) instead of being rendered and thrown away.
+            if (bd.off_x - border >= CX + CW || bd.off_x + bd.size_x + border <= CX || bd.off_y - border >= CY + CH || bd.off_y + bd.size_y + border <= CY) continue;
             ImageBlock blk;
             blk.off_x = bd.off_x; blk.off_y = bd.off_y; blk.channels = n_ch;
             blk.init(bd.size_x, bd.size_y, &sc.film, true);
@@ -1131,13 +1170,14 @@ static void render(const Scene &sc, const msk_render_params &prm, float *film, C
         }
         std::lock_guard<std::mutex> g(mtx);
         total->samples += cnt.samples; total->segments += cnt.segments; total->shadow_rays += cnt.shadow_rays;
+        isect_flush();
     };
     std::vector<std::thread> pool;
     for (int i = 0; i < std::max(1, n_threads); ++i) pool.emplace_back(worker);
     for (auto &t : pool) t.join();
-    std::fill(film, film + (size_t) W * H * n_ch, 0.f);            // hdrfilm.cpp:37-39
+    std::fill(film, film + (size_t) CW * CH * n_ch, 0.f);          // hdrfilm.cpp:37-39
     for (size_t id = 0; id < blocks.size(); ++id)                  // D6
-        if (!done[id].data.empty()) film_put(film, W, H, done[id]);
+        if (!done[id].data.empty()) film_put(film, CW, CH, done[id], CX, CY);
 }
 
 }  // namespace orc
@@ -1151,11 +1191,11 @@ template <typename F> static void for_rays(uint64_t n, F body) {
     unsigned nt = std::thread::hardware_concurrency();
     if (const char *e = getenv("MSK_ORACLE_THREADS")) nt = (unsigned) atoi(e);
     nt = std::max(1u, std::min(nt, 64u));
-    if (n < 4096 || nt == 1) { for (uint64_t i = 0; i < n; ++i) body(i); return; }
+    if (n < 4096 || nt == 1) { for (uint64_t i = 0; i < n; ++i) body(i); orc::isect_flush(); return; }
     std::vector<std::thread> pool;
     std::atomic<uint64_t> next{0};
     for (unsigned t = 0; t < nt; ++t)
-        pool.emplace_back([&]() { for (;;) { const uint64_t b = next.fetch_add(256); if (b >= n) break; for (uint64_t i = b; i < std::min(n, b + 256); ++i) body(i); } });
+        pool.emplace_back([&]() { for (;;) { const uint64_t b = next.fetch_add(256); if (b >= n) break; for (uint64_t i = b; i < std::min(n, b + 256); ++i) body(i); } orc::isect_flush(); });
     for (auto &t : pool) t.join();
 }
 using namespace orc;
@@ -1166,6 +1206,8 @@ void msk_oracle_scene_destroy(void *s) { delete (Scene *) s; }
 void msk_oracle_set_bvh(void *s, int on) { ((Scene *) s)->use_bvh = on; }
 void msk_oracle_set_libm(int on) { g_use_libm = on; }
 void msk_oracle_set_trace(int on) { g_trace_path = on; }
+// reads and clears the intersection tallies (see g_isect)
+void msk_oracle_isect_counters(uint64_t *out8) { isect_flush(); for (int i = 0; i < 8; ++i) out8[i] = g_isect[i].exchange(0); }
 
 int msk_oracle_render(void *s, const msk_render_params *prm, float *film, msk_stats *stats, int n_threads) {
     Counters c;

@@ -131,6 +131,14 @@ class Oracle:
     def set_libm(self, on):
         self.lib.msk_oracle_set_libm(int(on))
 
+    def isect_counters(self):
+        """Reads and clears the oracle's intersection tallies (oracle.cpp: g_isect) -> dict"""
+        a = (C.c_uint64 * 8)()
+        self.lib.msk_oracle_isect_counters(a)
+        names = ("closest_rays", "any_rays", "mt_accepts", "d10_rejects", "closest_rays_d10_could_change", "any_rays_unoccluded_with_d10_reject",
+                 "closest_rays_tie_decided", "equal_t_pairs")
+        return dict(zip(names, [int(x) for x in a]))
+
     def gaussian_filter(self, stddev):
         r, sf = C.c_float(), C.c_float()
         b = C.c_int()
@@ -173,9 +181,13 @@ class OracleScene:
     def set_bvh(self, on):
         self.orc.lib.msk_oracle_set_bvh(self.h, int(on))
 
+    def _film_shape(self):
+        f = self.flat.desc.film             # the crop window (msk_film_desc: {0, 0} = the whole film)
+        return (f.crop_size[1], f.crop_size[0]) if (f.crop_size[0] or f.crop_size[1]) else (f.height, f.width)
+
     def render(self, params, threads=8):
-        d = self.flat.desc
-        film = np.zeros((d.film.height, d.film.width, 5), np.float32)
+        h, w = self._film_shape()
+        film = np.zeros((h, w, 5), np.float32)
         st = self.abi.Stats()
         rc = self.orc.lib.msk_oracle_render(self.h, C.byref(params), _p(film), C.byref(st), threads)
         assert rc == 0
@@ -185,7 +197,8 @@ class OracleScene:
         d = self.flat.desc
         types = np.ascontiguousarray(aov_types, np.int32)
         n_ch = sum(self.abi.AOV_WIDTH[t] for t in types)
-        film = np.zeros((d.film.height, d.film.width, 5 + n_ch), np.float32)
+        h, w = self._film_shape()
+        film = np.zeros((h, w, 5 + n_ch), np.float32)
         st = self.abi.Stats()
         rc = self.orc.lib.msk_oracle_render_aov(self.h, C.byref(params), _p(types), len(types), _p(film), C.byref(st), threads)
         assert rc == 0

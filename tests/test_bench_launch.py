@@ -29,6 +29,8 @@ def test_bare_shell_gpus_2_spawns_two_ranks():
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["dry_run"] and d["reduce_ok"] and d["steps"] == 2 and d["warmup"] == 1
     assert d["config"]["samples_per_step"] == 512 * 512 * 512 * 2          # weak scaling: 512 spp per rank
+    # the equal sample-stride split is the default (--balance is opt-in); the line says how many ranks met and what the node showed
+    assert d["config"]["balance"] is None and d["config"]["rccl_ranks"] == 2 and isinstance(d["config"]["devices_seen"], int)
 
 
 def test_under_torch_distributed_run():
@@ -53,6 +55,26 @@ def test_single_rank_dry_run():
 import pytest
 
 
+def test_too_few_gpus_ends_before_any_rendezvous():
+    """`--gpus N` on a node that shows fewer than N devices: one line on stderr, a non-zero exit code, nothing spawned (bare
+    shell) / no rendezvous entered (under a launcher) — asked of a box without a GPU here, so 0 < 2 either way."""
+    import time
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120, env=_env(), cwd=ROOT)
+    assert r.returncode == 2 and r.stdout == "" and len(r.stderr.strip().split("\n")) == 1 and "this node shows" in r.stderr, r.stderr
+    env = dict(_env(), RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_PORT="1")         # a rank as a launcher would start it
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert r.returncode == 2 and "rank 1 stops" in r.stderr and time.time() - t0 < 100
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--in-process", "2", "--gpus", "2"], capture_output=True, text=True,
+                       timeout=120, env=_env(), cwd=ROOT)
+    assert r.returncode == 2 and "two different multi-GPU paths" in r.stderr
+
+
 def test_a_dead_rank_ends_the_launch_quickly():
     """A rank that exits before the rendezvous must not leave the others (and the shell) waiting for the process-group
     timeout: the launcher stops the siblings and returns the failing rank's code."""
@@ -66,18 +88,39 @@ def test_a_dead_rank_ends_the_launch_quickly():
 @pytest.mark.gpu
 def test_two_ranks_rehearsed_on_one_gpu():
     """The N = 2 path with real renders: two rank processes spawned from a bare shell, both on cuda:0, sample shards
-    (each rank every tile, its half of the sample indices), the warm-up's speed-proportional re-split, the film summed onto
-    rank 0 (gloo through host copies here, RCCL on a real node) — checked against one rank rendering all the samples."""
+    (each rank every tile, its half of the sample indices; once with the equal split that is the default, once with --balance's
+    speed-proportional re-split after the warm-up), the film summed onto rank 0 (gloo through host copies here, RCCL on a real
+    node) and copied to the host — checked against one rank rendering all the samples."""
     common = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs"]
-    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--spp", "8"] + common,
-                        capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
-    assert r2.returncode == 0, r2.stderr[-2000:]
-    d2 = _last_json(r2.stdout)
-    assert d2["n_gpus"] == 2 and d2["rehearsal"] and d2["film_finite"] and d2["value"] > 0
-    assert d2["config"]["samples_per_step"] == 512 * 512 * 16
+    for extra in ([], ["--balance"]):
+        r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--spp", "8"] + common + extra,
+                            capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+        assert r2.returncode == 0, r2.stderr[-2000:]
+        d2 = _last_json(r2.stdout)
+        assert d2["n_gpus"] == 2 and d2["rehearsal"] and d2["film_finite"] and d2["value"] > 0
+        assert d2["config"]["samples_per_step"] == 512 * 512 * 16 and d2["config"]["rccl_ranks"] == 2
+        if not extra:
+            assert d2["config"]["balance"] is None
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rehearse-on-one-gpu", "--spp", "16"] + common,
                         capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
     assert r1.returncode == 0, r1.stderr[-2000:]
     d1 = _last_json(r1.stdout)
     # the same 16 samples per pixel either way: the filter-weight sums agree up to the re-association of two partial sums
     assert abs(d2["film_weight_sum"] - d1["film_weight_sum"]) <= 1e-5 * abs(d1["film_weight_sum"])
+
+
+@pytest.mark.gpu
+def test_in_process_group_rehearsed_on_one_gpu():
+    """`--in-process 2`: ONE process, two member contexts behind one msk_ctx (both on cuda:0 here), the library shards the
+    samples over them and sums the films with k_film_sum — the line of the other multi-GPU path (msk_multi.h)."""
+    common = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--spp", "8"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--in-process", "2", "--rehearse-on-one-gpu"] + common,
+                       capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["rehearsal"] and d["film_finite"] and d["config"]["in_process_members"] == 2
+    assert d["config"]["samples_per_step"] == 512 * 512 * 16 and "k_film_sum" in d["config"]["parallelism"]
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rehearse-on-one-gpu", "--spp", "16"] + common[:-2],
+                        capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    d1 = _last_json(r1.stdout)
+    assert abs(d["film_weight_sum"] - d1["film_weight_sum"]) <= 1e-5 * abs(d1["film_weight_sum"])

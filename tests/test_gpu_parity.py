@@ -138,6 +138,38 @@ def test_ragged_film_and_single_sample(gpu_ctx, abi, hostmirror, oracle, golden_
     o.close()
 
 
+def test_crop_window_bit_exact(gpu_ctx, abi, hostmirror, oracle, golden_lookup):
+    """film.cpp:12-21 / hdrfilm.cpp:37-38: the film's crop window.  The sensor and the block schedule stay those of the full
+    100x40 film; the film that comes back is the 37x21 window at (11, 5) — bit for bit the oracle's, and bit for bit that
+    window of the uncropped film (Film::put clips every block to the storage, imageblock.cpp:133-173)."""
+    full = cbox(hostmirror, golden_lookup, 100, 40)
+    crop = hostmirror.cbox_scene(100, 40, coeff_lookup=golden_lookup, crop=(11, 5, 37, 21))
+    g, gf, o = abi.Scene(gpu_ctx, crop), abi.Scene(gpu_ctx, full), oracle.scene(crop)
+    for prm in (abi.render_params(spp=6, seed=3), abi.render_params(spp=3, seed=3, block_size=16), abi.render_params(spp=4, block_first=1, block_stride=2)):
+        film, st = g.render(prm)
+        ref, rst = o.render(prm, threads=4)
+        assert film.shape == (21, 37, 5) and st.samples == rst.samples and st.segments == rst.segments
+        assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+        whole, wst = gf.render(prm)
+        assert np.array_equal(film.view(np.uint32), whole[5:26, 11:48].view(np.uint32))
+        assert st.samples < wst.samples                           # the blocks that cannot reach the window are not rendered
+    # a window in the last, ragged block row and column; the whole film given explicitly
+    for c in ((90, 30, 10, 10), (0, 0, 100, 40), (64, 0, 1, 1)):
+        fc = hostmirror.cbox_scene(100, 40, coeff_lookup=golden_lookup, crop=c)
+        gc = abi.Scene(gpu_ctx, fc)
+        prm = abi.render_params(spp=2, seed=5)
+        film, _ = gc.render(prm)
+        whole, _ = gf.render(prm)
+        assert np.array_equal(film.view(np.uint32), whole[c[1]:c[1] + c[3], c[0]:c[0] + c[2]].view(np.uint32)), c
+        gc.close()
+    for bad in ((-1, 0, 10, 10), (0, 0, 101, 40), (95, 35, 10, 10), (5, 5, 0, 7)):
+        with pytest.raises(abi.MskError) as e:
+            abi.Scene(gpu_ctx, hostmirror.cbox_scene(100, 40, coeff_lookup=golden_lookup, crop=bad))
+        assert "crop" in str(e.value)
+    for x in (g, gf, o):
+        x.close()
+
+
 def test_shards_sum_to_the_whole(scene256, abi, hostmirror):
     g, o, _ = scene256
     full, _ = g.render(abi.render_params(spp=8, seed=4))

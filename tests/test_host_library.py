@@ -157,6 +157,42 @@ def test_render_through_the_plugin_interface(hostlib, hostmirror, oracle, tmp_pa
     sc.close()
 
 
+def test_film_crop_window_properties(hostlib, hostmirror, tmp_path):
+    """<film> crop_offset_x / _y, crop_width / _height (film.cpp:12-21): flattened into msk_film_desc; the reference's check and
+    message (film.cpp:51-63) for a window outside the film."""
+    xml = hostmirror.write_scene_xml(hostmirror.cbox_meshes(), str(tmp_path), 100, 40, 2,
+                                     film_props={"crop_offset_x": 11, "crop_offset_y": 5, "crop_width": 37, "crop_height": 21})
+    sc = hostlib.HostScene(xml)
+    assert sc.film_size()[:2] == (100, 40) and sc.film_crop() == (11, 5, 37, 21)
+    f = sc.flatten().desc.film
+    assert (f.width, f.height, tuple(f.crop_offset), tuple(f.crop_size)) == (100, 40, (11, 5), (37, 21))
+    sc.close()
+    plain = hostlib.HostScene(hostmirror.write_scene_xml(hostmirror.cbox_meshes(), str(tmp_path), 100, 40, 2, filename="plain.xml"))
+    assert plain.film_crop() == (0, 0, 100, 40) and tuple(plain.flatten().desc.film.crop_size) == (100, 40)
+    plain.close()
+    bad = hostmirror.write_scene_xml(hostmirror.cbox_meshes(), str(tmp_path), 100, 40, 2, filename="bad.xml",
+                                     film_props={"crop_offset_x": 80, "crop_width": 37})
+    with pytest.raises(hostlib.HostError) as e:
+        hostlib.HostScene(bad)
+    assert "Invalid crop window specification" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_render_a_crop_window_through_the_plugin(hostlib, hostmirror, oracle, tmp_path):
+    """The "path" plugin with a cropped film: one borderless ImageBlock of the crop size at the crop offset goes to Film::put
+    (hdrfilm.cpp:37-46), HDRFilm::image() develops that window — the oracle's film, bit for bit."""
+    xml = hostmirror.write_scene_xml(hostmirror.cbox_meshes(), str(tmp_path), 100, 40, 4,
+                                     film_props={"crop_offset_x": 11, "crop_offset_y": 5, "crop_width": 37, "crop_height": 21})
+    sc = hostlib.HostScene(xml)
+    film, rgba, st = sc.render(develop_to=str(tmp_path / "crop.exr"))
+    flat = sc.flatten()
+    ref, rst = oracle.scene(flat).render(flat.params, threads=4)
+    assert film.shape == (21, 37, 5) and rgba.shape == (21, 37, 4) and st.samples == rst.samples
+    assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+    assert np.allclose(rgba, hostmirror.develop(ref), rtol=1e-6, atol=1e-7)
+    sc.close()
+
+
 @pytest.mark.gpu
 def test_plugin_gpu_devices_property(hostlib, hostmirror, oracle, tmp_path):
     """<integrator type="path"><string name="gpu_devices" value="0,0"/>: the plugin hands both ordinals to msk_gpu_init, the

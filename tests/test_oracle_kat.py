@@ -355,6 +355,23 @@ def degenerate_scenes(hostmirror):
             "one emitting triangle": ([tri], None)}
 
 
+def test_oracle_crop_window_is_a_window_of_the_full_film(oracle, abi, hostmirror):
+    """film.cpp:12-21, hdrfilm.cpp:37-38, imageblock.cpp:133-173: HDRFilm's storage is the crop window, every block is clipped
+    to it in spiral order — so the cropped film is, bit for bit, that window of the full film, for tile shards too."""
+    full = oracle.scene(hostmirror.cbox_scene(70, 50))
+    for crop in ((11, 5, 37, 21), (60, 40, 10, 10), (0, 0, 70, 50), (33, 0, 1, 50)):
+        sc = oracle.scene(hostmirror.cbox_scene(70, 50, crop=crop))
+        for prm in (abi.render_params(spp=2, seed=2), abi.render_params(spp=2, seed=2, block_size=16, block_first=1, block_stride=3),
+                    abi.render_params(spp=1, rng_mode=abi.MSK_RNG_PCG_BLOCK)):
+            a, sa = sc.render(prm, threads=4)
+            b, sb = full.render(prm, threads=4)
+            x, y, w, h = crop
+            assert a.shape == (h, w, 5) and np.array_equal(a.view(np.uint32), b[y:y + h, x:x + w].view(np.uint32))
+            assert sa.samples <= sb.samples
+        sc.close()
+    full.close()
+
+
 def test_oracle_renders_degenerate_scenes(oracle, abi, hostmirror):
     for name, (meshes, env) in degenerate_scenes(hostmirror).items():
         sc = oracle.scene(hostmirror.flatten(meshes, 24, 16, env=env))

@@ -12,6 +12,16 @@ out = os.path.join(root, "profiles")
 HBM_PEAK, VALU_PEAK = 8000.0, 256 * 4 * 2.4 / 2.0
 
 
+def build_id():
+    """bench.py's build_id(): a hash of the sources the GPU library is built from (bench.py flags `profile_stale` otherwise)"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(root, "misaki-render_amd", "csrc")
+    for f in sorted(os.listdir(csrc)) + ["../../include/msk_gpu.h"]:
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def short(name):
     return name.split("(")[0].replace("void ", "").replace("msk::", "")
 
@@ -52,7 +62,7 @@ def durations(sub):
 head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 for cfg in cfgs:
     p = "pm_" + cfg
-    res = {"_source": f"tools/profile_mesh.sh {cfg} on one MI355X; tree at or after commit {head}", "kernels": {}}
+    res = {"_source": f"tools/profile_mesh.sh {cfg} on one MI355X; tree at or after commit {head}", "_build_id": build_id(), "kernels": {}}
     for sub, name in (("_kt", "kernel_stats"), ("_kt1", "kernel_stats_1stream")):
         f = latest(p + sub, "*_kernel_stats.csv")
         if f:

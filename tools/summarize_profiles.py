@@ -28,6 +28,17 @@ for name in ("prof_kt.json", "prof_kt1.json"):      # the bench line printed ins
         shutil.copy(src, os.path.join(out, f"{tag}_bench_under_{name.replace('prof_', 'rocprof_')}"))
 
 
+def build_id():
+    """bench.py's build_id(): a hash of the sources the GPU library is built from — bench.py flags `profile_stale` when the
+    committed profile was taken on another build."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(root, "misaki-render_amd", "csrc")
+    for f in sorted(os.listdir(csrc)) + ["../../include/msk_gpu.h"]:
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def short(name):
     return name.split("(")[0].replace("void ", "").replace("msk::", "")
 
@@ -79,6 +90,7 @@ try:
     head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 except Exception:
     head = "?"
+summary["_build_id"] = build_id()
 summary["_source"] = f"profiles/{tag}_pmc.json (rocprofv3 PMC passes of tools/prof_run.py, single stream; tree at or after commit {head})"
 json.dump(summary, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
