@@ -909,8 +909,8 @@ static int check_params(msk_ctx *ctx, const msk_render_params *p, int block_min)
         return fail(ctx, MSK_ERR_UNSUPPORTED, "max_depth %d: the path state holds bounces up to %u", p->max_depth, MSK_MAX_DEPTH);
     if (p->max_depth < 0 && p->rr_depth > (int) MSK_MAX_DEPTH)
         return fail(ctx, MSK_ERR_UNSUPPORTED, "rr_depth %d with unbounded max_depth: the path state holds bounces up to %u", p->rr_depth, MSK_MAX_DEPTH);
-    if (p->block_size < block_min || p->block_size > 64)
-        return fail(ctx, MSK_ERR_INVALID_ARG, "block_size %d outside [%d, 64]", p->block_size, block_min);
+    if (p->block_size < block_min || p->block_size > 4096)        // (a pixel's place in its block is two 16-bit fields: PassParams::pix_table)
+        return fail(ctx, MSK_ERR_INVALID_ARG, "block_size %d outside [%d, 4096]", p->block_size, block_min);
     const uint32_t bs = p->block_stride ? p->block_stride : 1;
     if (p->block_first >= bs) return fail(ctx, MSK_ERR_INVALID_ARG, "shard selector out of range");
     return MSK_OK;

@@ -132,8 +132,9 @@ def test_ragged_film_and_single_sample(gpu_ctx, abi, hostmirror, oracle, golden_
         film, _ = g.render(prm)
         ref, _ = o.render(prm, threads=4)
         assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
-    prm = abi.render_params(spp=3, block_size=16)
-    assert np.array_equal(g.render(prm)[0].view(np.uint32), o.render(prm, threads=4)[0].view(np.uint32))
+    for bs in (16, 48, 96, 200):         # integrator.cpp:20 takes any block size: one block covers the whole film from 100 on
+        prm = abi.render_params(spp=3, block_size=bs)
+        assert np.array_equal(g.render(prm)[0].view(np.uint32), o.render(prm, threads=4)[0].view(np.uint32)), bs
     g.close()
     o.close()
 

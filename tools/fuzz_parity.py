@@ -80,7 +80,11 @@ def random_scene(rng):
     frng = np.random.RandomState(len(meshes) * 7919 + int(meshes[0].faces[0][0][0] * 1e3) % 100003)    # side stream: filter width
     stddev = float(frng.choice([0.5, 0.5, 0.5, 0.3, 0.625, 0.9]))
     fw, fh = [(48, 40), (48, 40), (33, 17), (64, 64), (7, 5), (100, 3), (1, 1), (37, 53)][frng.randint(0, 8)]      # ragged films, films smaller than a block
-    flat = hm.flatten(meshes, fw, fh, env=env, camera=camera, filter_stddev=stddev)
+    crop = None
+    if frng.randint(0, 4) == 0:      # a crop window (film.cpp:12-21): anywhere in the film, down to one pixel (side stream again)
+        cw, ch = int(frng.randint(1, fw + 1)), int(frng.randint(1, fh + 1))
+        crop = (int(frng.randint(0, fw - cw + 1)), int(frng.randint(0, fh - ch + 1)), cw, ch)
+    flat = hm.flatten(meshes, fw, fh, env=env, camera=camera, filter_stddev=stddev, crop=crop)
     # vertex normals (perturbed face normals) and texture coordinates on some meshes: mesh.cpp:68-96
     verts, faces = flat.vertices, flat.faces
     for i in range(flat.desc.n_meshes):
