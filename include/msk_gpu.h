@@ -65,8 +65,11 @@ extern "C" {
 #define MSK_AOV_PATH_RGBA      5   /* nested "path" integrator: xyz_to_srgb(XYZ of its sample), 1 (aov.cpp:124-141) */
 
 /* RNG semantics (the reference's own seeding is not reproducible) */
-#define MSK_RNG_PCG_BLOCK      0   /* one PCG32 stream per 32x32 block; CPU oracle only */
-#define MSK_RNG_COUNTER        1   /* stateless hash of (seed,pixel,sample,dim); GPU + oracle */
+#define MSK_RNG_PCG_BLOCK      0   /* samplers/independent.cpp as written: one PCG32 stream per image block, drawn from in the scalar
+                                      loops' order.  Sequential by construction: the device renders one block per LANE (msk_serial.h) —
+                                      a fidelity mode (BASELINE config 1 in about a second), bit-identical to the oracle's; msk_gpu_render /
+                                      _render_device only (not the "aov" integrator, not msk_gpu_sample_pixels) */
+#define MSK_RNG_COUNTER        1   /* stateless hash of (seed,pixel,sample,dim): the hot path (wavefront kernels); GPU + oracle */
 
 #define MSK_CIE_SAMPLES        95  /* include/misaki/core/spectrum.h:75        */
 #define MSK_FILTER_RESOLUTION  32  /* include/misaki/render/rfilter.h:6        */

@@ -5,6 +5,7 @@
 // schedule (imageblock.cpp:176-247), the wavefront iteration loop, and the ordered film
 // resolve.  Everything per-sample runs in the kernels of msk_kernels.h.
 #include "msk_kernels.h"
+#include "msk_serial.h"
 #include "msk_bvh.h"
 #include "msk_lbvh.h"
 #include "../../include/msk_gpu.h"
@@ -893,9 +894,8 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
 
 static int check_params(msk_ctx *ctx, const msk_render_params *p, int block_min) {
     if (!p) return fail(ctx, MSK_ERR_INVALID_ARG, "render params are NULL");
-    if (p->rng_mode != MSK_RNG_COUNTER)
-        return fail(ctx, MSK_ERR_UNSUPPORTED, "rng_mode %d: the GPU back end implements MSK_RNG_COUNTER only "
-                    "(a per-block PCG32 stream is sequential by construction)", p->rng_mode);
+    if (p->rng_mode != MSK_RNG_COUNTER && p->rng_mode != MSK_RNG_PCG_BLOCK)
+        return fail(ctx, MSK_ERR_INVALID_ARG, "rng_mode %d is neither MSK_RNG_COUNTER nor MSK_RNG_PCG_BLOCK", p->rng_mode);
     if (p->spp == 0) return fail(ctx, MSK_ERR_INVALID_ARG, "spp must be > 0");
     if (p->spp > (1u << MSK_DEPTH_SHIFT))
         return fail(ctx, MSK_ERR_UNSUPPORTED, "spp %u: at most %u samples per pixel and call (the path state holds 20 bits of sample index); "
@@ -942,6 +942,74 @@ static void pool_shape(const msk_scene *sc, uint64_t total_samples, uint32_t *re
 }
 
 
+// MSK_RNG_PCG_BLOCK: the reference's sampler as written — one PCG32 stream per block, so one lane per block (msk_serial.h).
+// Same block schedule, shards, crop window and Film::put as the wavefront path; a fidelity mode, not a fast one.
+static int render_serial(msk_scene *sc, const msk_render_params *prm, float *d_film, hipStream_t stream, msk_stats *stats) {
+    msk_ctx *ctx = sc->ctx;
+    const int border = sc->dev.filter_border;
+    EventPool ev{ctx, 0};
+    hipEvent_t t_begin = ev.get(), t_end = ev.get();
+    if (t_begin) (void) hipEventRecord(t_begin, stream);
+    const int W = sc->dev.width, H = sc->dev.height, bs = prm->block_size;
+    int nbx, nby;
+    std::vector<HostBlock> all = spiral_blocks(W, H, bs, &nbx, &nby);
+    const uint32_t bstride = prm->block_stride ? prm->block_stride : 1;
+    std::vector<int32_t> block_of((size_t) nbx * nby, -1);
+    std::vector<uint32_t> spiral_id((size_t) nbx * nby, 0);
+    std::vector<BlockInfo> owned;
+    for (size_t id = 0; id < all.size(); ++id) {
+        spiral_id[(size_t) all[id].by * nbx + all[id].bx] = (uint32_t) id;
+        if (id % bstride != prm->block_first || owned_spp(prm) == 0) continue;
+        if (all[id].off_x - border >= sc->dev.crop_x + sc->dev.crop_w || all[id].off_x + all[id].size_x + border <= sc->dev.crop_x ||
+            all[id].off_y - border >= sc->dev.crop_y + sc->dev.crop_h || all[id].off_y + all[id].size_y + border <= sc->dev.crop_y) continue;
+        block_of[(size_t) all[id].by * nbx + all[id].bx] = (int32_t) owned.size();
+        owned.push_back(BlockInfo{all[id].off_x, all[id].off_y, all[id].size_x, all[id].size_y, 0u, (uint32_t) owned.size()});
+    }
+    const uint32_t buf_stride = (uint32_t) ((bs + 2 * border) * (bs + 2 * border)) * 5;
+    if (!sc->ws) sc->ws = new Workspace();
+    Workspace &ws = *sc->ws;
+    ws.plan_key.clear();                                 // the block tables below replace whatever plan a wavefront render cached
+    const size_t buf_bytes = std::max<size_t>(owned.size(), 1) * buf_stride * 4;
+    HIP_TRY(ctx, ws.block_buf.reserve(buf_bytes));
+    HIP_TRY(ctx, ws.blocks.upload(owned)); HIP_TRY(ctx, ws.block_of.upload(block_of)); HIP_TRY(ctx, ws.spiral.upload(spiral_id));
+    HIP_TRY(ctx, hipMemsetAsync(ws.block_buf.p, 0, buf_bytes, stream));
+    DevBuf counters, ovf;
+    HIP_TRY(ctx, counters.reserve(32));
+    HIP_TRY(ctx, hipMemsetAsync(counters.p, 0, 24, stream));
+    const uint32_t grid = (uint32_t) ((owned.size() + MSK_BLOCK - 1) / MSK_BLOCK);
+    // the binary tree's stack: depth + 2 entries, the first sc->dev.stack_entries of them in LDS
+    DeviceScene ds = sc->dev;
+    const uint32_t need = (uint32_t) sc->bvh_depth + 2u;
+    if (ds.stack_entries > need) ds.stack_entries = (need + 3u) & ~3u;
+    const uint32_t ovf_words = need > ds.stack_entries ? need - ds.stack_entries : 0u;
+    if (ovf_words && grid) HIP_TRY(ctx, ovf.reserve((size_t) ovf_words * grid * MSK_BLOCK * 4));
+    if (grid) {
+        SerialParams sp;
+        sp.seed = prm->seed; sp.spp = prm->spp; sp.sample_first = prm->sample_first; sp.sample_stride = prm->sample_stride;
+        sp.rr_depth = prm->rr_depth; sp.max_depth = prm->max_depth; sp.hide_emitters = prm->hide_emitters;
+        sp.blocks = ws.blocks.as<BlockInfo>(); sp.n_blocks = (uint32_t) owned.size();
+        sp.block_buf = ws.block_buf.as<float>(); sp.buf_stride = buf_stride;
+        sp.stack_ovf = ovf.as<uint32_t>(); sp.counters = counters.as<unsigned long long>();
+        hipLaunchKernelGGL(k_path_serial, dim3(grid), dim3(MSK_BLOCK), (size_t) ds.stack_entries * MSK_BLOCK * 4, stream, ds, sp);
+    }
+    FilmOut fo;
+    fo.film = d_film; fo.stride = 5;
+    for (int c = 0; c < 5; ++c) fo.ch[c] = c;
+    hipLaunchKernelGGL(k_film_put, dim3((uint32_t) (((size_t) sc->dev.crop_w * sc->dev.crop_h + MSK_BLOCK - 1) / MSK_BLOCK)), dim3(MSK_BLOCK), 0, stream,
+                       sc->dev, ws.blocks.as<BlockInfo>(), ws.block_of.as<int32_t>(), ws.spiral.as<uint32_t>(), nbx, nby, bs,
+                       ws.block_buf.as<float>(), buf_stride, fo);
+    if (t_end) (void) hipEventRecord(t_end, stream);
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned long long h[3] = {0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(h, counters.p, 24, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    if (stats) {
+        stats->samples = h[0]; stats->segments = h[1]; stats->shadow_rays = h[2]; stats->passes = 1;
+        if (t_begin && t_end) (void) hipEventElapsedTime(&stats->ms_total, t_begin, t_end);
+    }
+    return MSK_OK;
+}
+
 static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_film, hipStream_t user_stream, msk_stats *stats,
                        const AovPlan *aov = nullptr) {
     msk_ctx *ctx = sc->ctx;
@@ -949,6 +1017,11 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     const int border = sc->dev.filter_border;
     int rc = check_params(ctx, prm, std::max(4, 2 * border));
     if (rc) return rc;
+    if (prm->rng_mode == MSK_RNG_PCG_BLOCK) {
+        if (aov) return fail(ctx, MSK_ERR_UNSUPPORTED, "MSK_RNG_PCG_BLOCK renders the \"path\" integrator only (the \"aov\" integrator uses MSK_RNG_COUNTER)");
+        if (stats) std::memset(stats, 0, sizeof *stats);
+        return render_serial(sc, prm, d_film, user_stream ? user_stream : ctx->stream, stats);
+    }
     hipStream_t stream = user_stream ? user_stream : ctx->stream;
     if (stats) std::memset(stats, 0, sizeof *stats);
     EventPool ev{ctx, 0};
@@ -1247,6 +1320,9 @@ extern "C" int msk_gpu_sample_pixels(msk_scene *scene, const msk_render_params *
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = check_params(ctx, prm, 1);
     if (rc) return rc;
+    if (prm->rng_mode != MSK_RNG_COUNTER)
+        return fail(ctx, MSK_ERR_UNSUPPORTED, "msk_gpu_sample_pixels: rng_mode %d (a pixel's samples are only addressable with the counter RNG: "
+                    "a per-block PCG32 stream is sequential by construction)", prm->rng_mode);
     const int W = scene->dev.width, H = scene->dev.height;
     if (n_pixels >> 32) return fail(ctx, MSK_ERR_INVALID_ARG, "too many pixels");
     // The path state names a sample by its FILM pixel (PathState::id), so a pixel listed twice is rendered once and its

@@ -339,8 +339,8 @@ def test_pool_shape_does_not_change_results(scene256, abi, monkeypatch):
 def test_error_behaviour(scene256, gpu_ctx, abi, hostmirror, golden_lookup):
     g, o, flat = scene256
     with pytest.raises(abi.MskError) as e:
-        g.render(abi.render_params(spp=4, rng_mode=abi.MSK_RNG_PCG_BLOCK))
-    assert e.value.code == abi.MSK_ERR_UNSUPPORTED
+        g.render(abi.render_params(spp=4, rng_mode=5))            # neither MSK_RNG_COUNTER nor MSK_RNG_PCG_BLOCK (tests/test_pcg_block.py)
+    assert e.value.code == abi.MSK_ERR_INVALID_ARG
     with pytest.raises(abi.MskError) as e:
         g.render(abi.render_params(spp=4, rr_depth=0))            # integrator.cpp:131-132
     assert "rr_depth" in str(e.value)
