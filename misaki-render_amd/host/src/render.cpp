@@ -840,6 +840,13 @@ public:
         // fixed at -1 / 5 / false (path.cpp:135-136); `honor_properties` opts into the values
         // the XML specifies instead.
         m_honor = props.bool_("honor_properties", false);
+        // "counter" (default): the stateless counter RNG of the wavefront kernels.  "pcg_block": the reference's `independent`
+        // sampler as written — one PCG32 stream per image block (samplers/independent.cpp:9-35) — rendered one block per lane
+        // (msk_serial.h): a fidelity mode for parity runs against the CPU path, not a fast one.
+        const std::string rng = props.string("rng", "counter");
+        if (rng == "counter") m_rng_mode = MSK_RNG_COUNTER;
+        else if (rng == "pcg_block") m_rng_mode = MSK_RNG_PCG_BLOCK;
+        else Throw("\"rng\" must be \"counter\" or \"pcg_block\" (got \"{}\")", rng);
     }
     ~PathTracer() { if (m_ctx) msk_gpu_shutdown(m_ctx); }
 
@@ -847,7 +854,7 @@ public:
         std::memset(&p, 0, sizeof p);
         p.spp = (uint32_t) sensor->sampler()->sample_count();
         p.seed = sensor->sampler()->base_seed();
-        p.rng_mode = MSK_RNG_COUNTER;
+        p.rng_mode = m_rng_mode;
         p.rr_depth = m_honor ? m_rr_depth : 5;
         p.max_depth = m_honor ? m_max_depth : -1;
         p.hide_emitters = m_honor ? (m_hide_emitters ? 1 : 0) : 0;
@@ -886,6 +893,7 @@ private:
     int m_device = 0;
     std::vector<int> m_devices;
     bool m_honor = false;
+    int m_rng_mode = MSK_RNG_COUNTER;
     msk_ctx *m_ctx = nullptr;
     msk_stats m_last_stats{};
 };

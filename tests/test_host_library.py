@@ -193,6 +193,32 @@ def test_render_a_crop_window_through_the_plugin(hostlib, hostmirror, oracle, tm
     sc.close()
 
 
+def test_rng_property_of_the_path_plugin(hostlib, hostmirror, tmp_path, abi):
+    """<integrator type="path"><string name="rng" value="pcg_block"/>: the reference's sampler semantics (one PCG32 stream per
+    block) instead of the counter RNG; anything else is refused when the scene is loaded."""
+    xml = hostmirror.write_scene_xml(hostmirror.cbox_meshes(), str(tmp_path), 64, 48, 2, integrator_props={"rng": "pcg_block"})
+    sc = hostlib.HostScene(xml)
+    assert sc.flatten().params.rng_mode == abi.MSK_RNG_PCG_BLOCK
+    sc.close()
+    (tmp_path / "bad_rng.xml").write_text(open(xml).read().replace('value="pcg_block"', 'value="sobol"'))
+    with pytest.raises(hostlib.HostError) as e:
+        hostlib.HostScene(str(tmp_path / "bad_rng.xml"))
+    assert '"rng" must be' in str(e.value)
+
+
+@pytest.mark.gpu
+def test_plugin_renders_in_the_references_sampler_mode(hostlib, hostmirror, oracle, tmp_path):
+    """The "path" plugin with rng="pcg_block": scene->integrator()->render() on the GPU == the oracle's pcg_block film, bit for bit."""
+    xml = hostmirror.write_scene_xml(hostmirror.cbox_meshes(), str(tmp_path), 96, 64, 4, integrator_props={"rng": "pcg_block"})
+    sc = hostlib.HostScene(xml)
+    film, rgba, st = sc.render()
+    flat = sc.flatten()
+    ref, rst = oracle.scene(flat).render(flat.params, threads=4)
+    assert st.samples == rst.samples == 96 * 64 * 4 and st.segments == rst.segments
+    assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+    sc.close()
+
+
 @pytest.mark.gpu
 def test_plugin_gpu_devices_property(hostlib, hostmirror, oracle, tmp_path):
     """<integrator type="path"><string name="gpu_devices" value="0,0"/>: the plugin hands both ordinals to msk_gpu_init, the
