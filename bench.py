@@ -27,7 +27,6 @@ rendezvous.  Rank 0 prints ONE JSON line.
 host tensor as the film, no render): what tests/test_bench_launch.py runs on CPU.
 """
 import argparse
-import hashlib
 import importlib
 import json
 import os
@@ -70,12 +69,11 @@ def parse_args():
 
 
 def build_id():
-    """What the committed profiles are matched against: a hash of the sources the GPU library is built from."""
-    h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "misaki-render_amd", "csrc")
-    for f in sorted(os.listdir(csrc)) + ["../../include/msk_gpu.h"]:
-        h.update(open(os.path.join(csrc, f), "rb").read())
-    return h.hexdigest()[:12]
+    """What the committed profiles are matched against (tools/build_id.py): a hash of the GPU library's sources without their
+    comments and white space."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import build_id as _b
+    return _b.build_id()
 
 
 def devices_seen():

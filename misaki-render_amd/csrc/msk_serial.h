@@ -8,7 +8,7 @@
 // of the block was, so a block is sequential by construction: here ONE LANE renders ONE BLOCK, sample after sample, path
 // after path, and splats into the block's bordered buffer with ImageBlock::put's own loops (imageblock.cpp:55-114), in
 // order.  Blocks are independent, so a film of B blocks is B lanes wide — a fidelity mode (BASELINE config 1, cbox 256^2
-// @ 16 spp, is 64 lanes for a second), not a fast one; the wavefront path (MSK_RNG_COUNTER) is the product's hot path.
+// @ 16 spp, is 64 lanes for three seconds), not a fast one; the wavefront path (MSK_RNG_COUNTER) is the product's hot path.
 // The arithmetic of a bounce is the wavefront kernel's (shade_region, msk_kernels.h), call for call — make_interaction,
 // bsdf_eval_pdf, bsdf_sample, the emitter sampling of scene.cpp:68-103 — only the control flow is the scalar loop's
 // (oracle.cpp: path_sample): a path whose throughput is zero keeps drawing until the loop ends it, as the reference's does,

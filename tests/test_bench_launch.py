@@ -124,3 +124,15 @@ def test_in_process_group_rehearsed_on_one_gpu():
                         capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
     d1 = _last_json(r1.stdout)
     assert abs(d["film_weight_sum"] - d1["film_weight_sum"]) <= 1e-5 * abs(d1["film_weight_sum"])
+
+
+def test_build_id_ignores_comments_and_white_space():
+    """bench.py's `roofline.profile_stale` compares tools/build_id.py's hash of the GPU library's sources: it must change with the
+    code and not with a reworded comment; the committed profile summaries carry the id of the tree they were taken on."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import build_id as b
+    assert b._strip('int a = 1; // one\n/* two */ const char *s = "// not a comment";') == 'inta=1;constchar*s="//notacomment";'
+    assert b._strip("x = 1;") != b._strip("x = 2;")
+    assert len(b.build_id()) == 12
+    summary = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+    assert summary.get("_build_id") == b.build_id(), "profiles/pmc_summary.json was taken on another build: re-run tools/profile_all.sh + summarize_profiles.py"

@@ -12,14 +12,8 @@ out = os.path.join(root, "profiles")
 HBM_PEAK, VALU_PEAK = 8000.0, 256 * 4 * 2.4 / 2.0
 
 
-def build_id():
-    """bench.py's build_id(): a hash of the sources the GPU library is built from (bench.py flags `profile_stale` otherwise)"""
-    import hashlib
-    h = hashlib.sha256()
-    csrc = os.path.join(root, "misaki-render_amd", "csrc")
-    for f in sorted(os.listdir(csrc)) + ["../../include/msk_gpu.h"]:
-        h.update(open(os.path.join(csrc, f), "rb").read())
-    return h.hexdigest()[:12]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from build_id import build_id          # hash of the GPU library's sources (bench.py flags `profile_stale` when it differs)
 
 
 def short(name):

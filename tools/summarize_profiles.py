@@ -28,15 +28,8 @@ for name in ("prof_kt.json", "prof_kt1.json"):      # the bench line printed ins
         shutil.copy(src, os.path.join(out, f"{tag}_bench_under_{name.replace('prof_', 'rocprof_')}"))
 
 
-def build_id():
-    """bench.py's build_id(): a hash of the sources the GPU library is built from — bench.py flags `profile_stale` when the
-    committed profile was taken on another build."""
-    import hashlib
-    h = hashlib.sha256()
-    csrc = os.path.join(root, "misaki-render_amd", "csrc")
-    for f in sorted(os.listdir(csrc)) + ["../../include/msk_gpu.h"]:
-        h.update(open(os.path.join(csrc, f), "rb").read())
-    return h.hexdigest()[:12]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from build_id import build_id          # hash of the GPU library's sources (bench.py flags `profile_stale` when it differs)
 
 
 def short(name):
