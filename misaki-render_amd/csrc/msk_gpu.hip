@@ -665,12 +665,6 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
         if (sc->trace_mode == 4) hipExtLaunchKernelGGL(k_trace_r<4>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         else if (sc->trace_mode == 0) hipExtLaunchKernelGGL(k_trace_r<0>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         else if (sc->trace_mode == 1) hipExtLaunchKernelGGL(k_trace_r<1>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
-        else if (sc->trace_mode == 5 && env_u32("MSK_TRACE_TWO", 0)) {
-            // k_trace_2: two rays per lane — two stack halves per lane, the node step's scratch, one result bit per slot and wave
-            const size_t lds2 = (size_t) 2 * sc->dev.stack_entries * MSK_BLOCK * 4 + (size_t) MSK_BLOCK * 16;
-            const uint32_t ovf_cap = sc->dev.stack_total > sc->dev.stack_entries ? sc->dev.stack_total - sc->dev.stack_entries : 0u;
-            hipExtLaunchKernelGGL(k_trace_2, dim3(grid), dim3(MSK_BLOCK), lds2, stream, t0, t1, 0, sc->dev, st, pp, (int) env_u32("MSK_TRACE_REFILL2", 16), max_inner, ovf_cap, (int) env_u32("MSK_TRACE_ROUNDS", 2));
-        }
         else if (sc->trace_mode == 5) hipExtLaunchKernelGGL(k_trace_r<5>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         else hipExtLaunchKernelGGL(k_trace_r<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         return;
@@ -871,7 +865,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
         std::memset(&parts.back().st, 0, sizeof(msk_stats));
         if (ovf_words) {                                // LaneStack overflow: one word per lane per extra entry, per launch
             const size_t lanes = (size_t) (((last - first) * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK) * MSK_BLOCK;
-            HIP_TRY(ctx, sb.stack_ovf[k].reserve((size_t) ovf_words * lanes * 4 * (env_u32("MSK_TRACE_TWO", 0) ? 2 : 1)));      // k_trace_2: two stacks per lane
+            HIP_TRY(ctx, sb.stack_ovf[k].reserve((size_t) ovf_words * lanes * 4));
             parts.back().stack_ovf = sb.stack_ovf[k].as<uint32_t>();
         }
     }

@@ -428,9 +428,9 @@ MSK_DEV Sel4q make_sel4q(f3 idir) {
 MSK_DEV __amdgpu_buffer_rsrc_t nodes4q_rsrc(const DeviceScene &sc) {
     return __builtin_amdgcn_make_buffer_rsrc((void *) sc.nodes4q, 0, sc.n_nodes4 * 64u, 0x00020000);
 }
-template <class STK>
+template <bool OVF>
 MSK_DEV uint32_t node4q_step(__amdgpu_buffer_rsrc_t rsrc, uint32_t node, const Sel4q &sel, f3 idir, f3 oi, float tmin, float tcur,
-                             const STK &stack, int &sp) {
+                             const LaneStack<OVF> &stack, int &sp) {
     const uint32_t base = node << 6;
     const msk_u4 h0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base, 0, 0), h1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 16u, 0, 0);
     const msk_u4 h2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 32u, 0, 0), rf = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 48u, 0, 0);
@@ -561,7 +561,7 @@ MSK_DEV bool traverse4h(const DeviceScene &sc, f3 o, f3 d, float tmin, float tma
     const uint32_t DONE = 0xffffffffu;
     while (cur != DONE) {
         while (!(cur & MSK_LEAF_BIT)) {
-            if constexpr (QUANT) cur = node4q_step(rn, cur, selq, idir, oi, tmin, bt, stack, sp);
+            if constexpr (QUANT) cur = node4q_step<true>(rn, cur, selq, idir, oi, tmin, bt, stack, sp);
             else cur = node4_step<true>(rn, cur, sel, idir, oi, tmin, bt, stack, sp);
         }
         if (cur == DONE) break;
@@ -939,7 +939,7 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
         } else if constexpr (MODE == 2) {
             t.cur = node4_step<true>(rsrc4, t.cur, t.sel, t.idir, t.oi, t.tmin, t.bt, stack, t.sp);
         } else if constexpr (MODE == 5) {
-            t.cur = node4q_step(rsrc4, t.cur, t.selq, t.idir, t.oi, t.tmin, t.bt, stack, t.sp);
+            t.cur = node4q_step<true>(rsrc4, t.cur, t.selq, t.idir, t.oi, t.tmin, t.bt, stack, t.sp);
         } else {
             const float4 *n = g.nodes + (size_t) t.cur * 4;
             const float4 a = n[0], b = n[1], c = n[2], m = n[3];
@@ -989,9 +989,6 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
 // 44 bytes of scratch) are slower in both (71.6 / 88.4 ms).
 #ifndef MSK_TRACE_R_WAVES
 #define MSK_TRACE_R_WAVES 6, 6
-#endif
-#ifndef MSK_TRACE_2_WAVES
-#define MSK_TRACE_2_WAVES 5, 5
 #endif
 template <int MODE>
 MSK_DEV void trace_replace(const DeviceScene &sc, const PathState &st, const PassParams &pp, int refill, int max_inner) {
@@ -1065,170 +1062,6 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
 template <>
 __global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_TRACE_R_WAVES)))
 k_trace_r<5>(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner) { trace_replace<5>(sc, st, pp, refill, max_inner); }
-
-// ------------------------------------------------------------------------------------------
-// k_trace_2: TWO RAYS PER LANE.  With one ray per lane (k_trace_r) a step of the wave — a node visit or a triangle test — only
-// occupies the lanes whose ray wants that kind of step next: about two thirds of a wave's rays want a node at any moment, a third
-// a triangle (33 / 29 of 64 lanes busy on the mesh scenes), whatever the schedule.  Here a lane
-// holds two rays, A and B, in registers: every iteration of the wave is one step of the kind more lanes can serve, and a lane
-// whose A does not want that kind but whose B does SWAPS them first (17 v_swap_b32 under the exec mask) — a lane idles only
-// when neither of its rays wants the step (1/9 of the lanes for a node step instead of 1/3).  Each ray carries which half of the
-// lane's LDS stack is its own.  Shadow rays first (any-hit code, results in an LDS bit per slot), then the extension rays, as
-// k_trace_q does.  A ray's visits, tests and their order are k_trace_r<5>'s: same hits.
-// ------------------------------------------------------------------------------------------
-struct Ray2 {
-    f3 o, d, idir;
-    float tmin, tmax, bt, bu, bv;
-    uint32_t bp, cur, meta;        // cur == 0xffffffff: no ray; meta: job index | this ray's stack half << 31
-    int sp;
-};
-struct Stack2 {
-    uint32_t *lds, *ovf; int cap, ovf_cap; size_t stride;       // half h, entry k: lds[(h * cap + k) * MSK_BLOCK] for k < cap, else ovf[(h * ovf_cap + k - cap) * stride]
-    uint32_t *scratch;
-    int half;
-    const uint4 *top = nullptr; uint32_t n_top = 0;             // (node4q_step's treetop hook: unused)
-    MSK_DEV void push(int &sp, uint32_t v) const {
-        if (sp < cap) lds[(half * cap + sp) * MSK_BLOCK] = v; else ovf[(size_t) (half * ovf_cap + sp - cap) * stride] = v;
-        sp += 1;
-    }
-    MSK_DEV uint32_t pop(int &sp) const {
-        sp -= 1;
-        return sp < cap ? lds[(half * cap + sp) * MSK_BLOCK] : ovf[(size_t) (half * ovf_cap + sp - cap) * stride];
-    }
-};
-#define MSK_SWAPF(a, b) asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b))
-MSK_DEV void swap_rays(Ray2 &a, Ray2 &b) {
-    MSK_SWAPF(a.o.x, b.o.x); MSK_SWAPF(a.o.y, b.o.y); MSK_SWAPF(a.o.z, b.o.z);
-    MSK_SWAPF(a.d.x, b.d.x); MSK_SWAPF(a.d.y, b.d.y); MSK_SWAPF(a.d.z, b.d.z);
-    MSK_SWAPF(a.idir.x, b.idir.x); MSK_SWAPF(a.idir.y, b.idir.y); MSK_SWAPF(a.idir.z, b.idir.z);
-    MSK_SWAPF(a.tmin, b.tmin); MSK_SWAPF(a.tmax, b.tmax); MSK_SWAPF(a.bt, b.bt); MSK_SWAPF(a.bu, b.bu); MSK_SWAPF(a.bv, b.bv);
-    MSK_SWAPF(a.bp, b.bp); MSK_SWAPF(a.cur, b.cur); MSK_SWAPF(a.meta, b.meta); MSK_SWAPF(a.sp, b.sp);
-}
-// meta of a slot's ray: bits 0..27 the live index c of its slot in the region, bit 29 "the slot's shadow ray was unoccluded",
-// bit 30 "this is the slot's shadow ray" (the extension ray follows in the same lane slot), bit 31 the stack half
-#define MSK_R2_C 0x0fffffffu
-#define MSK_R2_UNOCC 0x20000000u
-#define MSK_R2_SHADOW 0x40000000u
-#define MSK_R2_HALF 0x80000000u
-__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_TRACE_2_WAVES)))
-k_trace_2(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner, uint32_t ovf_cap, int leaf_rounds) {
-    extern __shared__ float4 lds_dyn[];
-    uint32_t *stack_base = (uint32_t *) lds_dyn;                         // 2 x stack_entries x MSK_BLOCK words, then 4 words of scratch per lane
-    const uint32_t lwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE, lane = threadIdx.x & (MSK_WAVE - 1);
-    uint32_t *scratch = stack_base + 2u * sc.stack_entries * MSK_BLOCK + threadIdx.x * 4u;
-    if (lwave >= pp.region_count) return;
-    Stack2 stack{stack_base + threadIdx.x, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x, (int) sc.stack_entries, (int) ovf_cap,
-                 (size_t) gridDim.x * MSK_BLOCK, scratch, 0};
-    const uint32_t wave = pp.region_first + lwave;
-    const RegionView rv = region_view(wave, pp.region_size, pp.regions[wave].count, pp.regions[wave].half_ns);
-    const uint32_t DONE = 0xffffffffu, n = rv.n;
-    const __amdgpu_buffer_rsrc_t rn = nodes4q_rsrc(sc), rt = tris3_rsrc(sc);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    Ray2 A, B;
-    A.cur = DONE; B.cur = DONE; A.meta = 0u; B.meta = MSK_R2_HALF; A.sp = 0; B.sp = 0;
-    A.o = A.d = A.idir = B.o = B.d = B.idir = mk3(0.f, 0.f, 0.f);
-    A.tmin = A.tmax = A.bt = A.bu = A.bv = B.tmin = B.tmax = B.bt = B.bu = B.bv = 0.f; A.bp = B.bp = MSK_NO_PRIM;
-    bool occA = false, occB = false;             // the slot's shadow ray found its hit (valid while the ray is the shadow ray)
-    bool liveA = false, liveB = false;           // the lane slot holds a region slot's rays
-    uint32_t next = 0;
-    auto begin = [&](Ray2 &r, f3 o, f3 d, float tmin, float tmax) {
-        r.o = o; r.d = d; r.idir = slab_idir(d); r.tmin = tmin; r.tmax = tmax; r.bt = tmax; r.bu = 0.f; r.bv = 0.f; r.bp = MSK_NO_PRIM; r.sp = 0;
-        r.cur = sc.n_tris ? sc.root_ref4 : DONE;
-    };
-    auto fill = [&](Ray2 &r, bool &live, unsigned long long empty) {
-        if (!live) {
-            const uint32_t c = next + (uint32_t) __popcll(empty & lt);
-            if (c < n) {
-                const uint32_t slot = rv.slot(c);
-                const float4 ro = st.ray_o[slot];
-                live = true;
-                if (c < rv.ns) {
-                    const float4 s = st.sh[slot];
-                    r.meta = (r.meta & MSK_R2_HALF) | MSK_R2_SHADOW | c;
-                    begin(r, mk3(ro.x, ro.y, ro.z), mk3(s.x, s.y, s.z), ro.w, s.w);
-                } else {
-                    const float4 rd = st.ray_d[slot];
-                    r.meta = (r.meta & MSK_R2_HALF) | c;
-                    begin(r, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, slot_tmax(rd.w));
-                }
-            }
-        }
-        next += (uint32_t) __popcll(empty);
-    };
-    // a finished ray: the shadow ray hands its lane slot to the slot's extension ray, the extension ray writes the hit record
-    auto retire = [&](Ray2 &r, bool &live, bool &occ) {
-        if (live && r.cur == DONE) {
-            MSK_CNT(0, 1);
-            const uint32_t slot = rv.slot(r.meta & MSK_R2_C);
-            if (r.meta & MSK_R2_SHADOW) {
-                r.meta = (r.meta & ~(MSK_R2_SHADOW | MSK_R2_UNOCC)) | (occ ? 0u : MSK_R2_UNOCC);
-                occ = false;
-                const float4 rd = st.ray_d[slot];
-                begin(r, r.o, mk3(rd.x, rd.y, rd.z), r.tmin, slot_tmax(rd.w));
-            } else {
-                const bool valid = (r.bp != MSK_NO_PRIM) && (r.bt != r.tmax);              // scene.cpp:234 tfar != maxt
-                st.hit[slot] = make_float4(valid ? r.bt : MSK_INF_F, r.bu, r.bv,
-                                           __uint_as_float((valid ? r.bp : MSK_PRIM_MASK) | ((r.meta & MSK_R2_UNOCC) ? MSK_HIT_UNOCCLUDED : 0u)));
-                live = false;
-            }
-        }
-    };
-    for (;;) {
-        // ---- region slots for the empty lane slots (A's first), once enough of the 128 are empty
-        if (next < n) {
-            const unsigned long long eA = __ballot(!liveA), eB = __ballot(!liveB);
-            const int n_empty = __popcll(eA) + __popcll(eB);
-            if (n_empty >= refill || n_empty == 2 * MSK_WAVE) { fill(A, liveA, eA); if (next < n) fill(B, liveB, eB); }
-        }
-        if (__ballot(liveA || liveB) == 0ull) break;          // next >= n here: an all-empty wave always refills while slots remain
-        MSK_CNT_WAVE(1);
-        if (liveA || liveB) MSK_CNT(2, 1);
-        // ---- node steps: a lane serves whichever of its rays wants a node (swapping it into A)
-        for (int step = 0; step < max_inner; ++step) {
-            const bool aN = (A.cur & MSK_LEAF_BIT) == 0u, bN = (B.cur & MSK_LEAF_BIT) == 0u;       // (an empty slot's cur is all ones)
-            if (__ballot(aN || bN) == 0ull) break;
-            if (!aN && bN) { swap_rays(A, B); const bool t_ = occA; occA = occB; occB = t_; const bool l_ = liveA; liveA = liveB; liveB = l_; }
-            if (aN || bN) {
-                MSK_CNT_WAVE(3); MSK_CNT(4, 1);
-                stack.half = (int) (A.meta >> 31);
-                Sel4q selq;                            // all ones where the reciprocal direction is negative: its sign bit, smeared
-                selq.mx = (uint32_t) ((int32_t) __float_as_uint(A.idir.x) >> 31); selq.my = (uint32_t) ((int32_t) __float_as_uint(A.idir.y) >> 31);
-                selq.mz = (uint32_t) ((int32_t) __float_as_uint(A.idir.z) >> 31);
-                const f3 oi = mk3(A.o.x * A.idir.x, A.o.y * A.idir.y, A.o.z * A.idir.z);
-                A.cur = node4q_step(rn, A.cur, selq, A.idir, oi, A.tmin, A.bt, stack, A.sp);
-            }
-        }
-        // ---- leaves: two rounds, so that both rays of a lane can have theirs tested
-        for (int round = 0; round < leaf_rounds; ++round) {
-            const bool aL = A.cur != DONE && (A.cur & MSK_LEAF_BIT) != 0u, bL = B.cur != DONE && (B.cur & MSK_LEAF_BIT) != 0u;
-            if (__ballot(aL || bL) == 0ull) break;
-            if (!aL && bL) { swap_rays(A, B); const bool t_ = occA; occA = occB; occB = t_; const bool l_ = liveA; liveA = liveB; liveB = l_; }
-            if (aL || bL) {
-                stack.half = (int) (A.meta >> 31);
-                const uint32_t first = (A.cur & 0x7fffffffu) >> 5, cnt = A.cur & 31u;
-                const bool any = (A.meta & MSK_R2_SHADOW) != 0u;
-                bool found = false;
-                MSK_CNT(7, 1);
-                for (uint32_t i = 0; i < cnt; ++i) {
-                    MSK_CNT_WAVE(5); MSK_CNT(6, 1);
-                    float4 q0, q1, q2, q3;
-                    load_tri3(rt, first + i, q0, q1, q2, q3);
-                    float tt, u, v;
-                    if (tri_test(q0, q1, q2, q3, A.o, A.d, A.tmin, A.tmax, &tt, &u, &v, nullptr, sc.tri_pad)) {
-                        if (any) { found = true; break; }
-                        const uint32_t prim = __float_as_uint(q0.w);
-                        if (A.bp == MSK_NO_PRIM || tt < A.bt || (tt == A.bt && (prim & MSK_PRIM_ID) < (A.bp & MSK_PRIM_ID))) { A.bt = tt; A.bu = u; A.bv = v; A.bp = prim; }
-                    }
-                }
-                if (found) occA = true;
-                A.cur = (A.sp > 0 && !found) ? stack.pop(A.sp) : DONE;
-            }
-        }
-        // ---- finished rays
-        retire(A, liveA, occA);
-        retire(B, liveB, occB);
-    }
-}
 
 // tris (4 x float4: v0|prim, e1, e2, Ng) -> tris3 (3 x float4: v0|prim, e1|e2.x, e2.y e2.z - -), at scene creation
 __global__ void __launch_bounds__(MSK_BLOCK) k_pack_tris3(const float4 *tris, uint32_t n, float4 *out) {
