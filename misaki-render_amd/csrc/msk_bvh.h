@@ -12,7 +12,8 @@
 //   bounds t: [lo.xyz, 0] [hi.xyz, 0], same order, a separate array (the 64-byte triangle records keep their cache-line
 //             alignment): bounding box of (v0, v0 - e1, v0 + e2) grown by tri_pad — the bounds predicate of oracle
 //             deviation D10 (an accepted hit point must lie inside), read only for accepted hits.
-// Child boxes are padded by 1e-4 of the scene diagonal so the slab test can never cull a
+// Child boxes are padded by 2 tri_pad (1e-5 of the scene's scale = max(diagonal, largest |coordinate|): some forty times the
+// slab tests' worst rounding error, which tests/test_padding_margin.py locates) so the slab test can never cull a
 // triangle the (differently rounded) triangle test accepts: hit selection is by (t, prim) and
 // therefore independent of the tree.
 #pragma once
@@ -174,8 +175,7 @@ static inline Built build(const float *pos, uint32_t n, float tri_pad) {
         b.tb[i] = bx; b.tc[i] = {0.5f * (bx.lo.x + bx.hi.x), 0.5f * (bx.lo.y + bx.hi.y), 0.5f * (bx.lo.z + bx.hi.z)};
         b.order[i] = i; all.grow(bx);
     }
-    float dx = all.hi.x - all.lo.x, dy = all.hi.y - all.lo.y, dz = all.hi.z - all.lo.z;
-    b.pad = n ? 1e-4f * std::sqrt(dx * dx + dy * dy + dz * dz) : 0.f;
+    b.pad = n ? 2.f * tri_pad : 0.f;
     if (n == 0) return out;
     Builder::Child root = b.build(0, n, 0);
     out.root_ref = Builder::pack(root);

@@ -351,8 +351,9 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     }
     if (cdf_all.empty()) cdf_all.push_back(0.f);
 
-    // oracle D10: the triangle-bounds predicate's padding, computed exactly as the oracle does (0.5e-4 * |hi - lo|)
-    float tri_pad, scene_lo[3] = {INFINITY, INFINITY, INFINITY}, scene_hi[3] = {-INFINITY, -INFINITY, -INFINITY}, scene_diag;
+    // oracle D10: the triangle-bounds predicate's padding, computed exactly as the oracle does (0.5e-5 of the scene's scale =
+    // max(diagonal, largest coordinate magnitude)); node boxes are padded by twice that
+    float tri_pad, scene_lo[3] = {INFINITY, INFINITY, INFINITY}, scene_hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     {
         float *lo = scene_lo, *hi = scene_hi;
         for (uint32_t t = 0; t < d->n_faces; ++t)
@@ -360,8 +361,9 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
                 for (int k = 0; k < 3; ++k) { const float q = pos[(size_t) t * 9 + v * 3 + k]; lo[k] = std::min(lo[k], q); hi[k] = std::max(hi[k], q); }
         const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
         const float diag = d->n_faces ? std::sqrt(ex * ex + (ey * ey + ez * ez)) : 1.f;
-        tri_pad = 0.5e-4f * diag;
-        scene_diag = diag;
+        float amax = 0.f;
+        if (d->n_faces) amax = std::max(std::max(std::max(std::fabs(lo[0]), std::fabs(hi[0])), std::max(std::fabs(lo[1]), std::fabs(hi[1]))), std::max(std::fabs(lo[2]), std::fabs(hi[2])));
+        tri_pad = 0.5e-5f * std::max(diag, amax);
     }
     // MSK_BVH_BUILD=gpu: the tree is built on the device (msk_lbvh.hip, a linear BVH) once the vertices are uploaded — the
     // option for scenes that change between renders; default: the host's binned-SAH builder (msk_bvh.h), the better tree
@@ -400,7 +402,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         msklbvh::Input in;
         in.tri_verts = s->tri_verts.as<float4>(); in.n_tris = d->n_faces;
         for (int k = 0; k < 3; ++k) { in.lo[k] = scene_lo[k]; in.hi[k] = scene_hi[k]; }
-        in.box_pad = 1e-4f * scene_diag; in.tri_pad = tri_pad;
+        in.box_pad = 2.f * tri_pad; in.tri_pad = tri_pad;
         in.leaf_size = getenv("MSK_BVH_LEAF") ? (uint32_t) std::max(1, std::min(8, atoi(getenv("MSK_BVH_LEAF")))) : 2u;
         in.mesh_info = s->mesh_info.as<int4>(); in.bsdfs = s->bsdfs.as<float4>(); in.n_bsdfs = d->n_bsdfs; in.bsdf_f4 = MSK_BSDF_F4;
         in.class_shift = all_diffuse ? 0u : (uint32_t) MSK_CLASS_SHIFT;
@@ -411,7 +413,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
             return fail(ctx, MSK_ERR_HIP, "device BVH build: %s", msg);
         }
         // the node records back on the host: the size / depth bookkeeping below and the wide collapse read them
-        bvh.root_ref = res.root_ref; bvh.max_depth = res.depth;
+        bvh.root_ref = res.root_ref; bvh.max_depth = res.depth; s->bvh_depth = res.depth;      // (k_path_serial sizes its stack by it)
         bvh.nodes.resize((size_t) res.n_nodes * 16);
         if (res.n_nodes) {
             hipError_t ec = hipMemcpy(bvh.nodes.data(), s->nodes.p, (size_t) res.n_nodes * 64, hipMemcpyDeviceToHost);

@@ -241,15 +241,20 @@ MSK_DEV bool tri_test(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, fl
         const float4 lo = bounds[0], hi = bounds[1];
         return px >= lo.x && px <= hi.x && py >= lo.y && py <= hi.y && pz >= lo.z && pz <= hi.z;
     }
-    // tree in HBM/L2 (memory-latency-bound, VALU to spare): the same bounds from the record, no extra fetch
+    // tree in HBM/L2: the same bounds from the record, no extra fetch.  v_min3 / v_max3 instead of the host's std::min / std::max
+    // (a compare + select pair each, 6.3 against 4.2 SIMD cycles): the two differ only in the sign of a zero result, which the
+    // -/+ pad that follows erases (pad > 0; with pad == 0 the comparison against -0 is the one against +0).  The six comparisons
+    // are combined without branches (as `&&` the compiler nests six exec regions: 19 VALU and 11 SALU instructions more per step).
     const f3 w1 = v0 - e1, w2 = v0 + e2;
-    return px >= fmin_std(v0.x, fmin_std(w1.x, w2.x)) - pad && px <= fmax_std(v0.x, fmax_std(w1.x, w2.x)) + pad &&
-           py >= fmin_std(v0.y, fmin_std(w1.y, w2.y)) - pad && py <= fmax_std(v0.y, fmax_std(w1.y, w2.y)) + pad &&
-           pz >= fmin_std(v0.z, fmin_std(w1.z, w2.z)) - pad && pz <= fmax_std(v0.z, fmax_std(w1.z, w2.z)) + pad;
+    const float lox = fminf(fminf(v0.x, w1.x), w2.x) - pad, hix = fmaxf(fmaxf(v0.x, w1.x), w2.x) + pad;
+    const float loy = fminf(fminf(v0.y, w1.y), w2.y) - pad, hiy = fmaxf(fmaxf(v0.y, w1.y), w2.y) + pad;
+    const float loz = fminf(fminf(v0.z, w1.z), w2.z) - pad, hiz = fmaxf(fmaxf(v0.z, w1.z), w2.z) + pad;
+    return (px >= lox) & (px <= hix) & (py >= loy) & (py <= hiy) & (pz >= loz) & (pz <= hiz);
 }
 
 // Reciprocal direction of the slab test: v_rcp_f32 (1 ulp) instead of an IEEE division (11 instructions each).  The slab
-// test only culls, behind boxes padded by 1e-4 of the scene diagonal — seven orders of magnitude more than this error.
+// test only culls, behind boxes padded by 1e-5 of the scene's scale — two orders of magnitude more than this error and the
+// other roundings of the slab arithmetic together (DESIGN.md §3 rule 4).
 MSK_DEV f3 slab_idir(f3 d) {
     return mk3(fminf(fmaxf(__builtin_amdgcn_rcpf(d.x), -1e25f), 1e25f), fminf(fmaxf(__builtin_amdgcn_rcpf(d.y), -1e25f), 1e25f),
                fminf(fmaxf(__builtin_amdgcn_rcpf(d.z), -1e25f), 1e25f));
@@ -419,6 +424,11 @@ MSK_DEV uint32_t node4_step(__amdgpu_buffer_rsrc_t rsrc, uint32_t node, const Se
 // +1.4 %) — so bytes per visit are what counts, and the VALU has room for the decoding: t = q * (scale * idir) + (origin * idir -
 // o * idir) for the plane byte q (v_cvt_f32_ubyte, v_fma).  Near / far plane words are picked by the ray's sign masks (v_bfi).
 // The decoded boxes contain the padded full-precision ones (checked when they are built), so this, too, only culls.
+MSK_DEV uint32_t bfi_b32(uint32_t mask, uint32_t a, uint32_t b) {          // (mask & a) | (~mask & b)
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
 struct Sel4q { uint32_t mx, my, mz; };          // all ones where the reciprocal direction is negative (near plane = hi)
 MSK_DEV Sel4q make_sel4q(f3 idir) {
     Sel4q s;
@@ -439,15 +449,16 @@ MSK_DEV uint32_t node4q_step(__amdgpu_buffer_rsrc_t rsrc, uint32_t node, const S
     const float ax = __uint_as_float(h0.w) * idir.x, ay = __uint_as_float(h1.x) * idir.y, az = __uint_as_float(h1.y) * idir.z;
     const float bx = __fmaf_rn(__uint_as_float(h0.x), idir.x, -oi.x), by = __fmaf_rn(__uint_as_float(h0.y), idir.y, -oi.y),
                 bz = __fmaf_rn(__uint_as_float(h0.z), idir.z, -oi.z);
-    const uint32_t nx = (h2.y & sel.mx) | (h1.z & ~sel.mx), fx = (h1.z & sel.mx) | (h2.y & ~sel.mx);
-    const uint32_t ny = (h2.z & sel.my) | (h1.w & ~sel.my), fy = (h1.w & sel.my) | (h2.z & ~sel.my);
-    const uint32_t nz = (h2.w & sel.mz) | (h2.x & ~sel.mz), fz = (h2.x & sel.mz) | (h2.w & ~sel.mz);
+    // (v_bfi_b32 by hand: the compiler's v_and + v_and_or pair costs 6.5 SIMD cycles against 4.2, tools/micro/valu_ops.hip)
+    const uint32_t nx = bfi_b32(sel.mx, h2.y, h1.z), fx = bfi_b32(sel.mx, h1.z, h2.y);
+    const uint32_t ny = bfi_b32(sel.my, h2.z, h1.w), fy = bfi_b32(sel.my, h1.w, h2.z);
+    const uint32_t nz = bfi_b32(sel.mz, h2.w, h2.x), fz = bfi_b32(sel.mz, h2.x, h2.w);
     uint32_t key[4];
 #define MSK_QB(w, k) ((float) (((w) >> (8 * (k))) & 0xffu))
 #define MSK_CHILD(I) {                                                                                                            \
         const float t0 = fmaxf(fmaxf(fmaxf(__fmaf_rn(MSK_QB(nx, I), ax, bx), __fmaf_rn(MSK_QB(ny, I), ay, by)), __fmaf_rn(MSK_QB(nz, I), az, bz)), tmin); \
         const float t1 = fminf(fminf(fminf(__fmaf_rn(MSK_QB(fx, I), ax, bx), __fmaf_rn(MSK_QB(fy, I), ay, by)), __fmaf_rn(MSK_QB(fz, I), az, bz)), tcur); \
-        const uint32_t miss = (uint32_t) ((int32_t) __float_as_uint(t1 * 1.0000004f - t0) >> 31);                               \
+        const uint32_t miss = (uint32_t) ((int32_t) __float_as_uint(__fmaf_rn(t1, 1.0000004f, -t0)) >> 31);                      \
         key[I] = ((__float_as_uint(t0) & 0x7ffffff0u) | (uint32_t) ((I) << 2)) | miss; }
     MSK_CHILD(0) MSK_CHILD(1) MSK_CHILD(2) MSK_CHILD(3)
 #undef MSK_CHILD
@@ -814,7 +825,9 @@ MSK_DEV void trace_queue(const DeviceScene &sc, const TraceLds &g, const PathSta
             // (Measured and rejected, round 3: near / far planes picked by LDS address from per-ray sign offsets instead of by
             // v_min / v_max, as node4_step does for trees in HBM — 9 % fewer VALU instructions per segment, but three more live
             // registers in a kernel pinned at 64: 28 instead of 12 bytes of scratch, +26 % HBM-side bytes per launch, trace time
-            // -1.5 % alone and unchanged beside the shading kernel.)
+            // -1.5 % alone and unchanged beside the shading kernel.  Round 4, with registers to spare (58 VGPRs since the build
+            // stopped pairing scalar arithmetic, __graft_entry__.HIPCC_FLAGS): the stack's top entry in a register, refilled
+            // from LDS behind the pop — 59 VGPRs, trace alone 16.4 vs 15.9 ms, step unchanged.)
             const float4 *n = g.nodes + (size_t) cur * 4;
             const float4 a = n[0], b = n[1], cc = n[2], m = n[3];
             float t0, t1;
@@ -1877,11 +1890,14 @@ __global__ void __launch_bounds__(MSK_BLOCK)
 k_shade_gen(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<LDS_TABLES, DIFFUSE_ONLY>(sc, st, pp); }
 // The general variants sit a few registers above the 168 that three waves per SIMD allow (two cost 20 % of the shading time
 // on the mesh scenes): the allocator is told to stay at three.
+#ifndef MSK_SHADE_GEN_WAVES
+#define MSK_SHADE_GEN_WAVES 3, 3
+#endif
 template <>
-__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_SHADE_GEN_WAVES)))
 k_shade_gen<false, false>(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<false, false>(sc, st, pp); }
 template <>
-__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_SHADE_GEN_WAVES)))
 k_shade_gen<true, false>(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<true, false>(sc, st, pp); }
 // The diffuse-only variants fit four waves per SIMD (128 VGPRs, no scratch); left alone, the allocator spends 24 more registers
 // on the explicit fp64 fma chains of det_sincos and lands at three.

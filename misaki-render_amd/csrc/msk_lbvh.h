@@ -10,7 +10,7 @@ struct Input {
     const float4 *tri_verts;     // device, 3 x float4 per triangle in scene-global order: p0 | mesh (uint bits), p1, p2
     uint32_t n_tris;
     float lo[3], hi[3];          // scene bounding box (the Morton grid)
-    float box_pad;               // padding of the child boxes (msk_bvh.h: 1e-4 of the scene diagonal)
+    float box_pad;               // padding of the child boxes (msk_bvh.h: 2 tri_pad)
     float tri_pad;               // padding of the triangles' D10 bounds
     uint32_t leaf_size;          // key ranges of at most this many triangles become leaves
     // material class bits of the prim word (0 = none): bsdf type of the triangle's mesh, shifted by class_shift

@@ -65,8 +65,8 @@
  *            properties (tests/test_rough_*.py, tests/test_environment.py), not by
  *            reference outputs: "parity unpinned" applies to them.
  *   D10      ray/triangle acceptance = the Moeller-Trumbore test above AND "the hit point
- *            o + t d lies in the triangle's own bounding box (grown by 0.5e-4 of the scene
- *            diagonal)": see intersect_triangle().  Found by the randomised parity sweep
+ *            o + t d lies in the triangle's own bounding box (grown by 0.5e-5 of the scene's
+ *            scale = max(diagonal, largest |coordinate|))": see intersect_triangle().  Found by the randomised parity sweep
  *            (tools/fuzz_parity.py): a shadow ray lying in the plane of a sliver emitter
  *            triangle produced a numerical "hit" 40 units outside the triangle that one
  *            tree reported and another culled.
@@ -267,9 +267,16 @@ static Scene *scene_from_desc(const msk_scene_desc *d) {
         lo = mk3(std::min(lo.x, a.x), std::min(lo.y, a.y), std::min(lo.z, a.z));
         hi = mk3(std::max(hi.x, b.x), std::max(hi.y, b.y), std::max(hi.z, b.z));
     }
+    // D10 / node padding: 0.5e-5 (triangle bounds) and 1e-5 (node boxes) of the scene's SCALE = the larger of its diagonal and
+    // its largest coordinate magnitude — what the rounding errors of the hit point and of the slab tests are proportional to
+    // (a scene far from the origin has the ulps of its coordinates, not of its extent)
     float diag = d->n_faces ? norm(hi - lo) : 1.f;
-    sc->tri_pad = 0.5e-4f * diag;                       // the nodes' padding (1e-4 diag) strictly contains it
-    if (d->n_faces) build_node(*sc, 0, (int) d->n_faces, 1e-4f * diag);
+    float amax = 0.f;
+    if (d->n_faces) amax = std::max(std::max(std::max(std::fabs(lo.x), std::fabs(hi.x)), std::max(std::fabs(lo.y), std::fabs(hi.y))), std::max(std::fabs(lo.z), std::fabs(hi.z)));
+    // (MSK_ORACLE_PAD_SCALE: tests/test_padding_margin.py shrinks the padding to show how far the rule is from failing)
+    const float pad_scale = getenv("MSK_ORACLE_PAD_SCALE") ? (float) atof(getenv("MSK_ORACLE_PAD_SCALE")) : 1e-5f;
+    sc->tri_pad = (0.5f * pad_scale) * std::max(diag, amax);       // the nodes' padding (twice this) strictly contains it
+    if (d->n_faces) build_node(*sc, 0, (int) d->n_faces, 2.f * sc->tri_pad);
     return sc;
 }
 

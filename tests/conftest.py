@@ -14,6 +14,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that stops making progress (a kernel that never drains, a reset of the host's GPUs by another tenant) ends after
+    seven minutes with every thread's stack on stderr instead of sitting there until the caller's limit (pytest-timeout, when it
+    is installed; method "thread": a main thread blocked inside a HIP call never sees a signal).  The slowest GPU test takes 15 s."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(420, method="thread"))
+
+
 @pytest.fixture(scope="session")
 def pkg():
     return importlib.import_module("misaki-render_amd")

@@ -99,3 +99,27 @@ def test_adversarial_rays_gpu_equals_oracle_brute_force(gpu_ctx, oracle, abi):
         assert np.array_equal(g.trace_any(rays), o.trace_any(rays)), s
         g.close()
         o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("offset", [1e5, -3e5])
+def test_adversarial_rays_on_a_scene_far_from_the_origin(gpu_ctx, oracle, abi, offset):
+    """The same sweep on scenes translated away from the origin, where an ulp of a coordinate (0.008 at 1e5) is no longer small
+    against the scene's extent: the padding of the boxes and of the D10 bounds follows the scene's SCALE = max(diagonal, largest
+    |coordinate|) (tests/test_padding_margin.py), so the LDS-resident binary tree (seed 3) and the quantised 4-wide tree in HBM
+    (seed 4: 4.5 k triangles) still give the brute-force answer bit for bit."""
+    fr = _fuzz_rays()
+    for s in (3, 4):
+        rng = np.random.RandomState(s)
+        flat = fr.fz.random_scene(rng)
+        flat.vertices[:, :3] += np.float32(offset)
+        d = flat.desc
+        tris = np.array([[flat.vertices[d.meshes[m].first_vertex + i, :3] for i in flat.faces[f]] for m in range(d.n_meshes)
+                         for f in range(d.meshes[m].first_face, d.meshes[m].first_face + d.meshes[m].face_count)], np.float32)
+        rays = fr.adversarial_rays(rng, tris, 20000)
+        g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+        o.set_bvh(0)
+        assert np.array_equal(g.trace_closest(rays).view(np.uint32), o.trace_closest(rays).view(np.uint32)), s
+        assert np.array_equal(g.trace_any(rays), o.trace_any(rays)), s
+        g.close()
+        o.close()

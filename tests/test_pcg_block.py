@@ -66,6 +66,17 @@ def test_every_bsdf_and_emitter_type(gpu_ctx, abi, hostmirror, oracle, golden_lo
     o.close()
 
 
+def test_on_a_device_built_tree(gpu_ctx, abi, hostmirror, oracle, golden_lookup, monkeypatch):
+    """MSK_BVH_BUILD=gpu: the linear BVH of msk_lbvh.hip is deeper than the host builder's tree and k_path_serial sizes its
+    traversal stack by the tree's depth (round 4: the depth of a device-built tree reached it as 0 — a GPU memory fault)."""
+    monkeypatch.setenv("MSK_BVH_BUILD", "gpu")
+    for flat in (hostmirror.cbox_scene(64, 48, coeff_lookup=golden_lookup), glass_scene(hostmirror, golden_lookup, 48, 48)):
+        g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+        _same(abi, g, o, spp=3)
+        g.close()
+        o.close()
+
+
 def test_what_the_mode_does_not_cover(gpu_ctx, abi, hostmirror, golden_lookup):
     g = abi.Scene(gpu_ctx, hostmirror.cbox_scene(32, 32, coeff_lookup=golden_lookup))
     with pytest.raises(abi.MskError) as e:

@@ -62,7 +62,10 @@ int main(int argc, char **argv) {
     const size_t n_rays = argc > 2 ? (size_t) atol(argv[2]) : 2000000;
     Box all; for (uint32_t i = 0; i < n * 3; ++i) all.grow(V3{pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]});
     const float diag = std::sqrt((all.hi.x - all.lo.x) * (all.hi.x - all.lo.x) + (all.hi.y - all.lo.y) * (all.hi.y - all.lo.y) + (all.hi.z - all.lo.z) * (all.hi.z - all.lo.z));
-    Built b = build(pos.data(), n, 0.5e-4f * diag);
+    float amax = 0;
+    for (float v : {all.lo.x, all.lo.y, all.lo.z, all.hi.x, all.hi.y, all.hi.z}) amax = std::max(amax, std::fabs(v));
+    // msk_gpu.hip's rule (0.5e-5 of the scene's scale); PAD_SCALE=1e-4 reproduces rounds 1-3
+    Built b = build(pos.data(), n, 0.5f * (getenv("PAD_SCALE") ? (float) atof(getenv("PAD_SCALE")) : 1e-5f) * std::max(diag, amax));
     collapse4(b, !getenv("GREEDY"));
     const uint32_t nn = (uint32_t) (b.nodes4.size() / 32);
     std::printf("%u triangles, %u 4-wide nodes (%.2f MB as 64-byte nodes), depth %d, triangles %.2f MB as 48-byte records\n", n, nn, nn * 64 / 1e6, b.max_depth4, n * 48 / 1e6);
@@ -142,7 +145,7 @@ int main(int argc, char **argv) {
         for (int a = 0; a < 3; ++a) s[a] /= len;
         tt[0] = nrm[1] * s[2] - nrm[2] * s[1]; tt[1] = nrm[2] * s[0] - nrm[0] * s[2]; tt[2] = nrm[0] * s[1] - nrm[1] * s[0];
         for (int a = 0; a < 3; ++a) r.d[a] = lx * s[a] + ly * tt[a] + lz * nrm[a];
-        r.tmin = 1e-3f;
+        r.tmin = 8.940697e-05f * (1.f + std::max(std::fabs(r.o[0]), std::max(std::fabs(r.o[1]), std::fabs(r.o[2]))));   // interaction.h:40-44
         float idir[3], oi[3];
         for (int a = 0; a < 3; ++a) { idir[a] = std::max(-1e25f, std::min(1e25f, 1.f / r.d[a])); oi[a] = r.o[a] * idir[a]; }
         float best = INFINITY;

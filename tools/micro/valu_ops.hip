@@ -60,6 +60,10 @@
 #define A_RCP(x) asm volatile("v_rcp_f32 %0, %0" : "+v"(x));
 #define A_MULLO(x) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x) : "v"(a));
 #define A_MAD24(x) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
+#define A_FMAMIX(x) asm volatile("v_fma_mix_f32 %0, %1, %0, %2 op_sel_hi:[1,0,0]" : "+v"(x) : "v"(a), "v"(b));
+#define A_FMAMIXH(x) asm volatile("v_fma_mix_f32 %0, %1, %0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x) : "v"(a), "v"(b));
+#define A_BFI(x) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(x) : "v"(a), "v"(b));
+#define A_CVTF16(x) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(x));
 #define A_FMA64(x) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d##x) : "v"(da));
 KERNEL(k_fma, A_FMA) KERNEL(k_mul, A_MUL) KERNEL(k_add, A_ADD) KERNEL(k_min, A_MIN) KERNEL(k_max, A_MAX) KERNEL(k_max3, A_MAX3)
 KERNEL(k_cnd, A_CND) KERNEL(k_cmp, A_CMP) KERNEL(k_cmps, A_CMPS) KERNEL(k_and, A_AND) KERNEL(k_xor, A_XOR) KERNEL(k_addu, A_ADDU)
@@ -67,6 +71,7 @@ KERNEL(k_cnd64, A_CND64) KERNEL(k_cmpcnd, A_CMPCND) KERNEL(k_sub, A_SUB) KERNEL(
 KERNEL(k_cmpcnd4, A_CMPCND4) KERNEL(k_cmpcnds, A_CMPCNDS) KERNEL(k_cmp2cnd, A_CMP2CND) KERNEL(k_minu, A_MINU) KERNEL(k_ashr, A_ASHR) KERNEL(k_andor, A_ANDOR)
 KERNEL(k_perm, A_PERM) KERNEL(k_med3, A_MED3) KERNEL(k_sqrt, A_SQRT) KERNEL(k_rsq, A_RSQ) KERNEL(k_exp, A_EXP) KERNEL(k_mulu24, A_MULU24) KERNEL(k_mulhi, A_MULHI)
 KERNEL(k_subu, A_SUBU) KERNEL(k_or, A_OR) KERNEL(k_lshr, A_LSHR) KERNEL(k_floor, A_FLOOR) KERNEL(k_cvti, A_CVTI) KERNEL(k_cvtf, A_CVTF) KERNEL(k_mbcnt, A_MBCNT) KERNEL(k_fmak, A_FMAK)
+KERNEL(k_fmamix, A_FMAMIX) KERNEL(k_fmamixh, A_FMAMIXH) KERNEL(k_bfi, A_BFI) KERNEL(k_cvtf16, A_CVTF16)
 KERNEL(k_lshl, A_LSHL) KERNEL(k_mov, A_MOV) KERNEL(k_cvtub, A_CVTUB) KERNEL(k_rcp, A_RCP) KERNEL(k_mullo, A_MULLO) KERNEL(k_mad24, A_MAD24)
 // packed fp32: two lanes' worth per instruction on 64-bit register pairs
 __global__ void __launch_bounds__(256) k_pkmul(float *out, int iters, float a, float b) {
@@ -95,7 +100,7 @@ int main() {
         {"v_exp_f32", k_exp}, {"v_mul_u32_u24", k_mulu24}, {"v_mul_hi_u32", k_mulhi}, {"v_sub_u32", k_subu}, {"v_or_b32", k_or}, {"v_lshrrev_b32", k_lshr}, {"v_floor_f32", k_floor},
         {"v_cvt_i32_f32", k_cvti}, {"v_cvt_f32_u32", k_cvtf}, {"v_mbcnt_lo", k_mbcnt}, {"v_fmaak_f32", k_fmak}, {"v_sub_f32", k_sub}, {"v_fmac_f32", k_fmac}, {"v_min3_f32", k_min3}, {"v_lshl_add_u32", k_lshladd}, {"v_or3_b32", k_or3}, {"v_bfe_u32", k_bfe}, {"v_cmp_lt_f32 vcc", k_cmp}, {"v_cmp_lt_f32 sgpr", k_cmps}, {"v_and_b32", k_and}, {"v_xor_b32", k_xor},
         {"v_add_u32", k_addu}, {"v_lshlrev_b32", k_lshl}, {"v_mov_b32", k_mov}, {"v_cvt_f32_ubyte1", k_cvtub}, {"v_rcp_f32", k_rcp}, {"v_mul_lo_u32", k_mullo},
-        {"v_mad_u32_u24", k_mad24}, {"v_pk_mul_f32", k_pkmul}, {"v_fma_f64", k_fma64}};
+        {"v_mad_u32_u24", k_mad24}, {"v_fma_mix_f32 (f16 lo src)", k_fmamix}, {"v_fma_mix_f32 (f16 hi src)", k_fmamixh}, {"v_bfi_b32", k_bfi}, {"v_cvt_f32_f16", k_cvtf16}, {"v_pk_mul_f32", k_pkmul}, {"v_fma_f64", k_fma64}};
     const int iters = 4000;
     for (auto &k : ks) {
         float best = 1e30f;
