@@ -475,7 +475,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         // the tree stays in HBM/L2: walk it four children at a time, one 128-byte line per visit
         mskbvh::collapse4(bvh, env_u32("MSK_COLLAPSE_OPTIMAL", 1) != 0);
         // the traversal addresses nodes and triangle records through buffer resources with 32-bit byte offsets
-        if ((uint64_t) (bvh.nodes4.size() / 32) * 128u >= (1ull << 32) || (uint64_t) d->n_faces * 48u >= (1ull << 32)) {
+        if ((uint64_t) (bvh.nodes4.size() / 32) * 128u >= (1ull << 32) || (uint64_t) d->n_faces * MSK_TRI_REC_BYTES >= (1ull << 32)) {
             delete s;
             return fail(ctx, MSK_ERR_UNSUPPORTED, "a tree of %zu 4-wide nodes exceeds the 4 GB a buffer resource addresses", bvh.nodes4.size() / 32);
         }
@@ -495,11 +495,11 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
             s->tree_bytes = bvh.nodes4q.size() * 4;
         }
         {
-            hipError_t et = s->tris3.alloc(std::max<size_t>((size_t) d->n_faces * 48, 16));
+            hipError_t et = s->tris3.alloc(std::max<size_t>((size_t) d->n_faces * MSK_TRI_REC_BYTES, 16));
             if (et != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(et)); }
             ds.tris3 = s->tris3.as<float4>();
             if (d->n_faces) hipLaunchKernelGGL(k_pack_tris3, dim3((d->n_faces + MSK_BLOCK - 1) / MSK_BLOCK), dim3(MSK_BLOCK), 0, ctx->stream,
-                                               s->tris.as<float4>(), d->n_faces, s->tris3.as<float4>());
+                                               s->tris.as<float4>(), s->tri_bounds.as<float4>(), d->n_faces, s->tris3.as<float4>());
         }
     } else if (s->lds_scene && env_u32("MSK_WIDE_LDS", 0) && !(bvh.root_ref & MSK_LEAF_BIT)) {
         // experiment knob, off by default: the 4-wide tree staged in LDS (half the dependent LDS round trips per ray).

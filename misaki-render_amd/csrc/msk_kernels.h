@@ -218,8 +218,8 @@ MSK_DEV float xor_sign(float a, uint32_t s) { return __uint_as_float(__float_as_
 // precomputed with the oracle's arithmetic): acceptance is then a property of the ray and the triangle, not of the tree —
 // Moeller-Trumbore alone accepts points well outside sliver triangles and, for near-parallel rays, at meaningless t.
 // The bounds are read only for hits the test above accepted.
-MSK_DEV bool tri_test(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, float tmin, float tmax,
-                      float *t, float *u, float *v, const float4 *bounds, float pad) {
+// tri_mt: the Moeller-Trumbore part; *p = the hit point o + t d the bounds predicate looks at
+MSK_DEV bool tri_mt(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, float tmin, float tmax, float *t, float *u, float *v, f3 *p) {
     const f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z),
              ng = mk3(q3.x, q3.y, q3.z);
     const f3 C = v0 - o;
@@ -236,7 +236,15 @@ MSK_DEV bool tri_test(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, fl
     *t = T * rcp;
     *u = fmin_std(U * rcp, 1.f);
     *v = fmin_std(V * rcp, 1.f);
-    const float px = o.x + *t * d.x, py = o.y + *t * d.y, pz = o.z + *t * d.z;
+    *p = mk3(o.x + *t * d.x, o.y + *t * d.y, o.z + *t * d.z);
+    return true;
+}
+MSK_DEV bool tri_test(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, float tmin, float tmax,
+                      float *t, float *u, float *v, const float4 *bounds, float pad) {
+    f3 p;
+    if (!tri_mt(q0, q1, q2, q3, o, d, tmin, tmax, t, u, v, &p)) return false;
+    const f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);
+    const float px = p.x, py = p.y, pz = p.z;
     if (bounds) {                           // LDS-resident scene: precomputed, two LDS reads
         const float4 lo = bounds[0], hi = bounds[1];
         return px >= lo.x && px <= hi.x && py >= lo.y && py <= hi.y && pz >= lo.z && pz <= hi.z;
@@ -480,8 +488,49 @@ MSK_DEV uint32_t node4q_step(__amdgpu_buffer_rsrc_t rsrc, uint32_t node, const S
 }
 
 // a triangle of a tree in HBM/L2: three loads (DeviceScene::tris3), the normal recomputed with the builder's operations
+// MSK_TRI_REC: what a tree in HBM/L2 reads per triangle test.  0: 48 bytes {v0 | prim, e1 | e2.x, e2.yz}, the normal and the D10
+// bounds recomputed (three loads);  1: 64 bytes with the normal (DeviceScene::tris as the builder wrote it), bounds recomputed;
+// 2: 64 bytes {v0 | prim, e1 | e2.x, e2.yz | lo.xy, lo.z | hi}: the D10 bounds as the builder padded them, the normal recomputed.
+// Measured (round 4, config-5 / config-3 class renders, three runs each): 0: 128.3 / 165.0 ms;  1: 127.5 / 165.1 (8 VALU instructions
+// fewer per test, one load more: nothing);  2: 131.0 / 169.5 (17 fewer, one load more: +2 %) — the fourth load costs what the
+// arithmetic saves or more, although the kernel's VALU is busy all the time: the default stays 0.
+#ifndef MSK_TRI_REC
+#define MSK_TRI_REC 0
+#endif
+#define MSK_TRI_REC_BYTES (MSK_TRI_REC == 0 ? 48u : 64u)
 MSK_DEV __amdgpu_buffer_rsrc_t tris3_rsrc(const DeviceScene &sc) {
-    return __builtin_amdgcn_make_buffer_rsrc((void *) sc.tris3, 0, sc.n_tris * 48u, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc((void *) (MSK_TRI_REC == 1 ? sc.tris : sc.tris3), 0, sc.n_tris * MSK_TRI_REC_BYTES, 0x00020000);
+}
+struct TriRec { float4 q0, q1, q2, q3; f3 lo, hi; };
+MSK_DEV void load_tri_rec(__amdgpu_buffer_rsrc_t rsrc, uint32_t k, TriRec &r) {
+    const uint32_t off = k * MSK_TRI_REC_BYTES;
+    const msk_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16u, 0, 0),
+                 c = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32u, 0, 0);
+    r.q0 = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+    if constexpr (MSK_TRI_REC == 1) {
+        const msk_u4 e = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 48u, 0, 0);
+        r.q1 = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), 0.f);
+        r.q2 = make_float4(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z), 0.f);
+        r.q3 = make_float4(__uint_as_float(e.x), __uint_as_float(e.y), __uint_as_float(e.z), 0.f);
+        return;
+    }
+    r.q1 = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), 0.f);
+    r.q2 = make_float4(__uint_as_float(b.w), __uint_as_float(c.x), __uint_as_float(c.y), 0.f);
+    r.q3 = make_float4(r.q2.y * r.q1.z - r.q2.z * r.q1.y, r.q2.z * r.q1.x - r.q2.x * r.q1.z, r.q2.x * r.q1.y - r.q2.y * r.q1.x, 0.f);     // Ng = e2 x e1 (msk_bvh.h: build)
+    if constexpr (MSK_TRI_REC == 2) {
+        const msk_u4 e = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 48u, 0, 0);
+        r.lo = mk3(__uint_as_float(c.z), __uint_as_float(c.w), __uint_as_float(e.x));
+        r.hi = mk3(__uint_as_float(e.y), __uint_as_float(e.z), __uint_as_float(e.w));
+    }
+}
+MSK_DEV bool tri_test_rec(const TriRec &r, f3 o, f3 d, float tmin, float tmax, float *t, float *u, float *v, float pad) {
+    if constexpr (MSK_TRI_REC == 2) {
+        f3 p;
+        if (!tri_mt(r.q0, r.q1, r.q2, r.q3, o, d, tmin, tmax, t, u, v, &p)) return false;
+        return (p.x >= r.lo.x) & (p.x <= r.hi.x) & (p.y >= r.lo.y) & (p.y <= r.hi.y) & (p.z >= r.lo.z) & (p.z <= r.hi.z);
+    } else {
+        return tri_test(r.q0, r.q1, r.q2, r.q3, o, d, tmin, tmax, t, u, v, nullptr, pad);
+    }
 }
 MSK_DEV void load_tri3(__amdgpu_buffer_rsrc_t rsrc, uint32_t k, float4 &q0, float4 &q1, float4 &q2, float4 &q3) {
     const uint32_t off = k * 48u;
@@ -578,12 +627,12 @@ MSK_DEV bool traverse4h(const DeviceScene &sc, f3 o, f3 d, float tmin, float tma
         if (cur == DONE) break;
         const uint32_t first = (cur & 0x7fffffffu) >> 5, cnt = cur & 31u;
         for (uint32_t i = 0; i < cnt; ++i) {
-            float4 q0, q1, q2, q3;
-            load_tri3(rt, first + i, q0, q1, q2, q3);
+            TriRec r;
+            load_tri_rec(rt, first + i, r);
             float t, u, v;
-            if (tri_test(q0, q1, q2, q3, o, d, tmin, tmax, &t, &u, &v, nullptr, sc.tri_pad)) {
+            if (tri_test_rec(r, o, d, tmin, tmax, &t, &u, &v, sc.tri_pad)) {
                 if (ANY) return true;
-                const uint32_t prim = __float_as_uint(q0.w);
+                const uint32_t prim = __float_as_uint(r.q0.w);
                 if (bp == MSK_NO_PRIM || t < bt || (t == bt && (prim & MSK_PRIM_ID) < (bp & MSK_PRIM_ID))) { bt = t; bu = u; bv = v; bp = prim; }
             }
         }
@@ -981,13 +1030,19 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
         for (uint32_t i = 0; i < cnt; ++i) {
             MSK_CNT_WAVE(5); MSK_CNT(6, 1);
             const float4 *q = g.tris + (size_t) (first + i) * (MSK_OVF(MODE) ? 4 : 6);
-            float4 q0, q1, q2, q3;
-            if constexpr (MODE == 2 || MODE == 5) load_tri3(rsrc_t3, first + i, q0, q1, q2, q3);
-            else { q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; }
+            TriRec r;
+            bool acc;
             float tt, u, v;
-            if (tri_test(q0, q1, q2, q3, t.o, t.d, t.tmin, t.tmax, &tt, &u, &v, MSK_OVF(MODE) ? nullptr : q + 4, sc.tri_pad)) {
+            if constexpr (MODE == 2 || MODE == 5) {
+                load_tri_rec(rsrc_t3, first + i, r);
+                acc = tri_test_rec(r, t.o, t.d, t.tmin, t.tmax, &tt, &u, &v, sc.tri_pad);
+            } else {
+                r.q0 = q[0]; r.q1 = q[1]; r.q2 = q[2]; r.q3 = q[3];
+                acc = tri_test(r.q0, r.q1, r.q2, r.q3, t.o, t.d, t.tmin, t.tmax, &tt, &u, &v, MSK_OVF(MODE) ? nullptr : q + 4, sc.tri_pad);
+            }
+            if (acc) {
                 if (any) { found = true; break; }
-                const uint32_t prim = __float_as_uint(q0.w);
+                const uint32_t prim = __float_as_uint(r.q0.w);
                 if (t.bp == MSK_NO_PRIM || tt < t.bt || (tt == t.bt && (prim & MSK_PRIM_ID) < (t.bp & MSK_PRIM_ID))) { t.bt = tt; t.bu = u; t.bv = v; t.bp = prim; }
             }
         }
@@ -1077,10 +1132,16 @@ __global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(
 k_trace_r<5>(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner) { trace_replace<5>(sc, st, pp, refill, max_inner); }
 
 // tris (4 x float4: v0|prim, e1, e2, Ng) -> tris3 (3 x float4: v0|prim, e1|e2.x, e2.y e2.z - -), at scene creation
-__global__ void __launch_bounds__(MSK_BLOCK) k_pack_tris3(const float4 *tris, uint32_t n, float4 *out) {
+__global__ void __launch_bounds__(MSK_BLOCK) k_pack_tris3(const float4 *tris, const float4 *bounds, uint32_t n, float4 *out) {
     const uint32_t k = blockIdx.x * MSK_BLOCK + threadIdx.x;
     if (k >= n) return;
     const float4 a = tris[(size_t) k * 4], e1 = tris[(size_t) k * 4 + 1], e2 = tris[(size_t) k * 4 + 2];
+    if (MSK_TRI_REC == 2) {                  // + the padded D10 bounds (msk_bvh.h: Built::bounds)
+        const float4 lo = bounds[(size_t) k * 2], hi = bounds[(size_t) k * 2 + 1];
+        out[(size_t) k * 4] = a; out[(size_t) k * 4 + 1] = make_float4(e1.x, e1.y, e1.z, e2.x);
+        out[(size_t) k * 4 + 2] = make_float4(e2.y, e2.z, lo.x, lo.y); out[(size_t) k * 4 + 3] = make_float4(lo.z, hi.x, hi.y, hi.z);
+        return;
+    }
     out[(size_t) k * 3] = a; out[(size_t) k * 3 + 1] = make_float4(e1.x, e1.y, e1.z, e2.x); out[(size_t) k * 3 + 2] = make_float4(e2.y, e2.z, 0.f, 0.f);
 }
 
