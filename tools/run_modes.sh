@@ -1,7 +1,14 @@
-mkdir -p gpurun_out/r04
-: > gpurun_out/r04/pad_modes.txt
+#!/bin/bash
+# tools/run_modes.sh : the whole `-m gpu` suite once per optional mode of the GPU library (greedy collapse, 128-byte nodes, 8-wide
+# tree, device-built tree, no material sort + one stream, nothing staged in LDS), ON THE GPU BOX from the repo root:
+#   gpurun --timeout 1200 -- 'bash tools/run_modes.sh'      -> gpurun_out/modes.txt (two lines per mode)
+mkdir -p gpurun_out
+: > gpurun_out/modes.txt
 for m in "MSK_COLLAPSE_OPTIMAL=0" "MSK_QUANT_BVH=0" "MSK_WIDE_BVH=8" "MSK_BVH_BUILD=gpu" "MSK_SORT=0 MSK_STREAMS=1" "MSK_LDS_SCENE_KB=0"; do
-  echo "== $m" >> gpurun_out/r04/pad_modes.txt
-  env $m timeout -k 10 300 python -m pytest tests -x -q -m gpu 2>&1 | tail -2 >> gpurun_out/r04/pad_modes.txt || exit 1
+  echo "== $m" >> gpurun_out/modes.txt
+  env $m timeout -k 10 400 python -m pytest tests -x -q -m gpu > gpurun_out/modes_last.txt 2>&1
+  rc=$?
+  tail -n 2 gpurun_out/modes_last.txt >> gpurun_out/modes.txt
+  if [ $rc -ne 0 ]; then cat gpurun_out/modes.txt; exit $rc; fi        # a failed or hung mode ends the run: no further GPU step after it
 done
-cat gpurun_out/r04/pad_modes.txt
+cat gpurun_out/modes.txt
