@@ -363,7 +363,9 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         const float diag = d->n_faces ? std::sqrt(ex * ex + (ey * ey + ez * ez)) : 1.f;
         float amax = 0.f;
         if (d->n_faces) amax = std::max(std::max(std::max(std::fabs(lo[0]), std::fabs(hi[0])), std::max(std::fabs(lo[1]), std::fabs(hi[1]))), std::max(std::fabs(lo[2]), std::fabs(hi[2])));
-        tri_pad = 0.5e-5f * std::max(diag, amax);
+        // (MSK_PAD_SCALE, read by the oracle too: the margin tests shrink the padding on both sides to show how far the rule is from failing)
+        const float pad_scale = getenv("MSK_PAD_SCALE") ? (float) atof(getenv("MSK_PAD_SCALE")) : 1e-5f;
+        tri_pad = (0.5f * pad_scale) * std::max(diag, amax);
     }
     // MSK_BVH_BUILD=gpu: the tree is built on the device (msk_lbvh.hip, a linear BVH) once the vertices are uploaded — the
     // option for scenes that change between renders; default: the host's binned-SAH builder (msk_bvh.h), the better tree

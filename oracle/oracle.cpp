@@ -273,8 +273,9 @@ static Scene *scene_from_desc(const msk_scene_desc *d) {
     float diag = d->n_faces ? norm(hi - lo) : 1.f;
     float amax = 0.f;
     if (d->n_faces) amax = std::max(std::max(std::max(std::fabs(lo.x), std::fabs(hi.x)), std::max(std::fabs(lo.y), std::fabs(hi.y))), std::max(std::fabs(lo.z), std::fabs(hi.z)));
-    // (MSK_ORACLE_PAD_SCALE: tests/test_padding_margin.py shrinks the padding to show how far the rule is from failing)
-    const float pad_scale = getenv("MSK_ORACLE_PAD_SCALE") ? (float) atof(getenv("MSK_ORACLE_PAD_SCALE")) : 1e-5f;
+    // (MSK_PAD_SCALE, read by the GPU library too: tests/test_padding_margin.py and test_fuzz_parity.py shrink the padding to show
+    // how far the rule is from failing)
+    const float pad_scale = getenv("MSK_PAD_SCALE") ? (float) atof(getenv("MSK_PAD_SCALE")) : 1e-5f;
     sc->tri_pad = (0.5f * pad_scale) * std::max(diag, amax);       // the nodes' padding (twice this) strictly contains it
     if (d->n_faces) build_node(*sc, 0, (int) d->n_faces, 2.f * sc->tri_pad);
     return sc;

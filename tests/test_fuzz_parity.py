@@ -123,3 +123,28 @@ def test_adversarial_rays_on_a_scene_far_from_the_origin(gpu_ctx, oracle, abi, o
         assert np.array_equal(g.trace_any(rays), o.trace_any(rays)), s
         g.close()
         o.close()
+
+
+@pytest.mark.gpu
+def test_gpu_trees_equal_brute_force_with_a_tenth_of_the_padding(gpu_ctx, oracle, abi, monkeypatch):
+    """The margin of the padding rule for the DEVICE's slab arithmetic (v_rcp_f32 reciprocals, `plane * idir - o * idir`, the
+    quantised nodes' decode): with MSK_PAD_SCALE=1e-6 on both sides — a tenth of the rule's padding — the LDS-resident binary tree
+    (seeds 3, 5), the quantised 4-wide tree in HBM (seeds 0, 4) and the same scenes 1e5 units from the origin still give the oracle's
+    brute-force answer on adversarial rays, bit for bit (the CPU counterpart: tests/test_padding_margin.py)."""
+    monkeypatch.setenv("MSK_PAD_SCALE", "1e-6")
+    fr = _fuzz_rays()
+    for s, offset in ((3, 0.0), (0, 0.0), (4, 0.0), (5, 1e5), (4, 1e5)):
+        rng = np.random.RandomState(s)
+        flat = fr.fz.random_scene(rng)
+        if offset:
+            flat.vertices[:, :3] += np.float32(offset)
+        d = flat.desc
+        tris = np.array([[flat.vertices[d.meshes[m].first_vertex + i, :3] for i in flat.faces[f]] for m in range(d.n_meshes)
+                         for f in range(d.meshes[m].first_face, d.meshes[m].first_face + d.meshes[m].face_count)], np.float32)
+        rays = fr.adversarial_rays(rng, tris, 20000)
+        g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+        o.set_bvh(0)
+        assert np.array_equal(g.trace_closest(rays).view(np.uint32), o.trace_closest(rays).view(np.uint32)), (s, offset)
+        assert np.array_equal(g.trace_any(rays), o.trace_any(rays)), (s, offset)
+        g.close()
+        o.close()

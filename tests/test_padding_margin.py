@@ -46,15 +46,15 @@ def _disagreements(orc, fr, seed, offset, n_rays=12000):
 @pytest.mark.parametrize("scale", [None, "1e-6"])
 def test_tree_equals_brute_force_with_a_tenth_of_the_padding(monkeypatch, scale, offset):
     if scale is None:
-        monkeypatch.delenv("MSK_ORACLE_PAD_SCALE", raising=False)
+        monkeypatch.delenv("MSK_PAD_SCALE", raising=False)
     else:
-        monkeypatch.setenv("MSK_ORACLE_PAD_SCALE", scale)
+        monkeypatch.setenv("MSK_PAD_SCALE", scale)
     orc, fr = oracle_binding.load(), _fuzz()
     assert sum(_disagreements(orc, fr, seed, offset) for seed in (0, 6, 7)) == 0       # (seed 6 has a 4 k-triangle mesh)
 
 
 def test_the_padding_is_what_keeps_them_equal(monkeypatch):
     """... and without it (1e-9 of the scale: below the rounding errors) they do disagree: the test above tests something."""
-    monkeypatch.setenv("MSK_ORACLE_PAD_SCALE", "1e-9")
+    monkeypatch.setenv("MSK_PAD_SCALE", "1e-9")
     orc, fr = oracle_binding.load(), _fuzz()
     assert sum(_disagreements(orc, fr, seed, 0.0) for seed in (0, 4, 7)) > 0
