@@ -23,9 +23,11 @@ def _fuzz():
     return fr
 
 
-def _disagreements(orc, fr, seed, offset, n_rays=12000):
+def _disagreements(orc, fr, seed, offset, n_rays=12000, scale=1.0):
     rng = np.random.RandomState(seed)
     flat = fr.fz.random_scene(rng)
+    if scale != 1.0:
+        flat.vertices[:, :3] *= np.float32(scale)
     if offset:
         flat.vertices[:, :3] += np.float32(offset)
     d = flat.desc
@@ -51,6 +53,15 @@ def test_tree_equals_brute_force_with_a_tenth_of_the_padding(monkeypatch, scale,
         monkeypatch.setenv("MSK_PAD_SCALE", scale)
     orc, fr = oracle_binding.load(), _fuzz()
     assert sum(_disagreements(orc, fr, seed, offset) for seed in (0, 6, 7)) == 0       # (seed 6 has a 4 k-triangle mesh)
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1e3])
+def test_the_rule_follows_the_scenes_scale(monkeypatch, scale):
+    """The same scenes a thousand times smaller / larger: the padding is relative to the scene's scale, so nothing changes
+    (at a tenth of the padding, as above)."""
+    monkeypatch.setenv("MSK_PAD_SCALE", "1e-6")
+    orc, fr = oracle_binding.load(), _fuzz()
+    assert sum(_disagreements(orc, fr, seed, 0.0, scale=scale) for seed in (0, 4, 7)) == 0
 
 
 def test_the_padding_is_what_keeps_them_equal(monkeypatch):
