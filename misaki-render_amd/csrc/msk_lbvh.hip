@@ -5,13 +5,17 @@
 // the tree decides how fast a ray finds its hit, never which hit it finds: films are bit-identical with either builder.
 //
 //   k_prims      per triangle: bounding box, 30-bit Morton code of its centre in the scene box -> key = code << 32 | index
-//   (hipCUB)     radix sort of the 64-bit keys (unique by construction)
+//   k_rs_*       stable LSD radix sort of the keys on their Morton half, 8 bits a pass (the index half is ascending to begin with, so
+//                this is the order of the whole 64-bit key): per 2048-key tile a digit histogram, one exclusive scan over
+//                (digit, tile), and a scatter in which ONE WAVE walks its tile 64 keys at a time — a key's rank among the equal
+//                digits of its 64 comes from eight ballots, the running position of every digit sits in LDS
 //   k_hierarchy  per internal node: its key range and split from common-prefix lengths (one thread per node, no atomics)
 //   k_refit      per leaf, bottom-up: the second thread to arrive at a node unions its children's boxes (one counter per node)
-//   (hipCUB)     exclusive scan of the "kept" flags: ranges of <= leaf_size keys become leaves, the rest are renumbered densely
+//   scan         exclusive scan of the "kept" flags (k_scan_tile / k_scan_add, three levels: 2048 per block): ranges of <= leaf_size
+//                keys become leaves, the rest are renumbered densely
 //   k_emit       per kept node: the 64-byte record;  k_tris  per sorted triangle: record + bounds
 #include "msk_lbvh.h"
-#include <hipcub/hipcub.hpp>
+#include <algorithm>
 #include <cmath>
 
 namespace msklbvh {
@@ -190,6 +194,113 @@ k_tris(const unsigned long long *keys, uint32_t n, const float4 *tri_verts, cons
     bounds[(size_t) k * 2 + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
 }
 
+// ------------------------------------------------------------------------------------------
+// exclusive scan of uint32: a block scans a tile of LB_SCAN_TILE elements (eight per thread) and leaves the tile's sum; the sums
+// are scanned the same way (three levels reach 2048^3 elements) and added back
+// ------------------------------------------------------------------------------------------
+#define LB_SCAN_ITEMS 8
+#define LB_SCAN_TILE (LB_BLOCK * LB_SCAN_ITEMS)
+__global__ void __launch_bounds__(LB_BLOCK)
+k_scan_tile(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *tile_sums) {
+    __shared__ uint32_t wave_sum[LB_BLOCK / 64];
+    const uint32_t base = blockIdx.x * LB_SCAN_TILE + threadIdx.x * LB_SCAN_ITEMS, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint32_t v[LB_SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for (int k = 0; k < LB_SCAN_ITEMS; ++k) { v[k] = base + k < n ? in[base + k] : 0u; sum += v[k]; }
+    uint32_t incl = sum;                                  // inclusive scan of the threads' sums across the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= (uint32_t) d) incl += t; }
+    if (lane == 63) wave_sum[w] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < LB_BLOCK / 64; ++k) { if (k < w) before += wave_sum[k]; total += wave_sum[k]; }
+    uint32_t run = before + incl - sum;
+#pragma unroll
+    for (int k = 0; k < LB_SCAN_ITEMS; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 0 && tile_sums) tile_sums[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(LB_BLOCK)
+k_scan_add(uint32_t *out, uint32_t n, const uint32_t *tile_offsets) {
+    const uint32_t add = tile_offsets[blockIdx.x];
+    const uint32_t base = blockIdx.x * LB_SCAN_TILE + threadIdx.x * LB_SCAN_ITEMS;
+#pragma unroll
+    for (int k = 0; k < LB_SCAN_ITEMS; ++k) if (base + k < n) out[base + k] += add;
+}
+static size_t scan_tmp_words(size_t n) {                  // words of scratch exclusive_scan needs for n elements
+    const size_t t1 = (n + LB_SCAN_TILE - 1) / LB_SCAN_TILE, t2 = (t1 + LB_SCAN_TILE - 1) / LB_SCAN_TILE;
+    return 2 * t1 + 2 * t2 + 8;
+}
+static void exclusive_scan(hipStream_t stream, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *tmp) {
+    const uint32_t t1 = (n + LB_SCAN_TILE - 1) / LB_SCAN_TILE;
+    if (t1 <= 1) { hipLaunchKernelGGL(k_scan_tile, dim3(1), dim3(LB_BLOCK), 0, stream, in, out, n, (uint32_t *) nullptr); return; }
+    uint32_t *sums = tmp, *offs = tmp + t1, *rest = tmp + 2 * (size_t) t1;
+    hipLaunchKernelGGL(k_scan_tile, dim3(t1), dim3(LB_BLOCK), 0, stream, in, out, n, sums);
+    exclusive_scan(stream, sums, offs, t1, rest);
+    hipLaunchKernelGGL(k_scan_add, dim3(t1), dim3(LB_BLOCK), 0, stream, out, n, offs);
+}
+
+// ------------------------------------------------------------------------------------------
+// stable LSD radix sort, one 8-bit digit per pass.  Tile = LB_RS_TILE consecutive keys; hist is digit-major ([digit][tile]) so that
+// its exclusive scan is, for every (digit, tile), where that tile's first key of that digit goes.
+// ------------------------------------------------------------------------------------------
+#define LB_RS_TILE 2048
+__global__ void __launch_bounds__(LB_BLOCK)
+k_rs_hist(const unsigned long long *keys, uint32_t n, uint32_t shift, uint32_t n_tiles, uint32_t *hist) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * LB_RS_TILE;
+    for (uint32_t k = threadIdx.x; k < LB_RS_TILE && base + k < n; k += LB_BLOCK)
+        atomicAdd(&h[(uint32_t) (keys[base + k] >> shift) & 255u], 1u);
+    __syncthreads();
+    hist[(size_t) threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
+}
+__global__ void __launch_bounds__(64)
+k_rs_scatter(const unsigned long long *keys, unsigned long long *out, uint32_t n, uint32_t shift, uint32_t n_tiles, const uint32_t *offsets) {
+    __shared__ uint32_t pos[256];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t d = lane; d < 256u; d += 64u) pos[d] = offsets[(size_t) d * n_tiles + blockIdx.x];
+    __syncthreads();
+    const uint32_t base = blockIdx.x * LB_RS_TILE;
+    for (uint32_t c = 0; c < LB_RS_TILE && base + c < n; c += 64u) {           // (the condition is uniform: the whole wave leaves together)
+        const bool live = base + c + lane < n;
+        const unsigned long long key = live ? keys[base + c + lane] : 0ull;
+        const uint32_t d = (uint32_t) (key >> shift) & 255u;
+        unsigned long long peers = __ballot(live);                             // the live lanes that hold the same digit
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t) __popcll(peers & ((1ull << lane) - 1ull)), cnt = (uint32_t) __popcll(peers);
+        const uint32_t first = live ? pos[d] : 0u;
+        __syncthreads();                                                       // every lane has read before the digit's first lane moves it on
+        if (live) {
+            out[first + rank] = key;
+            if (rank == 0u) pos[d] = first + cnt;
+        }
+        __syncthreads();
+    }
+}
+
+// keys (code << 32 | index, index ascending) -> k1 sorted; k0 is scratch afterwards.  hist / hist_off: 256 * ceil(n / LB_RS_TILE) words
+// each, scan_tmp: scan_tmp_words(max(that, n)) words
+static hipError_t sort_by_morton(hipStream_t stream, unsigned long long *k0, unsigned long long *k1, uint32_t n, uint32_t *hist, uint32_t *hist_off,
+                                 uint32_t *scan_tmp) {
+    const uint32_t n_tiles = (n + LB_RS_TILE - 1) / LB_RS_TILE;
+    for (uint32_t pass = 0; pass < 4; ++pass) {              // 30 bits of Morton code: four 8-bit passes, k0 -> k1 -> k0 -> k1 -> k0
+        const unsigned long long *src = (pass & 1u) ? k1 : k0;
+        unsigned long long *dst = (pass & 1u) ? k0 : k1;
+        const uint32_t shift = 32u + 8u * pass;
+        hipLaunchKernelGGL(k_rs_hist, dim3(n_tiles), dim3(LB_BLOCK), 0, stream, src, n, shift, n_tiles, hist);
+        exclusive_scan(stream, hist, hist_off, 256u * n_tiles, scan_tmp);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(n_tiles), dim3(64), 0, stream, src, dst, n, shift, n_tiles, hist_off);
+    }
+    return hipMemcpyAsync(k1, k0, (size_t) n * 8, hipMemcpyDeviceToDevice, stream);
+}
+
 #define LB_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(err, err_len, "%s: %s", #x, hipGetErrorString(e_)); rc = -1; goto done; } } while (0)
 
 int build(hipStream_t stream, const Input &in, float4 *nodes, float4 *tris, float4 *bounds, Result *out, char *err, size_t err_len) {
@@ -199,7 +310,6 @@ int build(hipStream_t stream, const Input &in, float4 *nodes, float4 *tris, floa
     if (n == 0) return 0;
     const uint32_t leaf_size = in.leaf_size < 1 ? 1 : in.leaf_size;
     char *pool = nullptr;
-    void *cub_tmp = nullptr;
     // one allocation for the temporaries
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t) 255; return o; };
@@ -207,7 +317,9 @@ int build(hipStream_t stream, const Input &in, float4 *nodes, float4 *tris, floa
     const size_t o_first = take((size_t) n * 4), o_last = take((size_t) n * 4), o_left = take((size_t) n * 4), o_right = take((size_t) n * 4),
                  o_par = take((size_t) n * 4), o_lpar = take((size_t) n * 4), o_nbox = take((size_t) n * sizeof(Box6)),
                  o_h = take((size_t) n * 4), o_arr = take((size_t) n * 4), o_keep = take((size_t) n * 4), o_new = take((size_t) n * 4);
-    size_t sort_bytes = 0, scan_bytes = 0;
+    const uint32_t n_tiles = (n + LB_RS_TILE - 1) / LB_RS_TILE;
+    const size_t n_hist = (size_t) 256 * n_tiles;
+    const size_t o_hist = take(n_hist * 4), o_hoff = take(n_hist * 4), o_stmp = take(scan_tmp_words(std::max<size_t>(n_hist, n)) * 4);
     const uint32_t grid = (n + LB_BLOCK - 1) / LB_BLOCK;
     LB_TRY(hipMalloc((void **) &pool, off));
     {
@@ -218,14 +330,12 @@ int build(hipStream_t stream, const Input &in, float4 *nodes, float4 *tris, floa
         Box6 *node_box = (Box6 *) (pool + o_nbox);
         uint32_t *height = (uint32_t *) (pool + o_h), *arrived = (uint32_t *) (pool + o_arr), *keep = (uint32_t *) (pool + o_keep),
                  *new_index = (uint32_t *) (pool + o_new);
-        LB_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, k0, k1, (int) n, 0, 64, stream));
-        LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, keep, new_index, (int) n, stream));
-        LB_TRY(hipMalloc(&cub_tmp, std::max(sort_bytes, scan_bytes) + 256));
+        uint32_t *hist = (uint32_t *) (pool + o_hist), *hist_off = (uint32_t *) (pool + o_hoff), *scan_tmp = (uint32_t *) (pool + o_stmp);
         const float ex = in.hi[0] - in.lo[0], ey = in.hi[1] - in.lo[1], ez = in.hi[2] - in.lo[2];
         const float3 lo = make_float3(in.lo[0], in.lo[1], in.lo[2]);
         const float3 inv = make_float3(ex > 0.f ? 1.f / ex : 0.f, ey > 0.f ? 1.f / ey : 0.f, ez > 0.f ? 1.f / ez : 0.f);
         hipLaunchKernelGGL(k_prims, dim3(grid), dim3(LB_BLOCK), 0, stream, in.tri_verts, n, lo, inv, tri_box, k0);
-        LB_TRY(hipcub::DeviceRadixSort::SortKeys(cub_tmp, sort_bytes, k0, k1, (int) n, 0, 64, stream));
+        LB_TRY(sort_by_morton(stream, k0, k1, n, hist, hist_off, scan_tmp));
         if (n == 1 || n <= leaf_size) {
             out->root_ref = LB_LEAF_BIT | (0u << 5) | n;
         } else {
@@ -234,7 +344,7 @@ int build(hipStream_t stream, const Input &in, float4 *nodes, float4 *tris, floa
             hipLaunchKernelGGL(k_hierarchy, dim3(grid), dim3(LB_BLOCK), 0, stream, k1, (int) n, h);
             hipLaunchKernelGGL(k_refit, dim3(grid), dim3(LB_BLOCK), 0, stream, k1, (int) n, h, tri_box, node_box, height, arrived);
             hipLaunchKernelGGL(k_keep, dim3(grid), dim3(LB_BLOCK), 0, stream, (int) n, h, leaf_size, keep);
-            LB_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp, scan_bytes, keep, new_index, (int) (n - 1), stream));
+            exclusive_scan(stream, keep, new_index, n - 1, scan_tmp);
             hipLaunchKernelGGL(k_emit, dim3(grid), dim3(LB_BLOCK), 0, stream, k1, (int) n, h, leaf_size, keep, new_index, tri_box, node_box,
                                in.box_pad, nodes);
             uint32_t last_keep = 0, last_new = 0, root_height = 0;
@@ -252,7 +362,6 @@ int build(hipStream_t stream, const Input &in, float4 *nodes, float4 *tris, floa
         LB_TRY(hipStreamSynchronize(stream));
     }
 done:
-    if (cub_tmp) (void) hipFree(cub_tmp);
     if (pool) (void) hipFree(pool);
     return rc;
 }
