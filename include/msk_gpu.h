@@ -67,7 +67,7 @@ extern "C" {
 /* RNG semantics (the reference's own seeding is not reproducible) */
 #define MSK_RNG_PCG_BLOCK      0   /* samplers/independent.cpp as written: one PCG32 stream per image block, drawn from in the scalar
                                       loops' order.  Sequential by construction: the device renders one block per LANE (msk_serial.h) —
-                                      a fidelity mode (BASELINE config 1 in about three seconds on 64 lanes), bit-identical to the oracle's; msk_gpu_render /
+                                      a fidelity mode (BASELINE config 1 in about 1.2 seconds, one block per wave), bit-identical to the oracle's; msk_gpu_render /
                                       _render_device only (not the "aov" integrator, not msk_gpu_sample_pixels) */
 #define MSK_RNG_COUNTER        1   /* stateless hash of (seed,pixel,sample,dim): the hot path (wavefront kernels); GPU + oracle */
 

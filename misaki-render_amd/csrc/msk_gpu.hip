@@ -980,7 +980,10 @@ static int render_serial(msk_scene *sc, const msk_render_params *prm, float *d_f
     DevBuf counters, ovf;
     HIP_TRY(ctx, counters.reserve(32));
     HIP_TRY(ctx, hipMemsetAsync(counters.p, 0, 24, stream));
-    const uint32_t grid = (uint32_t) ((owned.size() + MSK_BLOCK - 1) / MSK_BLOCK);
+    // few blocks (BASELINE config 1 has 64): one block per WAVE — the GPU holds ~2000 of this kernel's waves at once, and a wave that
+    // runs one scalar loop does not pay for the branches of 63 others (config 1: 3.0 s -> see profiles/r04_pcg_block_config1.txt)
+    const bool per_wave = owned.size() <= env_u32("MSK_SERIAL_PER_WAVE_MAX", 16384);
+    const uint32_t grid = (uint32_t) ((owned.size() * (per_wave ? MSK_WAVE : 1) + MSK_BLOCK - 1) / MSK_BLOCK);
     // the binary tree's stack: depth + 2 entries, the first sc->dev.stack_entries of them in LDS
     DeviceScene ds = sc->dev;
     const uint32_t need = (uint32_t) sc->bvh_depth + 2u;
@@ -993,7 +996,7 @@ static int render_serial(msk_scene *sc, const msk_render_params *prm, float *d_f
         sp.rr_depth = prm->rr_depth; sp.max_depth = prm->max_depth; sp.hide_emitters = prm->hide_emitters;
         sp.blocks = ws.blocks.as<BlockInfo>(); sp.n_blocks = (uint32_t) owned.size();
         sp.block_buf = ws.block_buf.as<float>(); sp.buf_stride = buf_stride;
-        sp.stack_ovf = ovf.as<uint32_t>(); sp.counters = counters.as<unsigned long long>();
+        sp.stack_ovf = ovf.as<uint32_t>(); sp.counters = counters.as<unsigned long long>(); sp.per_wave = per_wave ? 1u : 0u;
         hipLaunchKernelGGL(k_path_serial, dim3(grid), dim3(MSK_BLOCK), (size_t) ds.stack_entries * MSK_BLOCK * 4, stream, ds, sp);
     }
     FilmOut fo;

@@ -40,6 +40,7 @@ struct SerialParams {
     const BlockInfo *blocks; uint32_t n_blocks;
     float *block_buf; uint32_t buf_stride;
     uint32_t *stack_ovf;
+    uint32_t per_wave;          // 1: image block = wave index, only lane 0 works (see k_path_serial)
     unsigned long long *counters;               // [0] samples [1] segments [2] shadow rays
 };
 
@@ -67,7 +68,11 @@ k_path_serial(DeviceScene sc, SerialParams prm) {
     uint32_t *stack_base = (uint32_t *) lds_dyn;
     const LaneStack<true> stack{stack_base + threadIdx.x, prm.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x,
                                 (int) sc.stack_entries, (size_t) gridDim.x * MSK_BLOCK, nullptr};
-    const uint32_t bi = blockIdx.x * MSK_BLOCK + threadIdx.x;
+    // one image block per lane — or, while there are fewer blocks than the GPU has room for waves, per WAVE (lane 0): 64 scalar
+    // loops packed into one wave execute the union of their branches, one loop per wave executes its own (prm.per_wave)
+    const uint32_t tid = blockIdx.x * MSK_BLOCK + threadIdx.x;
+    if (prm.per_wave && (threadIdx.x & (MSK_WAVE - 1u))) return;
+    const uint32_t bi = prm.per_wave ? tid / MSK_WAVE : tid;
     if (bi >= prm.n_blocks) return;
     const SceneTables tb = stage_tables<false>(sc, nullptr);
     const BlockInfo b = prm.blocks[bi];
