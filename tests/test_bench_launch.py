@@ -136,3 +136,19 @@ def test_build_id_ignores_comments_and_white_space():
     assert len(b.build_id()) == 12
     summary = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
     assert summary.get("_build_id") == b.build_id(), "profiles/pmc_summary.json was taken on another build: re-run tools/profile_all.sh + summarize_profiles.py"
+
+
+def test_build_flags_are_the_contracts_and_part_of_the_build_id(monkeypatch):
+    """The two numerics flags of DESIGN.md §3 are in the one place every build reads (__graft_entry__.HIPCC_FLAGS, through
+    tools/build_id.py --flags also tools/build_variant.sh and kernel_regs.sh), and a change of flags is a change of build."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import build_id as b
+    flags = b._flags()
+    assert "-ffp-contract=off" in flags and "-fhip-fp32-correctly-rounded-divide-sqrt" in flags and "--offload-arch=gfx950" in flags
+    assert not any(f.startswith("-ffast-math") or f == "-Ofast" for f in flags)
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    assert flags == g.HIPCC_FLAGS
+    before = b.build_id()
+    monkeypatch.setattr(b, "_flags", lambda: flags + ["-DSOMETHING"])
+    assert b.build_id() != before
