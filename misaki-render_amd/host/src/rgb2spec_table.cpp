@@ -17,6 +17,7 @@
 #include <misaki/render.h>
 
 #include <stdlib.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -198,6 +199,7 @@ void rgb2spec_write_table(const std::string &path, const std::vector<float> &sca
     std::string tmp = path + ".tmp.XXXXXX";
     const int fd = mkstemp(&tmp[0]);
     if (fd < 0) Throw("Could not create \"{}\"", tmp);
+    (void) fchmod(fd, 0644);          // mkstemp creates 0600: the table beside a shared install must be readable by its other users
     FILE *f = fdopen(fd, "wb");
     if (!f) { close(fd); std::remove(tmp.c_str()); Throw("Could not create \"{}\"", tmp); }
     const uint32_t res = (uint32_t) scale.size();
