@@ -556,7 +556,7 @@ def main():
         value = samples_step * args.steps / dt / 1e6
         par = "single GPU"
         if world > 1:
-            par = f"{args.shard[:-1]}-shard x{world}, one process per GPU + RCCL film reduce"
+            par = f"{args.shard[:-1]}-shard x{world}, one process per GPU + " + ("gloo film reduce through host copies (rehearsal on one GPU)" if rehearsal else "RCCL film reduce")
         elif members > 1:
             par = f"sample-shard x{members} behind one context (msk_gpu_init(ids, {members})), films summed by k_film_sum over peer access"
         out = {
