@@ -1453,6 +1453,28 @@ MSK_DEV spec bsdf_sample(const BsdfRec &b, f3 wi, float sample1, f2 sample, spec
 // k_shade_gen
 // ------------------------------------------------------------------------------------------
 
+// Cold kernel arguments, read where they are used (MSK_COLD_KARGS, default on since round 5).  The shading kernels take
+// DeviceScene, PathState and PassParams by value: ~180 dwords of kernel arguments which the compiler loads at the kernel's entry
+// and — the chunk loop needing every SGPR it can get — parks in VGPR lanes: a v_writelane per dword up front and a v_readlane,
+// a VALU instruction, at every use (the camera matrices alone: 34 lanes, read back per new camera sample chunk).  What only
+// the record writer and the regeneration loop need (record addresses, pixel tables, filter constants, camera) is instead read
+// from the kernel-argument segment by scalar loads at that point, through a pointer the optimiser cannot see through (an empty
+// `asm volatile`), so that the loads cannot be hoisted back to the entry.  Requires (DeviceScene, PathState, PassParams) to be
+// the kernel's first three arguments, in that order: k_shade_gen and k_wavefront, the only kernels that run shade_region.
+#ifndef MSK_COLD_KARGS
+#define MSK_COLD_KARGS 1
+#endif
+typedef const char __attribute__((address_space(4))) *karg_ptr;
+MSK_DEV karg_ptr karg_base() {
+    karg_ptr p = (karg_ptr) __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+template <class T> MSK_DEV T karg(karg_ptr base, size_t off) { return *(const T __attribute__((address_space(4))) *) (base + off); }
+#define MSK_KARG_SC(base, T, member) karg<T>(base, offsetof(DeviceScene, member))
+#define MSK_KARG_PP(base, T, member) karg<T>(base, sizeof(DeviceScene) + sizeof(PathState) + offsetof(PassParams, member))
+static_assert(sizeof(DeviceScene) % 8 == 0 && sizeof(PathState) % 8 == 0, "the three argument structs are laid out back to back");
+
 // ImageBlock::put's per-sample part (imageblock.cpp:84-96), done once per sample instead of once per (sample, target pixel):
 // a sample of block pixel (lx, ly) can only reach the five target columns lx .. lx + 4 and rows ly .. ly + 4 of the bordered
 // block (border = 2: the default Gaussian, radius 2).  Field i (6 bits) of the x word is the index into the filter's
@@ -1473,18 +1495,19 @@ MSK_DEV uint32_t weight_word(float pos, uint32_t l, float radius, float scale) {
     }
     return w;
 }
-MSK_DEV SampleWeights sample_weights(const DeviceScene &sc, uint4 pt, float px, float py) {
+MSK_DEV SampleWeights sample_weights(float filter_radius, float filter_scale, uint4 pt, float px, float py) {
     // imageblock.cpp:84-85: pos - 0.5 - (offset - border)
     const float bx = px - 0.5f - (float) (int) pt.z, by = py - 0.5f - (float) (int) pt.w;
     SampleWeights r;
-    r.x = weight_word(bx, pt.y & 0xffffu, sc.filter_radius, sc.filter_scale);
-    r.y = weight_word(by, pt.y >> 16, sc.filter_radius, sc.filter_scale);
+    r.x = weight_word(bx, pt.y & 0xffffu, filter_radius, filter_scale);
+    r.y = weight_word(by, pt.y >> 16, filter_radius, filter_scale);
     return r;
 }
+MSK_DEV SampleWeights sample_weights(const DeviceScene &sc, uint4 pt, float px, float py) { return sample_weights(sc.filter_radius, sc.filter_scale, pt, px, py); }
 // film coordinates of a pass pixel from its table entry {film index, x | y << 16 inside its block, block offset - border}
 // (= film index % width, film index / width, without the integer divisions)
-MSK_DEV uint32_t pixel_x(const DeviceScene &sc, uint4 pt) { return (uint32_t) ((int) pt.z + sc.filter_border) + (pt.y & 0xffffu); }
-MSK_DEV uint32_t pixel_y(const DeviceScene &sc, uint4 pt) { return (uint32_t) ((int) pt.w + sc.filter_border) + (pt.y >> 16); }
+MSK_DEV uint32_t pixel_x(int filter_border, uint4 pt) { return (uint32_t) ((int) pt.z + filter_border) + (pt.y & 0xffffu); }
+MSK_DEV uint32_t pixel_y(int filter_border, uint4 pt) { return (uint32_t) ((int) pt.w + filter_border) + (pt.y >> 16); }
 MSK_DEV uint32_t nonfinite_flag(float a, float b, float c) {
     const bool fin = fabsf(a) < MSK_INF_F && fabsf(b) < MSK_INF_F && fabsf(c) < MSK_INF_F;      // false for nan too
     return fin ? 0u : MSK_W_NONFINITE;
@@ -1493,32 +1516,47 @@ MSK_DEV uint32_t nonfinite_flag(float a, float b, float c) {
 // render_sample's tail for one finished path (integrator.cpp:115-125): ray weight, XYZ, film position -> sample record
 template <bool DIFFUSE_ONLY>
 MSK_DEV void emit_record(const DeviceScene &sc, const SceneTables &tb, const PassParams &pp, spec wl, spec res, uint32_t pix, uint32_t si) {
-    const uint32_t j = pp.pix_to_j[pix];
+    // what only this function needs of the kernel's arguments (MSK_COLD_KARGS above)
+    struct Cold { const uint32_t *pix_to_j; const uint4 *pix_table; float4 *rec_a; float *rec_b; float4 *aov_rgb; uint32_t spp_owned, packed;
+                  float filter_radius, filter_scale; int filter_border; } k;
+    if (MSK_COLD_KARGS) {
+        const karg_ptr ka = karg_base();
+        k.pix_to_j = MSK_KARG_PP(ka, const uint32_t *, pix_to_j); k.pix_table = MSK_KARG_PP(ka, const uint4 *, pix_table);
+        k.rec_a = MSK_KARG_PP(ka, float4 *, rec_a); k.rec_b = MSK_KARG_PP(ka, float *, rec_b); k.aov_rgb = MSK_KARG_PP(ka, float4 *, aov_rgb);
+        k.spp_owned = MSK_KARG_PP(ka, uint32_t, spp_owned); k.packed = MSK_KARG_PP(ka, uint32_t, packed);
+        k.filter_radius = MSK_KARG_SC(ka, float, filter_radius); k.filter_scale = MSK_KARG_SC(ka, float, filter_scale);
+        k.filter_border = MSK_KARG_SC(ka, int32_t, filter_border);
+    } else {
+        k.pix_to_j = pp.pix_to_j; k.pix_table = pp.pix_table; k.rec_a = pp.rec_a; k.rec_b = pp.rec_b; k.aov_rgb = pp.aov_rgb;
+        k.spp_owned = pp.spp_owned; k.packed = pp.packed;
+        k.filter_radius = sc.filter_radius; k.filter_scale = sc.filter_scale; k.filter_border = sc.filter_border;
+    }
+    const uint32_t j = k.pix_to_j[pix];
     spec wgt;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { wgt.v[k] = wavelength_weight(wl.v[k]); __builtin_amdgcn_sched_barrier(0); }
+    for (int q = 0; q < 4; ++q) { wgt.v[q] = wavelength_weight(wl.v[q]); __builtin_amdgcn_sched_barrier(0); }
     const spec result = res * wgt;
     float X, Y, Z;
     spectrum_to_xyz(tb.cie, result, wl, &X, &Y, &Z);
     const uint64_t key = counter_key(pp.seed, pix, pp.sample_first + si * pp.sample_stride);
     const f2 jit = counter_pair(key, 0);
-    const uint4 pt = pp.pix_table[j];
-    const float px = (float) pixel_x(sc, pt) + jit.x, py = (float) pixel_y(sc, pt) + jit.y;
-    const size_t r = (size_t) j * pp.spp_owned + si;
+    const uint4 pt = k.pix_table[j];
+    const float px = (float) pixel_x(k.filter_border, pt) + jit.x, py = (float) pixel_y(k.filter_border, pt) + jit.y;
+    const size_t r = (size_t) j * k.spp_owned + si;
     float wx = px, wy = py;
-    if (pp.packed) {
-        const SampleWeights sw = sample_weights(sc, pt, px, py);
+    if (k.packed) {
+        const SampleWeights sw = sample_weights(k.filter_radius, k.filter_scale, pt, px, py);
         wx = __uint_as_float(sw.x | nonfinite_flag(X, Y, Z)); wy = __uint_as_float(sw.y);
     }
-    st4<2>(pp.rec_a + r, make_float4(X, Y, Z, wx));
-    if (MSK_NT >= 2) __builtin_nontemporal_store(wy, pp.rec_b + r); else pp.rec_b[r] = wy;
-    if (!DIFFUSE_ONLY && pp.aov_rgb) {                             // aov.cpp:124-136: the sample before ray_weight
+    st4<2>(k.rec_a + r, make_float4(X, Y, Z, wx));
+    if (MSK_NT >= 2) __builtin_nontemporal_store(wy, k.rec_b + r); else k.rec_b[r] = wy;
+    if (!DIFFUSE_ONLY && k.aov_rgb) {                              // aov.cpp:124-136: the sample before ray_weight
         float x0, y0, z0;
         spectrum_to_xyz(tb.cie, res, wl, &x0, &y0, &z0);
         const float R = 3.240479f * x0 + (-1.537150f * y0 + -0.498535f * z0), G = -0.969256f * x0 + (1.875991f * y0 + 0.041556f * z0),
                     B = 0.055648f * x0 + (-0.204043f * y0 + 1.057311f * z0);
-        if (pp.packed) wx = __uint_as_float((__float_as_uint(wx) & MSK_W_FIELDS) | nonfinite_flag(R, G, B));
-        pp.aov_rgb[r] = make_float4(R, G, B, wx);
+        if (k.packed) wx = __uint_as_float((__float_as_uint(wx) & MSK_W_FIELDS) | nonfinite_flag(R, G, B));
+        k.aov_rgb[r] = make_float4(R, G, B, wx);
     }
 }
 
@@ -1871,21 +1909,36 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
     const uint32_t n_free = pp.region_size - (cur_s + cur_n);
     const unsigned long long first = rc.next_sample, left = rc.end_sample - rc.next_sample;
     const uint32_t got = (uint32_t) (left < n_free ? left : n_free);
+    if (got > 0) {
+    // the camera, the pixel table and the sample partition: read here, where they are used (MSK_COLD_KARGS)
+    struct Cold { float s2c[16], to_world[16], near_clip, far_clip; int filter_border; const uint4 *pix_table; uint32_t spp_owned, n_regions; } k;
+    if (MSK_COLD_KARGS) {
+        const karg_ptr ka = karg_base();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { k.s2c[q] = karg<float>(ka, offsetof(DeviceScene, s2c) + 4 * q); k.to_world[q] = karg<float>(ka, offsetof(DeviceScene, to_world) + 4 * q); }
+        k.near_clip = MSK_KARG_SC(ka, float, near_clip); k.far_clip = MSK_KARG_SC(ka, float, far_clip); k.filter_border = MSK_KARG_SC(ka, int32_t, filter_border);
+        k.pix_table = MSK_KARG_PP(ka, const uint4 *, pix_table); k.spp_owned = MSK_KARG_PP(ka, uint32_t, spp_owned); k.n_regions = MSK_KARG_PP(ka, uint32_t, n_regions);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { k.s2c[q] = sc.s2c[q]; k.to_world[q] = sc.to_world[q]; }
+        k.near_clip = sc.near_clip; k.far_clip = sc.far_clip; k.filter_border = sc.filter_border;
+        k.pix_table = pp.pix_table; k.spp_owned = pp.spp_owned; k.n_regions = pp.n_regions;
+    }
     // the linear sample index -> (pass pixel, sample) split is a 32-bit division whenever this sweep's indices fit (a pass
     // of < 2^32 samples: every configuration but the largest single-GPU ones), the 64-bit one otherwise
-    const bool idx32 = got > 0 && (((((first + got - 1) >> 6) * pp.n_regions + wave) << 6) | 63ull) < (1ull << 32);
-    for (uint32_t k = lane; k < got; k += MSK_WAVE) {
-        const unsigned long long q = first + k;
-        const unsigned long long sidx_lin = (((q >> 6) * pp.n_regions + wave) << 6) | (q & 63ull);
+    const bool idx32 = (((((first + got - 1) >> 6) * k.n_regions + wave) << 6) | 63ull) < (1ull << 32);
+    for (uint32_t kk = lane; kk < got; kk += MSK_WAVE) {
+        const unsigned long long q = first + kk;
+        const unsigned long long sidx_lin = (((q >> 6) * k.n_regions + wave) << 6) | (q & 63ull);
         uint32_t j, si;
-        if (idx32) { j = (uint32_t) sidx_lin / pp.spp_owned; si = (uint32_t) sidx_lin - j * pp.spp_owned; }
-        else { j = (uint32_t) (sidx_lin / pp.spp_owned); si = (uint32_t) (sidx_lin % pp.spp_owned); }
-        const uint4 pt = pp.pix_table[j];
+        if (idx32) { j = (uint32_t) sidx_lin / k.spp_owned; si = (uint32_t) sidx_lin - j * k.spp_owned; }
+        else { j = (uint32_t) (sidx_lin / k.spp_owned); si = (uint32_t) (sidx_lin % k.spp_owned); }
+        const uint4 pt = k.pix_table[j];
         const uint32_t pix = pt.x;
         const uint64_t key = counter_key(pp.seed, pix, pp.sample_first + si * pp.sample_stride);
         const f2 jit = counter_pair(key, 0);
         const float wsample = counter_pair(key, 1).x;
-        const float px = (float) pixel_x(sc, pt) + jit.x, py = (float) pixel_y(sc, pt) + jit.y;
+        const float px = (float) pixel_x(k.filter_border, pt) + jit.x, py = (float) pixel_y(k.filter_border, pt) + jit.y;
         spec wl;
 #pragma unroll
         for (int q = 0; q < 4; ++q) { wl.v[q] = wavelength_of(wsample, q); __builtin_amdgcn_sched_barrier(0); }   // one fp64 chain at a time: interleaved they cost 28 VGPRs
@@ -1893,25 +1946,26 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
         float r4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            r4[q] = ((sc.s2c[q * 4 + 0] * px + sc.s2c[q * 4 + 1] * py) + sc.s2c[q * 4 + 2] * 0.f) + sc.s2c[q * 4 + 3] * 1.f;
+            r4[q] = ((k.s2c[q * 4 + 0] * px + k.s2c[q * 4 + 1] * py) + k.s2c[q * 4 + 2] * 0.f) + k.s2c[q * 4 + 3] * 1.f;
         const f3 near_p = mk3(r4[0] / r4[3], r4[1] / r4[3], r4[2] / r4[3]);
         const f3 dl = normalized(near_p);
         const float inv_z = 1.f / dl.z;
         float o4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            o4[q] = ((sc.to_world[q * 4 + 0] * 0.f + sc.to_world[q * 4 + 1] * 0.f) + sc.to_world[q * 4 + 2] * 0.f) +
-                    sc.to_world[q * 4 + 3] * 1.f;
+            o4[q] = ((k.to_world[q * 4 + 0] * 0.f + k.to_world[q * 4 + 1] * 0.f) + k.to_world[q * 4 + 2] * 0.f) +
+                    k.to_world[q * 4 + 3] * 1.f;
         const f3 ow = mk3(o4[0] / o4[3], o4[1] / o4[3], o4[2] / o4[3]);
-        const float *m = sc.to_world;
+        const float *m = k.to_world;
         const f3 dw = mk3(m[0] * dl.x + (m[1] * dl.y + m[2] * dl.z), m[4] * dl.x + (m[5] * dl.y + m[6] * dl.z),
                           m[8] * dl.x + (m[9] * dl.y + m[10] * dl.z));
-        const uint32_t o = base_out + (last - (cur_n + k));         // the new samples carry no shadow ray: they continue that group
+        const uint32_t o = base_out + (last - (cur_n + kk));        // the new samples carry no shadow ray: they continue that group
         st2<1>(st.id + o, make_uint2(pix, si | (1u << MSK_DEPTH_SHIFT)));
         st4<1>(st.wl + o, to4(wl));                                      // thr = 1, res = 0: RegionCtl::n_new
-        st4<4>(st.ray_o + o, make_float4(ow.x, ow.y, ow.z, sc.near_clip * inv_z));
-        st4<4>(st.ray_d + o, make_float4(dw.x, dw.y, dw.z, sc.far_clip * inv_z));
+        st4<4>(st.ray_o + o, make_float4(ow.x, ow.y, ow.z, k.near_clip * inv_z));
+        st4<4>(st.ray_d + o, make_float4(dw.x, dw.y, dw.z, k.far_clip * inv_z));
         if (!DIFFUSE_ONLY) st.aux[o] = make_float2(1.f, 0.f);
+    }
     }
     const uint32_t n_out = cur_s + cur_n + got;
     rc.count = n_out; rc.half_ns = (cur_s << 1) | ((rc.half_ns & 1u) ^ 1u); rc.n_new = got;
