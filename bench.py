@@ -543,8 +543,9 @@ def main():
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "dry_run": True, "reduce_ok": ok,
                           "config": {"workload": "none (launch / rendezvous / reduce only)", "samples_per_step": WIDTH * HEIGHT * spp_total,
+                                     "shard": args.shard if world > 1 else "none",
                                      "rccl_ranks": dist.get_world_size() if dist is not None else 1, "devices_seen": n_dev,
-                                     "balance": balance}}),
+                                     "balanced": balance is not None}, "balance": balance}),
               flush=True)
     elif not args.dry_run:
         # the same K steps with the film left in HBM (every rank takes part: the steps hold collectives)
@@ -564,12 +565,15 @@ def main():
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             **({"rehearsal": True, "film_finite": bool(np.isfinite(host_film).all()), "film_weight_sum": float(host_film[..., 4].astype(np.float64).sum())} if rehearsal else {}),
-            "config": {"workload": f"cbox {WIDTH}x{HEIGHT} @ {args.spp} spp per GPU ({spp_total} spp total), diffuse BSDFs, "
-                                   f"path integrator (NEE+MIS, RR from depth 4), counter RNG, Gaussian filter, "
-                                   f"ordered film resolve and the film's copy-back to the host included",
-                       "parallelism": par, "samples_per_step": samples_step,
+            # (`config` holds scalars only: the driver's parser drops nested values; `workload` stays under 120 characters)
+            "config": {"workload": f"cbox {WIDTH}x{HEIGHT} @ {args.spp} spp/GPU, diffuse, path (NEE+MIS, RR), counter RNG, incl. film resolve + film copy-back",
+                       "timing_scope": "incl_copyback", "spp_total": spp_total,
+                       "parallelism": par, "shard": (args.shard if world > 1 else "samples" if members > 1 else "none"), "samples_per_step": samples_step,
                        "rccl_ranks": dist.get_world_size() if dist is not None else 1, "in_process_members": members,
-                       "devices_seen": n_dev, "balance": balance},
+                       "devices_seen": n_dev, "balanced": balance is not None},
+            # what the step's clock covers (integrator.cpp:43-78 is the reference's scope): since round 4 `value` includes the film's
+            # copy-back to the host (rounds 1-3: film left in HBM = `value_film_in_hbm`, the figure to compare across rounds)
+            "timing_scope": "incl_copyback", "balance": balance,
             "roofline": roofline(stats, args),
         }
         if dt_hbm is not None:
@@ -577,7 +581,7 @@ def main():
             out["value_film_in_hbm"] = round(samples_step * args.steps / dt_hbm / 1e6, 2)
         # the measured headline is safe on stderr before anything slower or riskier runs (CPU baselines, other configs)
         print("bench.py headline (extras follow on stdout): " + json.dumps(out), file=sys.stderr, flush=True)
-        compact = {}
+        compact = {}                    # scalars that ride in `config`: the driver's parser keeps `config`, `roofline` and `cpu_baseline`
         if not args.no_cpu_baseline and n_gpus == 1:
             try:
                 out["l2_vs_cpu"] = l2_vs_cpu(abi, hm, flat, host_film, prm)
@@ -587,6 +591,7 @@ def main():
             # the reference CLI caps TBB at 8 threads (main.cpp:43-44): that run is `cpu_baseline` (+ config 1 under `config1`);
             # the same port on every hardware thread of this host rides along (SURVEY §8d asks for both)
             out["cpu_baseline"] = cpu_baseline(abi, hm, flat, min(8, os.cpu_count() or 1))
+            compact["cpu_config1_msamples_per_s"] = out["cpu_baseline"]["config1"]["value"]
             # every hardware thread of this host: the full-size counter-RNG render l2_vs_cpu just timed (same port, same work
             # per sample but for the sampler).  The cores that can actually run are the cgroup's quota, not the thread count.
             l2 = out.get("l2_vs_cpu") or {}
@@ -603,8 +608,9 @@ def main():
             for e in out["other_configs"]:
                 if "value" in e:
                     compact[e["tag"] + "_msamples_per_s"] = e["value"]
-        # the driver's parser keeps `config`, `roofline` and `cpu_baseline`: the other configs' throughputs and the L2 ride there too
-        out["config"]["other"] = compact or None
+        out["config"].update(compact)       # c3 / c5 / c4_1gpu _msamples_per_s, l2_max, cpu_config1_msamples_per_s
+        if "cpu_baseline_all_threads" in out:
+            out["config"]["cpu_all_threads_msamples_per_s"] = out["cpu_baseline_all_threads"]["value"]
         print(json.dumps(out), flush=True)
     if scene is not None:
         scene.close()

@@ -222,7 +222,10 @@ typedef struct msk_render_params {
     uint32_t block_first, block_stride;
     /* ... and of every pixel the sample indices s = sample_first + k * sample_stride (k = 0, 1, ...) below spp.
        (0,1) = everything; (r,G) = rank r's interleaved share of G; (a,1) with spp = b = the contiguous range [a, b),
-       which lets shares of unequal size be handed out (misaki-render_amd/multigpu.py).                           */
+       which lets shares of unequal size be handed out (misaki-render_amd/multigpu.py).
+       MSK_RNG_PCG_BLOCK takes (0,1) only (MSK_ERR_UNSUPPORTED otherwise): a block's samples share one sequential PCG32 stream
+       (samplers/independent.cpp:9-35), so shards of its sample indices would all draw the same numbers; that mode shards
+       by blocks.                                                                                                 */
     uint32_t sample_first, sample_stride;
 } msk_render_params;
 
@@ -255,7 +258,8 @@ typedef struct msk_scene msk_scene;
 /* device_ids: n >= 1 HIP ordinals (at most 8).  n == 1: an ordinary context on that device.  n > 1: a GROUP context
    (SURVEY §8b writes the entry point with a device list; csrc/msk_multi.h): one member context per entry — an ordinal may
    repeat —, every scene created on it lives on every member, msk_gpu_render / _render_device / _render_aov shard the call's
-   samples over the members by index (member k: sample_first + (k + j n) sample_stride), one host thread each, and sum the
+   samples over the members by index (member k: sample_first + (k + j n) sample_stride; a MSK_RNG_PCG_BLOCK call, whose
+   samples cannot be sharded, by spiral block: block_first + (k + j n) block_stride), one host thread each, and sum the
    films on device_ids[0] over peer access in member order; d_film_xyzaw of msk_gpu_render_device is memory of device_ids[0];
    the sub-stage entry points run on the first member.  msk_stats of a group call: samples / segments / shadow_rays / launches_* and
    the kernel-time samples ms_trace / ms_shade / n_*_launches are SUMS over the members (device time of n devices: not comparable
@@ -267,7 +271,12 @@ void msk_gpu_shutdown(msk_ctx *ctx);
 const char *msk_gpu_last_error(const msk_ctx *ctx); /* ctx may be NULL */
 
 /* replaces Scene::accel_init (scene.cpp:201-212): upload geometry, build BVH,
-   area-light tables (mesh.cpp:39-48) */
+   area-light tables (mesh.cpp:39-48).
+   Node boxes are padded by 1e-5 (the D10 triangle bounds by 0.5e-5) of the scene's scale = max(diagonal, largest |coordinate|),
+   so that the slab test never culls what the triangle test accepts.  Measured margin (tests/test_padding_margin.py,
+   test_gpu_trees_equal_brute_force_with_a_tenth_of_the_padding): tree and brute force agree down to 1e-7 of the scale and
+   part at 1e-8 — the rule keeps a factor of ~100.  The environment variable MSK_PAD_SCALE (margin tests only; the oracle
+   reads it too) replaces the 1e-5; a value that is not a number in [1e-7, 1e-3] fails the call with MSK_ERR_INVALID_ARG. */
 int  msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *desc, msk_scene **out_scene);
 void msk_gpu_scene_destroy(msk_scene *scene);
 

@@ -61,6 +61,13 @@ struct Built {
     //   dw 12-15 child refs; an unused slot holds an inverted box (lo = 255, hi = 0) and the reference of an empty leaf
     // Empty (and nodes4 used instead) if a box cannot be quantised conservatively.
     std::vector<uint32_t> nodes4q;
+    // The same nodes with HALF-FLOAT child boxes, 20 dwords (80 B) per node (trace mode 6, MSK_QUANT_BVH=2; round 5):
+    //   dw 0-2 origin (low corner of the node's box), dw 3 scale (ONE power of two: the largest extent / scale lies in [1024, 2048))
+    //   dw 4-5 lo.x, dw 6-7 lo.y, dw 8-9 lo.z, dw 10-11 hi.x, dw 12-13 hi.y, dw 14-15 hi.z: four fp16 each (slot s = half s),
+    //          child box = [origin + lo * scale, origin + hi * scale], rounded OUTWARDS around the padded box of nodes4 (lo down,
+    //          hi up and never a subnormal; checked in exact arithmetic); dw 16-19 child refs; an unused slot holds lo = 65504, hi = 0
+    //          and the reference of an empty leaf.  Empty if a box cannot be represented.
+    std::vector<uint32_t> nodes4h;
     // 8-wide form with QUANTISED child boxes (collapse8): 32 dwords (128 B = one L2 line) per node,
     //   dw 0-2  origin (the low corner of the node's box)      dw 3  meta: bits 0-1 ordering axis, bits 8-15 mask of used slots
     //   dw 4-6  scale (a power of two per axis)                dw 7  -
@@ -85,6 +92,11 @@ struct Builder {
     float pad = 0;
     static constexpr int kBins = 16;
     int kLeaf = 2;              // max triangles per leaf (MSK_BVH_LEAF overrides for experiments)
+    int kSweepLevels = 8;       // the first kSweepLevels levels evaluate EVERY centroid split of the three axes (a full SAH sweep over sorted
+                                // centroids) instead of 16 bins over the centroids' range — which the room's few huge triangles span, so
+                                // that a 146 k-triangle mesh in the middle of it sees three or four of the bins (MSK_BVH_SWEEP overrides;
+                                // round 5: node visits per ray 12.9 -> 10.7 on the config-5-class scene, 8.4 -> 6.7 on config 3's)
+    std::vector<uint32_t> sweep_idx; std::vector<float> sweep_area;
     struct Child { int ref; int count; Box box; };
     std::vector<float> nodes;
     int max_depth = 0;
@@ -124,7 +136,9 @@ struct Builder {
             }
         }
         uint32_t mid;
-        if (best_axis < 0) {
+        if (depth < kSweepLevels && sweep_split(first, count, &mid)) {
+            // order[first .. first + count) is now sorted along the chosen axis and cut at mid
+        } else if (best_axis < 0) {
             mid = first + count / 2;   // all centroids coincide: split in the middle
         } else {
             float lo = axis_of(cb.lo, best_axis), hi = axis_of(cb.hi, best_axis), sc = kBins / (hi - lo);
@@ -143,6 +157,27 @@ struct Builder {
         write_node(me, l, r);
         Child c; c.ref = me; c.count = 0; c.box = l.box; c.box.grow(r.box);
         return c;
+    }
+    // exact SAH over all count - 1 centroid-order splits of the three axes; leaves order[] sorted along the best axis
+    bool sweep_split(uint32_t first, uint32_t count, uint32_t *mid) {
+        int best_axis = -1; uint32_t best_k = 0; float best_cost = INFINITY;
+        sweep_idx.resize(count); sweep_area.resize(count);
+        for (int a = 0; a < 3; ++a) {
+            std::copy(order.begin() + first, order.begin() + first + count, sweep_idx.begin());
+            std::stable_sort(sweep_idx.begin(), sweep_idx.end(), [&](uint32_t x, uint32_t y) { return axis_of(tc[x], a) < axis_of(tc[y], a); });
+            Box acc;
+            for (uint32_t i = count; i-- > 1;) { acc.grow(tb[sweep_idx[i]]); sweep_area[i] = acc.area(); }      // right part [i, count)
+            acc = Box();
+            for (uint32_t k = 1; k < count; ++k) {                                                                // left part [0, k)
+                acc.grow(tb[sweep_idx[k - 1]]);
+                const float cost = acc.area() * k + sweep_area[k] * (count - k);
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_k = k; }
+            }
+        }
+        if (best_axis < 0) return false;
+        std::stable_sort(order.begin() + first, order.begin() + first + count, [&](uint32_t x, uint32_t y) { return axis_of(tc[x], best_axis) < axis_of(tc[y], best_axis); });
+        *mid = first + best_k;
+        return true;
     }
     static uint32_t pack(const Child &c) {
         return c.count > 0 ? (0x80000000u | ((uint32_t) c.ref << 5) | (uint32_t) c.count) : (uint32_t) c.ref;
@@ -167,6 +202,7 @@ static inline Built build(const float *pos, uint32_t n, float tri_pad) {
     Built out;
     Builder b; b.pos = pos; b.n = n;
     if (const char *e = getenv("MSK_BVH_LEAF")) b.kLeaf = std::max(1, std::min(8, atoi(e)));
+    if (const char *e = getenv("MSK_BVH_SWEEP")) b.kSweepLevels = std::max(0, std::min(64, atoi(e)));
     b.tb.resize(n); b.tc.resize(n); b.order.resize(n);
     Box all;
     for (uint32_t i = 0; i < n; ++i) {
@@ -212,8 +248,32 @@ struct Collapser {
     int max_depth = 0;
     std::vector<uint32_t> out_q;        // the quantised twin (Built::nodes4q)
     bool ok_q = true;
+    std::vector<uint32_t> out_h;        // the half-float twin (Built::nodes4h)
+    bool ok_h = true;
+    // v >= 0 as fp16 bits, rounded down or up (never to a subnormal when rounding up: a flushed subnormal would shrink the box)
+    static uint16_t to_half(double v, bool up) {
+        if (!(v > 0.0)) return 0;
+        if (v >= 65504.0) return up && v > 65504.0 ? 0x7c00 : 0x7bff;
+        int e; const double m = std::frexp(v, &e);                       // v = m 2^e, m in [0.5, 1)
+        int he = e - 1 + 15;                                             // biased exponent of 1.f x 2^(e-1)
+        if (he <= 0) {                                                   // below the smallest normal (2^-14)
+            if (up) return 0x0400;
+            const double q = std::floor(v * 16777216.0);                 // subnormal: q 2^-24
+            return (uint16_t) q;
+        }
+        const double f = (m * 2.0 - 1.0) * 1024.0;                       // 10 fraction bits
+        double q = up ? std::ceil(f) : std::floor(f);
+        uint32_t h = ((uint32_t) he << 10) + (uint32_t) q;               // q = 1024 carries into the exponent
+        return (uint16_t) h;
+    }
+    static double from_half(uint16_t h) {
+        const int e = (h >> 10) & 31; const int f = h & 1023;
+        if (e == 31) return INFINITY;
+        return e ? std::ldexp(1.0 + f / 1024.0, e - 15) : std::ldexp((double) f, -24);
+    }
     struct Slot { uint32_t ref; float lo[3], hi[3]; };
     void quantise(uint32_t me, const Slot *s, int ns, const uint32_t *refs);
+    void quantise_h(uint32_t me, const Slot *s, int ns, const uint32_t *refs);
     static float area(const Slot &s) {
         float dx = s.hi[0] - s.lo[0], dy = s.hi[1] - s.lo[1], dz = s.hi[2] - s.lo[2];
         return 2.f * (dx * dy + dy * dz + dz * dx);
@@ -235,15 +295,28 @@ struct Collapser {
     struct Plan { float cost[4]; uint8_t split[4]; uint8_t slots[4]; };    // index i - 1 for "at most i slots": slots = 0: n is one wide node (whose own
                                                                            // four slots are split[0] : 4 - split[0]); else n's children share `slots` slots, split : slots - split
     std::vector<Plan> dp;
-    void plan() {
+    void plan(uint32_t root) {
         const size_t nn = n2.size() / 16;
         dp.assign(nn, Plan{});
         auto cost_of = [&](const Slot &c, int i) {                        // T[c][i] of a child reference
             if (c.ref & 0x80000000u) return 0.f;
             return dp[c.ref].cost[i - 1];
         };
-        for (size_t n = nn; n-- > 0;) {                                    // children have larger indices than their parent (build())
-            Slot l, r; children((uint32_t) n, &l, &r);
+        // children before their parent: a post-order walk from the root (the host builder numbers children above their parent,
+        // the device builder — msk_lbvh.hip, Karras' internal-node indices — does not: an index sweep would read unplanned children)
+        std::vector<uint32_t> order, todo;
+        order.reserve(nn);
+        if (!(root & 0x80000000u)) todo.push_back(root);
+        while (!todo.empty()) {
+            const uint32_t n = todo.back(); todo.pop_back();
+            order.push_back(n);
+            Slot l, r; children(n, &l, &r);
+            if (!(l.ref & 0x80000000u)) todo.push_back(l.ref);
+            if (!(r.ref & 0x80000000u)) todo.push_back(r.ref);
+        }
+        for (size_t k = order.size(); k-- > 0;) {                          // reversed pre-order: every node after its descendants
+            const uint32_t n = order[k];
+            Slot l, r; children(n, &l, &r);
             Plan &p = dp[n];
             float lo[3], hi[3];
             for (int a = 0; a < 3; ++a) { lo[a] = std::min(l.lo[a], r.lo[a]); hi[a] = std::max(l.hi[a], r.hi[a]); }
@@ -251,9 +324,9 @@ struct Collapser {
             float dist[5]; uint8_t dsplit[5] = {0, 0, 0, 0, 0};           // dist[j]: n's two children hung into at most j slots (j >= 2)
             for (int j = 2; j <= 4; ++j) {
                 dist[j] = INFINITY;
-                for (int k = 1; k < j; ++k) {
-                    const float c = cost_of(l, k) + cost_of(r, j - k);
-                    if (c < dist[j]) { dist[j] = c; dsplit[j] = (uint8_t) k; }
+                for (int k2 = 1; k2 < j; ++k2) {
+                    const float c = cost_of(l, k2) + cost_of(r, j - k2);
+                    if (c < dist[j]) { dist[j] = c; dsplit[j] = (uint8_t) k2; }
                 }
             }
             p.cost[0] = area(me) + dist[4]; p.split[0] = dsplit[4]; p.slots[0] = 0;     // one slot: n is a wide node
@@ -304,6 +377,7 @@ struct Collapser {
             }
         std::memcpy(&o[24], refs, 16);
         quantise(me, s, ns, refs);
+        quantise_h(me, s, ns, refs);
         return me;
     }
 };
@@ -337,14 +411,44 @@ inline void Collapser::quantise(uint32_t me, const Slot *s, int ns, const uint32
     for (int a = 0; a < 3; ++a) { q[6 + a] = lo_b[a]; q[9 + a] = hi_b[a]; }
     for (int i = 0; i < 4; ++i) q[12 + i] = refs[i] == kEmpty4 ? 0x80000000u : refs[i];       // empty leaf: first 0, count 0
 }
+inline void Collapser::quantise_h(uint32_t me, const Slot *s, int ns, const uint32_t *refs) {
+    if (out_h.size() < ((size_t) me + 1) * 20) out_h.resize(((size_t) me + 1) * 20, 0u);
+    uint32_t *q = &out_h[(size_t) me * 20];
+    float origin[3]; double ext = 0;
+    for (int a = 0; a < 3; ++a) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int i = 0; i < ns; ++i) { lo = std::min(lo, (double) s[i].lo[a]); hi = std::max(hi, (double) s[i].hi[a]); }
+        origin[a] = (float) lo;
+        ext = std::max(ext, hi - (double) origin[a]);
+    }
+    int e = 0;
+    if (ext > 0) { (void) std::frexp(ext, &e); e -= 11; }               // ext = m 2^e', m in [0.5, 1): ext / 2^(e' - 11) in [1024, 2048)
+    if (e < -120 || e > 120 || !std::isfinite(ext)) { ok_h = false; e = 0; }
+    const float scale = std::ldexp(1.f, e);
+    const double sc = (double) scale;
+    uint16_t h[6][4];
+    for (int a = 0; a < 3; ++a)
+        for (int i = 0; i < 4; ++i) {
+            if (i >= ns) { h[a][i] = 0x7bff; h[3 + a][i] = 0; continue; }                // inverted: lo = 65504, hi = 0
+            const double lo = ((double) s[i].lo[a] - (double) origin[a]) / sc, hi = ((double) s[i].hi[a] - (double) origin[a]) / sc;
+            h[a][i] = to_half(lo, false); h[3 + a][i] = to_half(hi, true);
+            // exact in double (a power-of-two scale): the decoded box must contain the child's
+            if (!((double) origin[a] + from_half(h[a][i]) * sc <= (double) s[i].lo[a] && (double) origin[a] + from_half(h[3 + a][i]) * sc >= (double) s[i].hi[a]) ||
+                h[3 + a][i] >= 0x7c00) ok_h = false;
+        }
+    std::memcpy(&q[0], origin, 12); std::memcpy(&q[3], &scale, 4);
+    for (int p = 0; p < 6; ++p) { q[4 + 2 * p] = (uint32_t) h[p][0] | ((uint32_t) h[p][1] << 16); q[5 + 2 * p] = (uint32_t) h[p][2] | ((uint32_t) h[p][3] << 16); }
+    for (int i = 0; i < 4; ++i) q[16 + i] = refs[i] == kEmpty4 ? 0x80000000u : refs[i];
+}
 static inline void collapse4(Built &b, bool optimal = true) {
-    b.nodes4.clear(); b.nodes4q.clear(); b.root_ref4 = b.root_ref; b.max_depth4 = 0;
+    b.nodes4.clear(); b.nodes4q.clear(); b.nodes4h.clear(); b.root_ref4 = b.root_ref; b.max_depth4 = 0;
     if (b.root_ref & 0x80000000u) return;            // a single leaf: nothing to collapse
     Collapser c{b.nodes, {}, 0};
-    if (optimal) c.plan();
+    if (optimal) c.plan(b.root_ref);
     b.root_ref4 = c.collapse(b.root_ref, 1);
     b.nodes4 = std::move(c.out);
     if (c.ok_q) b.nodes4q = std::move(c.out_q);
+    if (c.ok_h) b.nodes4h = std::move(c.out_h);
     b.max_depth4 = c.max_depth;
 }
 

@@ -363,8 +363,19 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         const float diag = d->n_faces ? std::sqrt(ex * ex + (ey * ey + ez * ez)) : 1.f;
         float amax = 0.f;
         if (d->n_faces) amax = std::max(std::max(std::max(std::fabs(lo[0]), std::fabs(hi[0])), std::max(std::fabs(lo[1]), std::fabs(hi[1]))), std::max(std::fabs(lo[2]), std::fabs(hi[2])));
-        // (MSK_PAD_SCALE, read by the oracle too: the margin tests shrink the padding on both sides to show how far the rule is from failing)
-        const float pad_scale = getenv("MSK_PAD_SCALE") ? (float) atof(getenv("MSK_PAD_SCALE")) : 1e-5f;
+        // (MSK_PAD_SCALE, read by the oracle too: the margin tests shrink the padding on both sides to show how far the rule is from
+        // failing — tree and brute force agree down to 1e-7 of the scale and part at 1e-8, tests/test_padding_margin.py.  A value that
+        // is not a number in [1e-7, 1e-3] is refused: zero, garbage or a stray setting would silently remove the padding on both
+        // sides of the parity tests at once.)
+        float pad_scale = 1e-5f;
+        if (const char *ps = getenv("MSK_PAD_SCALE")) {
+            char *end = nullptr;
+            const double v = strtod(ps, &end);
+            if (end == ps || *end != '\0' || !std::isfinite(v) || v < 1e-7 || v > 1e-3)
+                return fail(ctx, MSK_ERR_INVALID_ARG, "MSK_PAD_SCALE=\"%s\": the padding of the boxes must be a number in [1e-7, 1e-3] of the scene's scale "
+                            "(default 1e-5; the slab arithmetic needs a few 1e-7)", ps);
+            pad_scale = (float) v;
+        }
         tri_pad = (0.5f * pad_scale) * std::max(diag, amax);
     }
     // MSK_BVH_BUILD=gpu: the tree is built on the device (msk_lbvh.hip, a linear BVH) once the vertices are uploaded — the
@@ -487,9 +498,17 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         ds.stack_entries = (uint32_t) ((3 * bvh.max_depth4 + 2 + 3) & ~3);     // up to three pushes per level
         s->trace_mode = 2;
         s->tree_bytes = bvh.nodes4.size() * 4;
-        // the walked form: 64-byte nodes with quantised child boxes (MSK_QUANT_BVH=0: the full-precision 128-byte ones) and
-        // three-load triangle records, packed on the device from `tris`
-        if (env_u32("MSK_QUANT_BVH", 1) && !bvh.nodes4q.empty()) {
+        // the walked form (MSK_QUANT_BVH): 2 (default since round 5) 80-byte nodes with half-float child boxes read by v_fma_mix_f32,
+        // 1 64-byte nodes with byte-quantised boxes (rounds 3-4), 0 the full-precision 128-byte ones; + three-load triangle
+        // records, packed on the device from `tris`.  Config-5 / config-3 class renders (round 5, same box): 124.7 / 159.5 ms
+        // with 2 against 126.9 / 168.3 with 1.
+        if (env_u32("MSK_QUANT_BVH", 2) == 2 && !bvh.nodes4h.empty()) {
+            hipError_t eq = s->nodes4q.upload(bvh.nodes4h);
+            if (eq != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(eq)); }
+            ds.nodes4q = s->nodes4q.as<float4>();
+            s->trace_mode = 6;
+            s->tree_bytes = bvh.nodes4h.size() * 4;
+        } else if (env_u32("MSK_QUANT_BVH", 2) && !bvh.nodes4q.empty()) {
             hipError_t eq = s->nodes4q.upload(bvh.nodes4q);
             if (eq != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(eq)); }
             ds.nodes4q = s->nodes4q.as<float4>();
@@ -515,7 +534,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         s->trace_mode = 3;
     }
     ds.stack_total = ds.stack_entries;
-    if (s->trace_mode == 1 || s->trace_mode == 2 || s->trace_mode == 4 || s->trace_mode == 5) {
+    if (s->trace_mode == 1 || s->trace_mode == 2 || s->trace_mode == 4 || s->trace_mode == 5 || s->trace_mode == 6) {
         // trees in HBM: only the first MSK_STACK_CAP entries of a lane's stack live in LDS, the rest in an HBM overflow
         // array (LaneStack) — any tree depth works within a fixed 16 KB (+ 4 KB of node4_step scratch) of LDS per block, which
         // leaves room for six blocks per CU.  (Measured: the cap does not change the trace time between 8 and 40 entries.)
@@ -662,7 +681,7 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
     // Lane replacement pays when rays are long (tree in HBM/L2: trace -35 % on the 70 k-triangle scene) and costs when they
     // are short (LDS-resident cbox: +50 %): on by default for modes 1 and 2 only.  MSK_TRACE_REFILL=0 turns it off.
     const int refill_env = getenv("MSK_TRACE_REFILL") ? atoi(getenv("MSK_TRACE_REFILL")) : -1;
-    const int max_inner = (int) env_u32("MSK_TRACE_QUANTUM", 4);
+    const int max_inner = (int) env_u32("MSK_TRACE_QUANTUM", 3);       // (4 until round 5's better tree: 10.7 instead of 12.9 node visits per ray)
     const int refill = (sc->trace_mode == 3) ? 0 : refill_env >= 0 ? refill_env : (sc->trace_mode == 0 ? 0 : 16);
     const size_t lds = sc->trace_lds_bytes + (size_t) env_u32("MSK_TRACE_PAD_LDS_KB", 0) * 1024;      // occupancy experiments only
     if (refill > 0) {        // k_trace_r
@@ -670,6 +689,7 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
         else if (sc->trace_mode == 0) hipExtLaunchKernelGGL(k_trace_r<0>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         else if (sc->trace_mode == 1) hipExtLaunchKernelGGL(k_trace_r<1>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         else if (sc->trace_mode == 5) hipExtLaunchKernelGGL(k_trace_r<5>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
+        else if (sc->trace_mode == 6) hipExtLaunchKernelGGL(k_trace_r<6>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         else hipExtLaunchKernelGGL(k_trace_r<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp, refill, max_inner);
         return;
     }
@@ -691,6 +711,7 @@ static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st,
     else if (sc->trace_mode == 2) hipExtLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
     else if (sc->trace_mode == 4) hipExtLaunchKernelGGL(k_trace<4>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
     else if (sc->trace_mode == 5) hipExtLaunchKernelGGL(k_trace<5>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
+    else if (sc->trace_mode == 6) hipExtLaunchKernelGGL(k_trace<6>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
     else hipExtLaunchKernelGGL(k_trace<3>, dim3(grid), dim3(MSK_BLOCK), lds, stream, t0, t1, 0, sc->dev, st, pp);
 }
 
@@ -737,10 +758,13 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     pp0.aov_rgb = aov_rgb;
     pp0.packed = packed ? 1u : 0u;
     pp0.stack_ovf = nullptr;
-    const bool diffuse_only = sc->all_diffuse && !aov_rgb;      // the AOV RGB record lives in the general shading variant
+    // (MSK_FORCE_GENERAL_SHADE=1, measurements only: an all-diffuse scene through the general variant — what a per-class diffuse
+    // instantiation could save a mixed scene's diffuse chunks)
+    const bool force_general = env_u32("MSK_FORCE_GENERAL_SHADE", 0) != 0;
+    const bool diffuse_only = sc->all_diffuse && !aov_rgb && !force_general;      // the AOV RGB record lives in the general shading variant
     // material-sorted shading (general variant): LDS for the permutation, 3 bytes per slot of a region and wave (MSK_SORT=0: off)
     const size_t sort_lds = (size_t) (MSK_BLOCK / MSK_WAVE) * 3 * region_size;
-    const bool sort_on = !diffuse_only && !sc->all_diffuse && region_size <= 4096 && env_u32("MSK_SORT", 1) &&
+    const bool sort_on = !diffuse_only && (!sc->all_diffuse || force_general) && region_size <= 4096 && env_u32("MSK_SORT", 1) &&
                          sc->shade_lds_bytes + sort_lds <= 64 * 1024;
     pp0.sort_scratch = sort_on ? 1u : 0u;
     const size_t shade_lds = sc->shade_lds_bytes + (sort_on ? sort_lds : 0);
@@ -917,6 +941,13 @@ static int check_params(msk_ctx *ctx, const msk_render_params *p, int block_min)
         return fail(ctx, MSK_ERR_INVALID_ARG, "block_size %d outside [%d, 4096]", p->block_size, block_min);
     const uint32_t bs = p->block_stride ? p->block_stride : 1;
     if (p->block_first >= bs) return fail(ctx, MSK_ERR_INVALID_ARG, "shard selector out of range");
+    // MSK_RNG_PCG_BLOCK: a block's samples draw from ONE sequential PCG32 stream (samplers/independent.cpp:9-35), and how far a
+    // sample advances it is only known once its path has been traced: a shard of the sample indices would start the stream at
+    // the same place as every other shard and draw the same numbers (n shards summed = n copies of one spp / n render).  The
+    // blocks' streams are independent: this mode shards by blocks (block_first / block_stride) only.
+    if (p->rng_mode == MSK_RNG_PCG_BLOCK && (p->sample_first != 0 || (p->sample_stride != 0 && p->sample_stride != 1)))
+        return fail(ctx, MSK_ERR_UNSUPPORTED, "MSK_RNG_PCG_BLOCK: the samples of a block share one sequential PCG32 stream and cannot be sharded "
+                    "(sample_first %u, sample_stride %u); shard the blocks with block_first / block_stride", p->sample_first, p->sample_stride);
     return MSK_OK;
 }
 
@@ -931,7 +962,7 @@ static uint32_t owned_spp(const msk_render_params *p) {
 // wants many waves per launch).  Long rays (k_trace_r): 4096 regions of 2048 slots = 8 M, so that lane replacement has a long
 // list of rays to keep the lanes busy with.
 static void pool_shape(const msk_scene *sc, uint64_t total_samples, uint32_t *region_size, uint32_t *n_regions) {
-    const bool big = sc->trace_mode == 1 || sc->trace_mode == 2 || sc->trace_mode == 4 || sc->trace_mode == 5;
+    const bool big = sc->trace_mode == 1 || sc->trace_mode == 2 || sc->trace_mode == 4 || sc->trace_mode == 5 || sc->trace_mode == 6;
     // trees in HBM: one traversal wave per region at 5 waves per SIMD = 5120 resident waves; with 4096 regions the four loops'
     // launches never filled the GPU (8192 regions: config-5-class render 173 vs 191 ms, config-3-class 205 vs 227 ms)
     // LDS-resident scenes: 6144 x 1024 (with the state's cache policy in place — msk_kernels.h, MSK_NT — fewer, longer regions
@@ -1403,6 +1434,9 @@ static int trace_batch(msk_scene *scene, uint64_t n, const float *rays, float *o
                            d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
     else if (scene->trace_mode == 5)
         hipLaunchKernelGGL(k_trace_batch<5>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
+                           d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
+    else if (scene->trace_mode == 6)
+        hipLaunchKernelGGL(k_trace_batch<6>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
                            d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
     else
         hipLaunchKernelGGL(k_trace_batch<3>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,

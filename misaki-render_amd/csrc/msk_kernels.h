@@ -487,6 +487,61 @@ MSK_DEV uint32_t node4q_step(__amdgpu_buffer_rsrc_t rsrc, uint32_t node, const S
     return *(const uint32_t *) (sc4 + (key[0] & 12u));
 }
 
+// The same visit over the HALF-FLOAT twin of the node (Built::nodes4h, 80 bytes, trace mode 6; round 5): the child boxes' planes
+// as fp16 offsets from the node's origin in units of one power-of-two scale, read straight into the slab test's fma by
+// v_fma_mix_f32 (an fp16 operand costs nothing extra: 4.1 SIMD cycles against v_cvt_f32_ubyte + v_fma = 7.0 for a byte plane)
+// — at the price of a fifth 16-byte load per visit and twelve v_bfi instead of six (a plane quadruple is two dwords).  The
+// planes are rounded outwards (lo down, hi up; a non-zero hi never below the smallest normal fp16, so that a flushed
+// subnormal cannot shrink a box) around the padded boxes and checked in exact arithmetic when they are built; eleven bits of
+// mantissa make the boxes tighter than the byte grid's.  Measured: DESIGN.md section 9 row 3, round 5.
+//   q0 = origin.xyz, scale   q1 = lo.x[4], lo.y[4] (two fp16 per dword)   q2 = lo.z[4], hi.x[4]   q3 = hi.y[4], hi.z[4]   q4 = 4 refs
+typedef _Float16 msk_h2 __attribute__((ext_vector_type(2)));
+MSK_DEV float half_lo(uint32_t w) { return (float) __builtin_bit_cast(msk_h2, w)[0]; }
+MSK_DEV float half_hi(uint32_t w) { return (float) __builtin_bit_cast(msk_h2, w)[1]; }
+MSK_DEV __amdgpu_buffer_rsrc_t nodes4h_rsrc(const DeviceScene &sc) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *) sc.nodes4q, 0, sc.n_nodes4 * 80u, 0x00020000);
+}
+template <bool OVF>
+MSK_DEV uint32_t node4h_step(__amdgpu_buffer_rsrc_t rsrc, uint32_t node, const Sel4q &sel, f3 idir, f3 oi, float tmin, float tcur,
+                             const LaneStack<OVF> &stack, int &sp) {
+    const uint32_t base = node * 80u;
+    const msk_u4 h0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base, 0, 0), h1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 16u, 0, 0);
+    const msk_u4 h2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 32u, 0, 0), h3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 48u, 0, 0);
+    const msk_u4 rf = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 64u, 0, 0);
+    *(msk_u4 *) stack.scratch = rf;
+    const float sc_ = __uint_as_float(h0.w);
+    const float ax = sc_ * idir.x, ay = sc_ * idir.y, az = sc_ * idir.z;
+    const float bx = __fmaf_rn(__uint_as_float(h0.x), idir.x, -oi.x), by = __fmaf_rn(__uint_as_float(h0.y), idir.y, -oi.y),
+                bz = __fmaf_rn(__uint_as_float(h0.z), idir.z, -oi.z);
+    // lo.x = h1.xy  lo.y = h1.zw  lo.z = h2.xy  hi.x = h2.zw  hi.y = h3.xy  hi.z = h3.zw
+    const uint32_t nxa = bfi_b32(sel.mx, h2.z, h1.x), nxb = bfi_b32(sel.mx, h2.w, h1.y), fxa = bfi_b32(sel.mx, h1.x, h2.z), fxb = bfi_b32(sel.mx, h1.y, h2.w);
+    const uint32_t nya = bfi_b32(sel.my, h3.x, h1.z), nyb = bfi_b32(sel.my, h3.y, h1.w), fya = bfi_b32(sel.my, h1.z, h3.x), fyb = bfi_b32(sel.my, h1.w, h3.y);
+    const uint32_t nza = bfi_b32(sel.mz, h3.z, h2.x), nzb = bfi_b32(sel.mz, h3.w, h2.y), fza = bfi_b32(sel.mz, h2.x, h3.z), fzb = bfi_b32(sel.mz, h2.y, h3.w);
+    uint32_t key[4];
+#define MSK_CHILD(I, H, NX, NY, NZ, FX, FY, FZ) {                                                                               \
+        const float t0 = fmaxf(fmaxf(fmaxf(__fmaf_rn(H(NX), ax, bx), __fmaf_rn(H(NY), ay, by)), __fmaf_rn(H(NZ), az, bz)), tmin); \
+        const float t1 = fminf(fminf(fminf(__fmaf_rn(H(FX), ax, bx), __fmaf_rn(H(FY), ay, by)), __fmaf_rn(H(FZ), az, bz)), tcur); \
+        const uint32_t miss = (uint32_t) ((int32_t) __float_as_uint(__fmaf_rn(t1, 1.0000004f, -t0)) >> 31);                      \
+        key[I] = ((__float_as_uint(t0) & 0x7ffffff0u) | (uint32_t) ((I) << 2)) | miss; }
+    MSK_CHILD(0, half_lo, nxa, nya, nza, fxa, fya, fza) MSK_CHILD(1, half_hi, nxa, nya, nza, fxa, fya, fza)
+    MSK_CHILD(2, half_lo, nxb, nyb, nzb, fxb, fyb, fzb) MSK_CHILD(3, half_hi, nxb, nyb, nzb, fxb, fyb, fzb)
+#undef MSK_CHILD
+#define MSK_CSWAPU(a, b) { const uint32_t lo_ = a < b ? a : b; b = a < b ? b : a; a = lo_; }
+    MSK_CSWAPU(key[0], key[1]) MSK_CSWAPU(key[2], key[3]) MSK_CSWAPU(key[0], key[2]) MSK_CSWAPU(key[1], key[3]) MSK_CSWAPU(key[1], key[2])
+#undef MSK_CSWAPU
+    const uint32_t NONE = 0xffffffffu;
+    const char *sc4 = (const char *) stack.scratch;
+    if (key[0] == NONE) return sp > 0 ? stack.pop(sp) : NONE;
+    if (key[1] != NONE) {
+        if (key[2] != NONE) {
+            if (key[3] != NONE) stack.push(sp, *(const uint32_t *) (sc4 + (key[3] & 12u)));
+            stack.push(sp, *(const uint32_t *) (sc4 + (key[2] & 12u)));
+        }
+        stack.push(sp, *(const uint32_t *) (sc4 + (key[1] & 12u)));
+    }
+    return *(const uint32_t *) (sc4 + (key[0] & 12u));
+}
+
 // a triangle of a tree in HBM/L2: three loads (DeviceScene::tris3), the normal recomputed with the builder's operations
 // MSK_TRI_REC: what a tree in HBM/L2 reads per triangle test.  0: 48 bytes {v0 | prim, e1 | e2.x, e2.yz}, the normal and the D10
 // bounds recomputed (three loads);  1: 64 bytes with the normal (DeviceScene::tris as the builder wrote it), bounds recomputed;
@@ -603,8 +658,8 @@ MSK_DEV bool traverse4(const float4 *__restrict__ nodes, const float4 *__restric
     return false;
 }
 
-// The 4-wide tree in HBM/L2 (trace modes 2 and 5): node4_step / node4q_step visits, three-load triangles.
-template <bool ANY, bool QUANT>
+// The 4-wide tree in HBM/L2 (trace modes 2, 5 and 6): node4_step / node4q_step / node4h_step visits, three-load triangles.
+template <bool ANY, int MODE>
 MSK_DEV bool traverse4h(const DeviceScene &sc, f3 o, f3 d, float tmin, float tmax, const LaneStack<true> &stack, float *best_t, float *best_u,
                         float *best_v, uint32_t *best_prim) {
     float bt = tmax, bu = 0.f, bv = 0.f;
@@ -613,7 +668,7 @@ MSK_DEV bool traverse4h(const DeviceScene &sc, f3 o, f3 d, float tmin, float tma
     if (sc.n_tris == 0) return false;
     const f3 idir = slab_idir(d);
     const f3 oi = mk3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
-    const __amdgpu_buffer_rsrc_t rn = QUANT ? nodes4q_rsrc(sc) : nodes4_rsrc(sc), rt = tris3_rsrc(sc);
+    const __amdgpu_buffer_rsrc_t rn = MODE == 5 ? nodes4q_rsrc(sc) : MODE == 6 ? nodes4h_rsrc(sc) : nodes4_rsrc(sc), rt = tris3_rsrc(sc);
     const Sel4 sel = make_sel4(idir);
     const Sel4q selq = make_sel4q(idir);
     int sp = 0;
@@ -621,7 +676,8 @@ MSK_DEV bool traverse4h(const DeviceScene &sc, f3 o, f3 d, float tmin, float tma
     const uint32_t DONE = 0xffffffffu;
     while (cur != DONE) {
         while (!(cur & MSK_LEAF_BIT)) {
-            if constexpr (QUANT) cur = node4q_step<true>(rn, cur, selq, idir, oi, tmin, bt, stack, sp);
+            if constexpr (MODE == 5) cur = node4q_step<true>(rn, cur, selq, idir, oi, tmin, bt, stack, sp);
+            else if constexpr (MODE == 6) cur = node4h_step<true>(rn, cur, selq, idir, oi, tmin, bt, stack, sp);
             else cur = node4_step<true>(rn, cur, sel, idir, oi, tmin, bt, stack, sp);
         }
         if (cur == DONE) break;
@@ -770,12 +826,14 @@ MSK_DEV float slot_tmax(float rd_w) {
 #define MSK_HIT_UNOCCLUDED 0x80000000u
 #define MSK_PRIM_MASK 0x7fffffffu
 // MODE 0: binary tree staged in LDS; 1: binary tree in HBM/L2; 2: 4-wide tree in HBM/L2; 3: 4-wide tree staged in LDS;
-// 4: 8-wide tree with quantised boxes in HBM/L2; 5: 4-wide tree with quantised boxes in HBM/L2 (64-byte nodes: the default)
-#define MSK_OVF(MODE) ((MODE) == 1 || (MODE) == 2 || (MODE) == 4 || (MODE) == 5)      /* the stack can overflow to HBM only when the tree lives there */
+// 4: 8-wide tree with quantised boxes in HBM/L2; 5: 4-wide tree with quantised boxes in HBM/L2 (64-byte nodes: the default);
+// 6: 4-wide tree with half-float boxes in HBM/L2 (80-byte nodes, MSK_QUANT_BVH=2)
+#define MSK_WIDE4H(MODE) ((MODE) == 2 || (MODE) == 5 || (MODE) == 6)      /* the 4-wide trees in HBM: node4*_step + three-load triangles */
+#define MSK_OVF(MODE) ((MODE) == 1 || (MODE) == 4 || MSK_WIDE4H(MODE))      /* the stack can overflow to HBM only when the tree lives there */
 template <int MODE, bool ANY>
 MSK_DEV bool traverse_scene(const DeviceScene &sc, const TraceLds &g, f3 o, f3 d, float tmin, float tmax, const LaneStack<MSK_OVF(MODE)> &stack,
                             float *bt, float *bu, float *bv, uint32_t *bp) {
-    if constexpr (MODE == 2 || MODE == 5) return traverse4h<ANY, MODE == 5>(sc, o, d, tmin, tmax, stack, bt, bu, bv, bp);
+    if constexpr (MSK_WIDE4H(MODE)) return traverse4h<ANY, MODE>(sc, o, d, tmin, tmax, stack, bt, bu, bv, bp);
     else if constexpr (MODE == 4) return traverse8<ANY, true>(sc.nodes8, g.tris, sc.tri_pad, sc.root_ref8, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
     else if constexpr (MODE == 3) return traverse4<ANY, false>(g.nodes, g.tris, sc.tri_pad, sc.root_ref4, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
     else return traverse<ANY, MSK_OVF(MODE)>(g.nodes, g.tris, sc.tri_pad, sc.root_ref, sc.n_tris, o, d, tmin, tmax, stack, bt, bu, bv, bp);
@@ -991,7 +1049,8 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
     __amdgpu_buffer_rsrc_t rsrc4, rsrc_t3;
     if constexpr (MODE == 2) rsrc4 = nodes4_rsrc(sc);
     if constexpr (MODE == 5) rsrc4 = nodes4q_rsrc(sc);
-    if constexpr (MODE == 2 || MODE == 5) rsrc_t3 = tris3_rsrc(sc);
+    if constexpr (MODE == 6) rsrc4 = nodes4h_rsrc(sc);
+    if constexpr (MSK_WIDE4H(MODE)) rsrc_t3 = tris3_rsrc(sc);
     while (!(t.cur & MSK_LEAF_BIT) && steps < max_inner) {
         ++steps;
         MSK_CNT_WAVE(3); MSK_CNT(4, 1);
@@ -1002,6 +1061,8 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
             t.cur = node4_step<true>(rsrc4, t.cur, t.sel, t.idir, t.oi, t.tmin, t.bt, stack, t.sp);
         } else if constexpr (MODE == 5) {
             t.cur = node4q_step<true>(rsrc4, t.cur, t.selq, t.idir, t.oi, t.tmin, t.bt, stack, t.sp);
+        } else if constexpr (MODE == 6) {
+            t.cur = node4h_step<true>(rsrc4, t.cur, t.selq, t.idir, t.oi, t.tmin, t.bt, stack, t.sp);
         } else {
             const float4 *n = g.nodes + (size_t) t.cur * 4;
             const float4 a = n[0], b = n[1], c = n[2], m = n[3];
@@ -1033,7 +1094,7 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
             TriRec r;
             bool acc;
             float tt, u, v;
-            if constexpr (MODE == 2 || MODE == 5) {
+            if constexpr (MSK_WIDE4H(MODE)) {
                 load_tri_rec(rsrc_t3, first + i, r);
                 acc = tri_test_rec(r, t.o, t.d, t.tmin, t.tmax, &tt, &u, &v, sc.tri_pad);
             } else {
@@ -1094,9 +1155,9 @@ MSK_DEV void trace_replace(const DeviceScene &sc, const PathState &st, const Pas
                     unocc = 0; active = true;
                     if (shadow_phase) {
                         const float4 s = st.sh[slot];
-                        trav_begin(t, MODE == 4 ? sc.root_ref8 : (MODE == 2 || MODE == 5) ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(s.x, s.y, s.z), ro.w, s.w);
+                        trav_begin(t, MODE == 4 ? sc.root_ref8 : MSK_WIDE4H(MODE) ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(s.x, s.y, s.z), ro.w, s.w);
                     } else {
-                        trav_begin(t, MODE == 4 ? sc.root_ref8 : (MODE == 2 || MODE == 5) ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+                        trav_begin(t, MODE == 4 ? sc.root_ref8 : MSK_WIDE4H(MODE) ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
                     }
                 }
             }
@@ -1112,7 +1173,7 @@ MSK_DEV void trace_replace(const DeviceScene &sc, const PathState &st, const Pas
                 if (shadow_phase) {
                     unocc = occ ? 0u : MSK_HIT_UNOCCLUDED;
                     shadow_phase = false;
-                    trav_begin(t, MODE == 4 ? sc.root_ref8 : (MODE == 2 || MODE == 5) ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+                    trav_begin(t, MODE == 4 ? sc.root_ref8 : MSK_WIDE4H(MODE) ? sc.root_ref4 : sc.root_ref, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
                 } else {
                     const bool valid = (t.bp != MSK_NO_PRIM) && (t.bt != rd.w);
                     st.hit[slot] = make_float4(valid ? t.bt : MSK_INF_F, t.bu, t.bv, __uint_as_float((valid ? t.bp : MSK_PRIM_MASK) | unocc));
@@ -1130,6 +1191,9 @@ k_trace_r(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner
 template <>
 __global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_TRACE_R_WAVES)))
 k_trace_r<5>(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner) { trace_replace<5>(sc, st, pp, refill, max_inner); }
+template <>
+__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_TRACE_R_WAVES)))
+k_trace_r<6>(DeviceScene sc, PathState st, PassParams pp, int refill, int max_inner) { trace_replace<6>(sc, st, pp, refill, max_inner); }
 
 // tris (4 x float4: v0|prim, e1, e2, Ng) -> tris3 (3 x float4: v0|prim, e1|e2.x, e2.y e2.z - -), at scene creation
 __global__ void __launch_bounds__(MSK_BLOCK) k_pack_tris3(const float4 *tris, const float4 *bounds, uint32_t n, float4 *out) {

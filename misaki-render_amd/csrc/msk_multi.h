@@ -100,9 +100,17 @@ static void group_scene_destroy(msk_scene *s) {
     delete s;
 }
 
-// member k's share of the call's samples
+// member k's share of the call: of its sample indices (MSK_RNG_COUNTER: every sample has its own counter key) or of its blocks
+// (MSK_RNG_PCG_BLOCK: a block's samples share one sequential stream, only the blocks' streams are independent — check_params
+// refuses a sample shard of that mode); either composes with a shard the caller asked for
 static msk_render_params group_shard(const msk_render_params &p, uint32_t k, uint32_t n) {
     msk_render_params q = p;
+    if (p.rng_mode == MSK_RNG_PCG_BLOCK) {
+        const uint32_t stride = p.block_stride ? p.block_stride : 1;
+        q.block_first = p.block_first + k * stride;
+        q.block_stride = stride * n;
+        return q;
+    }
     const uint32_t stride = p.sample_stride ? p.sample_stride : 1;
     q.sample_first = p.sample_first + k * stride;
     q.sample_stride = stride * n;

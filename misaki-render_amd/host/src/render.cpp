@@ -963,7 +963,8 @@ public:
         if (!m_ctx && msk_gpu_init(m_devices.data(), (int) m_devices.size(), &m_ctx) != MSK_OK) Throw("{}", msk_gpu_last_error(nullptr));
         msk_scene *gs = nullptr;
         if (msk_gpu_scene_create(m_ctx, &flat.desc, &gs) != MSK_OK) Throw("{}", msk_gpu_last_error(m_ctx));
-        ref<ImageBlock> whole = new ImageBlock(size, channels.size());
+        ref<ImageBlock> whole = new ImageBlock(film->crop_size(), channels.size());   // the crop window, as the storage holds it (as in "path")
+        whole->set_offset(film->crop_offset());
         msk_stats st;
         const int rc = msk_gpu_render_aov(gs, &flat.params, m_types.data(), (uint32_t) m_types.size(), whole->data().data(), &st);
         msk_gpu_scene_destroy(gs);

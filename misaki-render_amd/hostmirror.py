@@ -34,52 +34,140 @@ def cie_tables():
 
 
 # ----------------------------------------------------------------------------- filter
-def gaussian_filter(stddev=0.5):
-    """GaussianFilter ctor + ReconstructionFilter::init_discretization in fp32.
+# ONE flattener truth (round 5): this module and the C++ host library (host/src/render.cpp, core.cpp) produce the same bits for
+# the camera matrices and the filter table — tests/test_host_library.py holds them to np.array_equal at three film sizes.  What
+# they share is the arithmetic, restated here operation for operation: the filter in fp32 with the C library's expf (numpy's
+# own vectorised exp differs from it in the last place), the transforms in fp64 — Transform4f keeps a matrix and its inverse,
+# products multiply both, inverse() swaps them, one rounding to fp32 at the end — which is NOT the reference's arithmetic
+# to the bit: that is Eigen's fp32 4x4 product and its SSE cofactor inverse (transform.h:87-187), not reproducible without Eigen;
+# the fp64 path is what those fp32 results approximate, and both of this repository's hosts now round it the same way.
+_libm = C.CDLL("libm.so.6")
+_libm.expf.restype, _libm.expf.argtypes = C.c_float, [C.c_float]
 
-    Returns (radius, lut[33]).  gaussian.cpp:10-20, rfilter.cpp:12-27.
-    """
+
+def _expf(x):
+    return np.float32(_libm.expf(C.c_float(float(x))))
+
+
+def gaussian_filter(stddev=0.5):
+    """GaussianFilter ctor + ReconstructionFilter::init_discretization in fp32 (gaussian.cpp:10-20, rfilter.cpp:12-27), with the
+    operations and the expf of host/src/render.cpp.  Returns (radius, lut[33])."""
     f = np.float32
+    n = abi.MSK_FILTER_RESOLUTION
     stddev = f(stddev)
-    radius = f(4) * stddev
-    alpha = f(-1.0) / (f(2.0) * stddev * stddev)
-    bias = np.exp(alpha * radius * radius, dtype=np.float32)
-    vals = np.zeros(abi.MSK_FILTER_RESOLUTION + 1, np.float32)
+    radius = f(f(4) * stddev)
+    alpha = f(f(-1.0) / f(f(f(2.0) * stddev) * stddev))
+    bias = _expf(f(f(alpha * radius) * radius))
+    vals = np.zeros(n + 1, np.float32)
     s = f(0)
-    for i in range(abi.MSK_FILTER_RESOLUTION):
-        x = f(radius * f(i)) / f(abi.MSK_FILTER_RESOLUTION)
-        vals[i] = max(f(0), np.exp(alpha * x * x, dtype=np.float32) - bias)
+    for i in range(n):
+        x = f(f(radius * f(i)) / f(n))
+        vals[i] = max(f(0), f(_expf(f(f(alpha * x) * x)) - bias))
         s = f(s + vals[i])
-    s = f(s * (f(2) * radius / f(abi.MSK_FILTER_RESOLUTION)))
-    norm = f(1.0) / s
-    vals[:abi.MSK_FILTER_RESOLUTION] *= norm
+    s = f(s * f(f(f(2) * radius) / f(n)))
+    norm = f(f(1.0) / s)
+    for i in range(n):
+        vals[i] = f(vals[i] * norm)
     return float(radius), vals
 
 
 # ----------------------------------------------------------------------------- camera
+class _T4:
+    """Transform4f of the C++ host (core.h:64-80, core.cpp:80-175): a 4x4 matrix and its inverse in fp64."""
+
+    def __init__(self, m, inv=None):
+        self.m = [list(map(float, r)) for r in m]
+        self.inv = [list(map(float, r)) for r in inv] if inv is not None else _T4._inverse(self.m)
+
+    @staticmethod
+    def _mul(a, b):                      # Matrix4f::operator*: sum over k = 0..3, left to right, from 0
+        out = [[0.0] * 4 for _ in range(4)]
+        for i in range(4):
+            for j in range(4):
+                acc = 0.0
+                for k in range(4):
+                    acc += a[i][k] * b[k][j]
+                out[i][j] = acc
+        return out
+
+    @staticmethod
+    def _inverse(m):                     # Matrix4f::inverse: Gauss-Jordan with partial pivoting
+        a = [list(m[i]) + [1.0 if i == j else 0.0 for j in range(4)] for i in range(4)]
+        for c in range(4):
+            p = c
+            for r in range(c + 1, 4):
+                if abs(a[r][c]) > abs(a[p][c]):
+                    p = r
+            if a[p][c] == 0.0:
+                return [[float("nan")] * 4 for _ in range(4)]
+            if p != c:
+                a[p], a[c] = a[c], a[p]
+            inv = 1.0 / a[c][c]
+            for j in range(8):
+                a[c][j] *= inv
+            for r in range(4):
+                if r != c:
+                    fct = a[r][c]
+                    if fct != 0.0:
+                        for j in range(8):
+                            a[r][j] -= fct * a[c][j]
+        return [a[i][4:] for i in range(4)]
+
+    def __mul__(self, t):
+        return _T4(_T4._mul(self.m, t.m), _T4._mul(t.inv, self.inv))
+
+    def inverse(self):
+        return _T4(self.inv, self.m)
+
+    def to_float16(self, inverse=False):
+        return np.array(self.inv if inverse else self.m, np.float64).astype(np.float32).reshape(16)
+
+    @staticmethod
+    def scale(v):
+        v = [float(np.float32(x)) for x in v]
+        return _T4([[v[0], 0, 0, 0], [0, v[1], 0, 0], [0, 0, v[2], 0], [0, 0, 0, 1]],
+                   [[1.0 / v[0], 0, 0, 0], [0, 1.0 / v[1], 0, 0], [0, 0, 1.0 / v[2], 0], [0, 0, 0, 1]])
+
+    @staticmethod
+    def translate(v):
+        v = [float(np.float32(x)) for x in v]
+        return _T4([[1, 0, 0, v[0]], [0, 1, 0, v[1]], [0, 0, 1, v[2]], [0, 0, 0, 1]],
+                   [[1, 0, 0, -v[0]], [0, 1, 0, -v[1]], [0, 0, 1, -v[2]], [0, 0, 0, 1]])
+
+    @staticmethod
+    def perspective(fov, near, far):
+        fov, near, far = np.float32(fov), float(np.float32(near)), float(np.float32(far))
+        recip = 1.0 / (far - near)
+        cot = 1.0 / math.tan(float(fov / np.float32(2.0)) * (math.pi / 180.0))
+        return _T4([[cot, 0, 0, 0], [0, cot, 0, 0], [0, 0, far * recip, -near * far * recip], [0, 0, 1, 0]])
+
+    @staticmethod
+    def lookat(origin, target, up):
+        o, t, u = ([float(np.float32(x)) for x in v] for v in (origin, target, up))
+
+        def nrm(v):
+            l = math.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+            return [v[0] / l, v[1] / l, v[2] / l]
+
+        def crs(a, b):
+            return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
+        d = nrm([t[0] - o[0], t[1] - o[1], t[2] - o[2]])
+        left = nrm(crs(nrm(u), d))
+        nup = nrm(crs(d, left))
+        return _T4([[left[r], nup[r], d[r], o[r]] for r in range(3)] + [[0, 0, 0, 1]])
+
+
 def perspective_camera(fov, near, far, width, height, origin, target, up):
     """-> (sample_to_camera[16], to_world[16]) row-major float32; sample space is in pixels.
 
-    perspective.cpp:11-19: camera_to_sample = S(w,h,1) S(-.5,-.5a,1) T(-1,-1/a,0) P(fov,near,far);
-    the inverse is formed analytically in float64 and rounded once.
+    perspective.cpp:11-19: camera_to_sample = S(w,h,1) S(-.5,-.5a,1) T(-1,-1/a,0) P(fov,near,far), sample_to_camera its inverse;
+    to_world = lookat (transform.h:169-178).  The C++ host's arithmetic (see the note above gaussian_filter), bit for bit.
     """
-    aspect = width / float(height)
-    recip = 1.0 / (float(far) - float(near))
-    cot = 1.0 / math.tan(math.radians(float(np.float32(fov) / np.float32(2.0))))
-    A, B = far * recip, -near * far * recip
-    p_inv = np.array([[1 / cot, 0, 0, 0], [0, 1 / cot, 0, 0], [0, 0, 0, 1], [0, 0, 1 / B, -A / B]], np.float64)
-    sx, sy = 1.0 / width / -0.5, 1.0 / height / (-0.5 * aspect)
-    m = np.array([[sx, 0, 0, 1], [0, sy, 0, 1 / aspect], [0, 0, 1, 0], [0, 0, 0, 1]], np.float64)
-    s2c = (p_inv @ m).astype(np.float32)
-    o, t, u = (np.asarray(v, np.float64) for v in (origin, target, up))
-    d = (t - o) / np.linalg.norm(t - o)
-    left = np.cross(u / np.linalg.norm(u), d)
-    left /= np.linalg.norm(left)
-    new_up = np.cross(d, left)
-    new_up /= np.linalg.norm(new_up)
-    tw = np.eye(4)
-    tw[:3, 0], tw[:3, 1], tw[:3, 2], tw[:3, 3] = left, new_up, d, np.asarray(origin, np.float32)
-    return s2c.reshape(16), tw.astype(np.float32).reshape(16)
+    f = np.float32
+    aspect = f(f(width) / f(height))                 # sensor.cpp: size.x / (float) size.y
+    c2s = _T4.scale((f(width), f(height), f(1))) * _T4.scale((f(-0.5), f(f(-0.5) * aspect), f(1))) * \
+        _T4.translate((f(-1), f(f(-1) / aspect), f(0))) * _T4.perspective(fov, near, far)
+    return c2s.inverse().to_float16(), _T4.lookat(origin, target, up).to_float16()
 
 
 # ----------------------------------------------------------------------------- meshes
@@ -464,10 +552,12 @@ def bunny_class_scene(size, res=187):
     return flatten(cbox_meshes()[:6] + [blob], size, size)
 
 
-def teapot_class_scene(size, res=270):
-    """Config-5 class: ~146 k-triangle rough-dielectric mesh, room + luminaire, no boxes."""
+def teapot_class_scene(size, res=270, diffuse=False):
+    """Config-5 class: ~146 k-triangle rough-dielectric mesh, room + luminaire, no boxes (diffuse=True: the same geometry,
+    white diffuse — measurements of the shading variants on one scene)."""
     blob = blob_mesh("teapot_class", (278, 200, 280), 160, res, res, WHITE, seed=7, bump=0.25)
-    blob.bsdf = {"type": "roughdielectric", "alpha": 0.1, "int_ior": 1.5, "ext_ior": 1.0}
+    if not diffuse:
+        blob.bsdf = {"type": "roughdielectric", "alpha": 0.1, "int_ior": 1.5, "ext_ior": 1.0}
     return flatten(cbox_meshes()[:6] + [blob], size, size)
 
 

@@ -62,6 +62,44 @@ int main(int argc, char **argv) {
             if (A > 0) { area_ratio += Aq / A; ++children; }
         }
     }
-    printf("ok nodes %zu children %zu unused_slots %zu mean_area_ratio %.5f depth4 %d\n", nn, children, empty, children ? area_ratio / children : 1.0, b.max_depth4);
+    // ---- the half-float twin (Built::nodes4h, 80-byte nodes): same containment, decoded here independently of the builder
+    auto half = [](uint32_t h) -> double {
+        const int e = (h >> 10) & 31, f = h & 1023;
+        if (e == 31) return f ? NAN : INFINITY;
+        return e ? std::ldexp(1024.0 + f, e - 25) : std::ldexp((double) f, -24);
+    };
+    if (b.nodes4h.size() != nn * 20) { printf("FAIL nodes4h has %zu dwords for %zu nodes\n", b.nodes4h.size(), nn); return 1; }
+    double area_ratio_h = 0; size_t children_h = 0;
+    for (size_t m = 0; m < nn; ++m) {
+        const float *f = &b.nodes4[m * 32];
+        const uint32_t *q = &b.nodes4h[m * 20];
+        float origin[3], scale;
+        memcpy(origin, q, 12); memcpy(&scale, &q[3], 4);
+        int ex; if (!(scale > 0.f) || !std::isfinite(scale) || std::frexp(scale, &ex) != 0.5f) { printf("FAIL node %zu: half scale %g is not a power of two\n", m, scale); return 1; }
+        uint32_t refs[4]; memcpy(refs, &f[24], 16);
+        for (int i = 0; i < 4; ++i) {
+            double e[3], eq[3];
+            for (int a = 0; a < 3; ++a) {
+                const uint32_t wl = q[4 + 2 * a + i / 2], wh = q[10 + 2 * a + i / 2];
+                const uint32_t hl = (wl >> (16 * (i & 1))) & 0xffffu, hh = (wh >> (16 * (i & 1))) & 0xffffu;
+                if (refs[i] == mskbvh::kEmpty4) {
+                    if (!(hl == 0x7bffu && hh == 0u) || q[16 + i] != 0x80000000u) { printf("FAIL node %zu slot %d: unused half slot not inverted / not an empty leaf\n", m, i); return 1; }
+                    continue;
+                }
+                if (hh != 0 && hh < 0x0400u) { printf("FAIL node %zu child %d axis %d: subnormal upper plane\n", m, i, a); return 1; }
+                const double lo = f[a * 4 + i], hi = f[12 + a * 4 + i];
+                const double dlo = (double) origin[a] + half(hl) * (double) scale, dhi = (double) origin[a] + half(hh) * (double) scale;
+                if (!(dlo <= lo && dhi >= hi) || !std::isfinite(dhi)) { printf("FAIL node %zu child %d axis %d: half box [%.9g, %.9g] does not contain [%.9g, %.9g]\n", m, i, a, dlo, dhi, lo, hi); return 1; }
+                // eleven bits: the slack is at most 2^-10 of the plane's own offset (or the smallest normal)
+                if (dlo < lo - ((lo - origin[a]) / 1024.0 + 1e-30) || dhi > hi + std::max((hi - origin[a]) / 1024.0, 6.2e-5 * (double) scale)) { printf("FAIL node %zu child %d axis %d: half box too loose\n", m, i, a); return 1; }
+                e[a] = hi - lo; eq[a] = dhi - dlo;
+            }
+            if (refs[i] == mskbvh::kEmpty4) continue;
+            if (q[16 + i] != refs[i]) { printf("FAIL node %zu child %d: half reference differs\n", m, i); return 1; }
+            const double A = e[0] * e[1] + e[1] * e[2] + e[2] * e[0], Aq = eq[0] * eq[1] + eq[1] * eq[2] + eq[2] * eq[0];
+            if (A > 0) { area_ratio_h += Aq / A; ++children_h; }
+        }
+    }
+    printf("ok half_area_ratio %.5f nodes %zu children %zu unused_slots %zu mean_area_ratio %.5f depth4 %d\n", children_h ? area_ratio_h / children_h : 1.0, nn, children, empty, children ? area_ratio / children : 1.0, b.max_depth4);
     return 0;
 }

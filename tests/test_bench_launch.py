@@ -16,6 +16,15 @@ def _last_json(out):
     return json.loads(lines[0])
 
 
+def _scalar_config(d):
+    """The driver's parser keeps only the scalar values of `config` (round 4's record lost `config.other`, a nested dict):
+    everything under `config` is a scalar, `workload` fits 120 characters and names the timer's scope."""
+    for k, v in d["config"].items():
+        assert v is None or isinstance(v, (str, int, float, bool)), (k, v)
+    assert len(d["config"]["workload"]) <= 120
+    return True
+
+
 def _env():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env["MASTER_ADDR"] = "127.0.0.1"
@@ -30,7 +39,11 @@ def test_bare_shell_gpus_2_spawns_two_ranks():
     assert d["n_gpus"] == 2 and d["dry_run"] and d["reduce_ok"] and d["steps"] == 2 and d["warmup"] == 1
     assert d["config"]["samples_per_step"] == 512 * 512 * 512 * 2          # weak scaling: 512 spp per rank
     # the equal sample-stride split is the default (--balance is opt-in); the line says how many ranks met and what the node showed
-    assert d["config"]["balance"] is None and d["config"]["rccl_ranks"] == 2 and isinstance(d["config"]["devices_seen"], int)
+    assert d["balance"] is None and d["config"]["balanced"] is False and d["config"]["rccl_ranks"] == 2 and isinstance(d["config"]["devices_seen"], int)
+    assert d["config"]["shard"] == "samples" and _scalar_config(d)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0", "--shard", "tiles"],
+                       capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode == 0 and _last_json(r.stdout)["config"]["shard"] == "tiles", r.stderr[-2000:]
 
 
 def test_under_torch_distributed_run():
@@ -92,21 +105,29 @@ def test_two_ranks_rehearsed_on_one_gpu():
     speed-proportional re-split after the warm-up), the film summed onto rank 0 (gloo through host copies here, RCCL on a real
     node) and copied to the host — checked against one rank rendering all the samples."""
     common = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs"]
-    for extra in ([], ["--balance"]):
+    for extra in ([], ["--balance"], ["--shard", "tiles"]):
         r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--spp", "8"] + common + extra,
                             capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
         assert r2.returncode == 0, r2.stderr[-2000:]
         d2 = _last_json(r2.stdout)
         assert d2["n_gpus"] == 2 and d2["rehearsal"] and d2["film_finite"] and d2["value"] > 0
         assert d2["config"]["samples_per_step"] == 512 * 512 * 16 and d2["config"]["rccl_ranks"] == 2
+        assert _scalar_config(d2) and d2["timing_scope"] == d2["config"]["timing_scope"] == "incl_copyback" and "copy-back" in d2["config"]["workload"]
+        assert d2["config"]["shard"] == ("tiles" if "tiles" in extra else "samples")
         if not extra:
-            assert d2["config"]["balance"] is None
+            assert d2["balance"] is None and d2["config"]["balanced"] is False
+        if "--balance" in extra:
+            assert d2["config"]["balanced"] == (d2["balance"] is not None)
+        if "tiles" in extra:
+            d_tiles = d2
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rehearse-on-one-gpu", "--spp", "16"] + common,
                         capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
     assert r1.returncode == 0, r1.stderr[-2000:]
     d1 = _last_json(r1.stdout)
     # the same 16 samples per pixel either way: the filter-weight sums agree up to the re-association of two partial sums
     assert abs(d2["film_weight_sum"] - d1["film_weight_sum"]) <= 1e-5 * abs(d1["film_weight_sum"])
+    assert abs(d_tiles["film_weight_sum"] - d1["film_weight_sum"]) <= 1e-5 * abs(d1["film_weight_sum"])
+    assert _scalar_config(d1) and d1["config"]["shard"] == "none"
 
 
 @pytest.mark.gpu
@@ -119,7 +140,7 @@ def test_in_process_group_rehearsed_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["rehearsal"] and d["film_finite"] and d["config"]["in_process_members"] == 2
-    assert d["config"]["samples_per_step"] == 512 * 512 * 16 and "k_film_sum" in d["config"]["parallelism"]
+    assert d["config"]["samples_per_step"] == 512 * 512 * 16 and "k_film_sum" in d["config"]["parallelism"] and _scalar_config(d)
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rehearse-on-one-gpu", "--spp", "16"] + common[:-2],
                         capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
     d1 = _last_json(r1.stdout)

@@ -23,3 +23,6 @@ def test_quantised_nodes_contain_the_padded_boxes(checker, n, seed, scale):
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
     ratio = float(r.stdout.split("mean_area_ratio")[1].split()[0])
     assert 1.0 <= ratio < 1.3, r.stdout        # (1.05 ... 1.22: the smallest soup, whose few nodes mix sizes two decades apart)
+    # the half-float twin (80-byte nodes, trace mode 6): contained as well, and tighter than the byte grid
+    ratio_h = float(r.stdout.split("half_area_ratio")[1].split()[0])
+    assert 1.0 <= ratio_h <= ratio and ratio_h < 1.02, r.stdout

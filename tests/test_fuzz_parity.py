@@ -148,3 +148,14 @@ def test_gpu_trees_equal_brute_force_with_a_tenth_of_the_padding(gpu_ctx, oracle
         assert np.array_equal(g.trace_any(rays), o.trace_any(rays)), (s, offset)
         g.close()
         o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bad", ["0", "abc", "-1e-5", "nan", "1", "1e-9", ""])
+def test_a_padding_knob_that_is_not_a_sane_number_is_refused(gpu_ctx, abi, hostmirror, golden_lookup, monkeypatch, bad):
+    """MSK_PAD_SCALE is honoured for the margin tests only within [1e-7, 1e-3]: zero, garbage or a stray value would silently take
+    the padding out of the GPU library AND the oracle at once — the parity tests would still pass (round 4's advisor finding)."""
+    monkeypatch.setenv("MSK_PAD_SCALE", bad)
+    with pytest.raises(abi.MskError) as e:
+        abi.Scene(gpu_ctx, hostmirror.cbox_scene(16, 16, coeff_lookup=golden_lookup))
+    assert e.value.code == abi.MSK_ERR_INVALID_ARG and "MSK_PAD_SCALE" in str(e.value)

@@ -224,14 +224,17 @@ def test_large_mesh_uses_hbm_bvh(gpu_ctx, abi, hostmirror, oracle, golden_lookup
                                  dict(MSK_WIDE_LDS="1", MSK_TRACE_REFILL="0"),
                                  dict(MSK_QUANT_BVH="0"), dict(MSK_QUANT_BVH="0", MSK_TRACE_REFILL="0"), dict(MSK_QUANT_BVH="0", MSK_STACK_CAP="4"),
                                  dict(MSK_BVH_BUILD="gpu", MSK_QUANT_BVH="0"),
+                                 dict(MSK_QUANT_BVH="1"), dict(MSK_QUANT_BVH="1", MSK_TRACE_REFILL="0"), dict(MSK_QUANT_BVH="1", MSK_BVH_BUILD="gpu", MSK_STACK_CAP="4"),
+                                 dict(MSK_QUANT_BVH="1", MSK_TRACE_QUANTUM="4", MSK_BVH_SWEEP="0"), dict(MSK_BVH_SWEEP="0"), dict(MSK_BVH_SWEEP="64", MSK_WIDE_BVH="0"),
                                  dict(MSK_WIDE_BVH="8"), dict(MSK_WIDE_BVH="8", MSK_TRACE_REFILL="0"),
                                  dict(MSK_WIDE_BVH="8", MSK_STACK_CAP="4", MSK_TRACE_QUANTUM="2"),
                                  dict(MSK_BVH_BUILD="gpu"), dict(MSK_BVH_BUILD="gpu", MSK_WIDE_BVH="0", MSK_STACK_CAP="4"),
                                  dict(MSK_BVH_BUILD="gpu", MSK_WIDE_BVH="8"), dict(MSK_BVH_BUILD="gpu", MSK_BVH_LEAF="1", MSK_TRACE_REFILL="0")])
 def test_every_traversal_kernel_gives_the_same_film(gpu_ctx, abi, hostmirror, oracle, golden_lookup, monkeypatch, env):
-    """k_trace<0|1|2|4|5> (chunk loop) and k_trace_r<0|1|2|4|5> (lane replacement), binary, 4-wide (64-byte quantised nodes: the
-    default for trees in HBM; MSK_QUANT_BVH=0: the full-precision 128-byte ones) and 8-wide quantised trees, built
-    by the host's binned-SAH builder or on the device (MSK_BVH_BUILD=gpu, msk_lbvh.hip): hit selection is by (t, prim), so
+    """k_trace<0|1|2|4|5|6> (chunk loop) and k_trace_r<0|1|2|4|5|6> (lane replacement), binary, 4-wide (80-byte nodes with half-float
+    boxes read by v_fma_mix_f32: the default for trees in HBM since round 5; MSK_QUANT_BVH=1: rounds 3-4's 64-byte byte-quantised
+    nodes; MSK_QUANT_BVH=0: the full-precision 128-byte ones) and 8-wide quantised trees, built by the host's SAH builder (a full
+    sweep on the first MSK_BVH_SWEEP levels, 16 bins below) or on the device (MSK_BVH_BUILD=gpu, msk_lbvh.hip): hit selection is by (t, prim), so
     every one of them must reproduce the oracle's film bit for bit."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)

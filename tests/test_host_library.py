@@ -33,14 +33,15 @@ def test_load_and_flatten_matches_the_python_mirror(hostlib, hostmirror, cbox_xm
     assert [(d.meshes[i].emitter_id, d.meshes[i].first_face, d.meshes[i].face_count) for i in range(8)] == \
            [(r.meshes[i].emitter_id, r.meshes[i].first_face, r.meshes[i].face_count) for i in range(8)]
     assert d.emitters[0].d65_scale == r.emitters[0].d65_scale and d.emitters[0].mesh_id == 0
-    assert np.allclose(d.camera.sample_to_camera[:], r.camera.sample_to_camera[:], rtol=2e-6, atol=1e-9)
-    assert np.allclose(d.camera.to_world[:], r.camera.to_world[:], rtol=1e-6, atol=1e-9)
+    # one flattener truth: camera, filter table and spectral coefficients are the mirror's, bit for bit (more sizes below)
+    assert np.array_equal(np.array(d.camera.sample_to_camera[:], np.float32).view(np.uint32), np.array(r.camera.sample_to_camera[:], np.float32).view(np.uint32))
+    assert np.array_equal(np.array(d.camera.to_world[:], np.float32).view(np.uint32), np.array(r.camera.to_world[:], np.float32).view(np.uint32))
     assert d.camera.near_clip == 10.0 and d.camera.far_clip == 2800.0
-    assert d.film.filter_radius == 2.0 and np.allclose(d.film.filter_lut[:], r.film.filter_lut[:], rtol=3e-7, atol=1e-9)
+    assert d.film.filter_radius == 2.0 and np.array_equal(np.array(d.film.filter_lut[:], np.float32).view(np.uint32), np.array(r.film.filter_lut[:], np.float32).view(np.uint32))
     assert np.array_equal(np.ctypeslib.as_array(d.cie1931_xyz, (285,)), np.ctypeslib.as_array(r.cie1931_xyz, (285,)))
-    # spectral upsampling: the C++ solver and the Python solver agree
     for i in range(8):
-        assert np.allclose(d.bsdfs[i].reflectance[:], r.bsdfs[i].reflectance[:], rtol=2e-4, atol=2e-6)
+        assert np.array_equal(np.array(d.bsdfs[i].reflectance[:], np.float32).view(np.uint32), np.array(r.bsdfs[i].reflectance[:], np.float32).view(np.uint32))
+    assert np.array_equal(np.array(d.emitters[0].radiance[:], np.float32).view(np.uint32), np.array(r.emitters[0].radiance[:], np.float32).view(np.uint32))
     # render parameters = the reference's effective integrator settings
     p = flat.params
     assert (p.spp, p.rng_mode, p.rr_depth, p.max_depth, p.hide_emitters, p.block_size) == (4, 1, 5, -1, 0, 32)
@@ -49,6 +50,35 @@ def test_load_and_flatten_matches_the_python_mirror(hostlib, hostmirror, cbox_xm
     film, st = osc.render(p, threads=2)
     assert st.samples == 64 * 48 * 4 and np.isfinite(film).all() and film[..., 4].min() > 0
     osc.close()
+    sc.close()
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (800, 600), (1920, 1080), (100, 40), (512, 512)])
+def test_the_two_flatteners_produce_the_same_bits(hostlib, hostmirror, tmp_path, w, h):
+    """ONE flattener truth at the boundary: the C++ host (XML -> plugins -> flatten: what the drop-in hands to the C ABI) and the
+    python mirror (what the parity suite and bench.py build their scenes with) give bit-identical camera matrices — also at
+    aspect ratios != 1, where round 4's two arithmetics parted in the last place —, filter tables, spectral coefficients,
+    geometry and tables, so a film rendered through either is the same film."""
+    xml = hostmirror.write_scene_xml(hostmirror.cbox_meshes(), str(tmp_path), w, h, 4)
+    sc = hostlib.HostScene(xml)
+    flat, ref = sc.flatten(), hostmirror.cbox_scene(w, h)
+    d, r = flat.desc, ref.desc
+    bits = lambda a: np.array(a[:], np.float32).view(np.uint32)
+    assert np.array_equal(bits(d.camera.sample_to_camera), bits(r.camera.sample_to_camera))
+    assert np.array_equal(bits(d.camera.to_world), bits(r.camera.to_world))
+    assert (d.camera.near_clip, d.camera.far_clip) == (r.camera.near_clip, r.camera.far_clip)
+    assert d.film.filter_radius == r.film.filter_radius and np.array_equal(bits(d.film.filter_lut), bits(r.film.filter_lut))
+    assert (d.film.width, d.film.height) == (r.film.width, r.film.height) == (w, h)
+    assert np.array_equal(flat.vertices.view(np.uint32), ref.vertices.view(np.uint32)) and np.array_equal(flat.faces, ref.faces)
+    assert d.n_bsdfs == r.n_bsdfs and d.n_emitters == r.n_emitters
+    for i in range(d.n_bsdfs):
+        assert np.array_equal(bits(d.bsdfs[i].reflectance), bits(r.bsdfs[i].reflectance)), i
+        assert bytes(d.bsdfs[i]) == bytes(r.bsdfs[i]), i
+    for i in range(d.n_emitters):
+        assert bytes(d.emitters[i]) == bytes(r.emitters[i]), i
+    assert bytes(d.camera) == bytes(r.camera)
+    # (the film's crop window: the plugin always writes it out, the mirror leaves {0, 0} = the whole film: the same window)
+    assert tuple(d.film.crop_offset) == (0, 0) and tuple(d.film.crop_size) == (w, h) and tuple(r.film.crop_size) in ((0, 0), (w, h))
     sc.close()
 
 

@@ -41,8 +41,13 @@ def test_integrator_properties_shards_crop_and_ragged_blocks(gpu_ctx, abi, hostm
     g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
     for kw in (dict(spp=5, seed=3), dict(spp=3, rr_depth=1), dict(spp=3, rr_depth=2, max_depth=3), dict(spp=2, max_depth=1), dict(spp=2, hide_emitters=1),
                dict(spp=3, block_size=16), dict(spp=2, block_size=200), dict(spp=3, block_first=1, block_stride=3),
-               dict(spp=6, sample_first=1, sample_stride=2), dict(spp=5, sample_first=2, sample_stride=1)):
+               dict(spp=4, block_size=16, block_first=2, block_stride=5)):
         _same(abi, g, o, **kw)
+    # a shard of the SAMPLE indices is refused: a block's samples share one sequential stream (every shard would draw the same numbers)
+    for kw in (dict(spp=6, sample_first=1, sample_stride=2), dict(spp=5, sample_first=2, sample_stride=1)):
+        with pytest.raises(abi.MskError) as e:
+            g.render(abi.render_params(rng_mode=abi.MSK_RNG_PCG_BLOCK, **kw))
+        assert e.value.code == abi.MSK_ERR_UNSUPPORTED and "block_first" in str(e.value)
     g.close()
     o.close()
     crop = hostmirror.cbox_scene(100, 40, coeff_lookup=golden_lookup, crop=(11, 5, 37, 21))
@@ -89,3 +94,31 @@ def test_what_the_mode_does_not_cover(gpu_ctx, abi, hostmirror, golden_lookup):
         g.render(abi.render_params(spp=2, rng_mode=7))
     assert e.value.code == abi.MSK_ERR_INVALID_ARG
     g.close()
+
+
+def test_a_group_context_shards_this_mode_by_blocks(abi, hostmirror, oracle, golden_lookup):
+    """msk_gpu_init(ids = {0, 0}) + MSK_RNG_PCG_BLOCK: the members take every other spiral block (their streams are independent),
+    not every other sample (which would draw the same numbers twice: round 4's advisor finding).  The summed film is the
+    unsharded one: bit for bit wherever one block contributes, re-associated sums of at most four terms on the block borders;
+    a caller's own block shard composes with the members'."""
+    flat = hostmirror.cbox_scene(96, 64, coeff_lookup=golden_lookup)
+    prm = abi.render_params(spp=3, seed=2, rng_mode=abi.MSK_RNG_PCG_BLOCK)
+    o = oracle.scene(flat)
+    ref, rst = o.render(prm, threads=8)
+    with abi.Context((0, 0)) as grp:
+        s = abi.Scene(grp, flat)
+        film, st = s.render(prm)
+        part = [s.render(abi.render_params(spp=3, seed=2, rng_mode=abi.MSK_RNG_PCG_BLOCK, block_first=k, block_stride=2))[0] for k in (0, 1)]
+        with pytest.raises(abi.MskError) as e:
+            s.render(abi.render_params(spp=4, seed=2, rng_mode=abi.MSK_RNG_PCG_BLOCK, sample_first=1, sample_stride=2))
+        assert e.value.code == abi.MSK_ERR_UNSUPPORTED
+        s.close()
+    assert (st.samples, st.segments, st.shadow_rays) == (rst.samples, rst.segments, rst.shadow_rays)
+    assert np.allclose(film, ref, rtol=1e-6, atol=1e-6)
+    inner = np.zeros((64, 96), bool)
+    for by in range(2):
+        for bx in range(3):
+            inner[by * 32 + 2:by * 32 + 30, bx * 32 + 2:bx * 32 + 30] = True      # pixels only their own block reaches (border 2)
+    assert np.array_equal(film[inner].view(np.uint32), ref[inner].view(np.uint32))
+    assert np.allclose(part[0] + part[1], ref, rtol=1e-6, atol=1e-6)
+    o.close()

@@ -3,7 +3,8 @@
   tools/config_bench.py c3|c4|c5|cbox [--spp N] [--size S] [--reps R] [--check]
       renders the config R times in this process and prints one line per render
       (c3 = 70 k-triangle rough-conductor mesh, 1024^2 x 256 spp; c5 = 146 k-triangle rough-dielectric mesh, 1024^2 x 128 spp;
-       c4 = cbox 1920x1080 x 4096 spp on one GPU; cbox = the headline scene 512^2 x 512 spp); --check compares three
+       c4 = cbox 1920x1080 x 4096 spp on one GPU; cbox = the headline scene 512^2 x 512 spp; c5d = c5's geometry with a diffuse
+       mesh: with MSK_FORCE_GENERAL_SHADE=0/1 the same all-diffuse scene through either shading variant); --check compares three
       pixels' samples with the oracle bit for bit
   tools/config_bench.py c5 --reps 3 --ab "MSK_TREETOP=0" "MSK_TREETOP=128" "MSK_GPU_LIB=gpurun_scratch/libmsk_gpu_x.so"
       A/B: every quoted group of K=V is one configuration, run as its own process, interleaved R times; prints the minimum
@@ -12,7 +13,7 @@
 import argparse, importlib, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-DEFAULTS = {"c3": (1024, 1024, 256), "c5": (1024, 1024, 128), "c4": (1920, 1080, 4096), "cbox": (512, 512, 512)}
+DEFAULTS = {"c3": (1024, 1024, 256), "c5": (1024, 1024, 128), "c5d": (1024, 1024, 128), "c4": (1920, 1080, 4096), "cbox": (512, 512, 512)}
 
 
 def run_once(a):
@@ -22,7 +23,7 @@ def run_once(a):
     if a.size: w = h = a.size
     if a.spp: spp = a.spp
     t0 = time.time()
-    flat = hm.bunny_class_scene(w) if a.config == "c3" else hm.teapot_class_scene(w) if a.config == "c5" else hm.cbox_scene(w, h)
+    flat = hm.bunny_class_scene(w) if a.config == "c3" else hm.teapot_class_scene(w, diffuse=a.config == "c5d") if a.config in ("c5", "c5d") else hm.cbox_scene(w, h)
     t1 = time.time(); ctx = abi.Context(0); sc = abi.Scene(ctx, flat); t2 = time.time()
     out = {"config": a.config, "triangles": int(flat.desc.n_faces), "size": [w, h], "spp": spp, "flatten_s": round(t1 - t0, 2), "scene_create_s": round(t2 - t1, 3), "renders": []}
     for i in range(a.reps):
@@ -48,7 +49,7 @@ def main():
     ap.add_argument("config", choices=sorted(DEFAULTS))
     ap.add_argument("--spp", type=int, default=0); ap.add_argument("--size", type=int, default=0); ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--check", action="store_true"); ap.add_argument("--json", action="store_true")
-    ap.add_argument("--ab", nargs="+", default=None)
+    ap.add_argument("--ab", nargs="+", default=None); ap.add_argument("--inner", type=int, default=3, help="renders per process in an A/B (the minimum counts)")
     a = ap.parse_args()
     if not a.ab:
         return run_once(a)
@@ -58,7 +59,7 @@ def main():
             env = dict(os.environ)
             for kv in c.split():
                 k, v = kv.split("=", 1); env[k] = v
-            cmd = [sys.executable, os.path.abspath(__file__), a.config, "--reps", "2", "--json"] + (["--spp", str(a.spp)] if a.spp else []) + (["--size", str(a.size)] if a.size else [])
+            cmd = [sys.executable, os.path.abspath(__file__), a.config, "--reps", str(a.inner), "--json"] + (["--spp", str(a.spp)] if a.spp else []) + (["--size", str(a.size)] if a.size else [])
             p = subprocess.run(cmd, env=env, capture_output=True, text=True)
             if p.returncode:
                 print("FAILED:", c, p.stderr[-400:]); continue
