@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MSK_ABI_VERSION 5
+#define MSK_ABI_VERSION 6
 
 /* ---- status codes ------------------------------------------------------- */
 #define MSK_OK                 0
@@ -249,6 +249,11 @@ typedef struct msk_stats {
     /* kernel launches the call actually made (timed or not): traversal kernels, k_shade_gen, k_wavefront (the device-side
        loop of the thin end of a pass, booked as up to 16 `iterations` each) */
     uint32_t launches_trace, launches_shade, launches_wavefront;
+    /* ABI v6: samples ImageBlock::put would have warned about (imageblock.cpp:57-81, "Invalid sample value: [...]"): a value of
+       the sample's X, Y, Z (or of the nested integrator's R, G, B under "aov") that is not finite, or — "path" only: the
+       reference switches the test off for blocks with AOV channels, integrator.cpp:59-60 — below -1e-5.  Such a sample is
+       splatted all the same, as the reference does; the plugin logs the count at Warn level. */
+    uint64_t invalid_samples;
 } msk_stats;
 
 typedef struct msk_ctx   msk_ctx;

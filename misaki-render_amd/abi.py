@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-MSK_ABI_VERSION = 5
+MSK_ABI_VERSION = 6
 MSK_OK = 0
 MSK_ERR_INVALID_ARG, MSK_ERR_NO_DEVICE, MSK_ERR_HIP, MSK_ERR_OOM, MSK_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 MSK_BSDF_DIFFUSE, MSK_BSDF_ROUGHCONDUCTOR, MSK_BSDF_ROUGHDIELECTRIC = 0, 1, 2
@@ -88,7 +88,7 @@ class Stats(C.Structure):
                 ("ms_generate", C.c_float), ("ms_trace", C.c_float), ("ms_shade", C.c_float),
                 ("ms_resolve", C.c_float), ("n_trace_launches", C.c_uint32),
                 ("n_shade_launches", C.c_uint32), ("launches_trace", C.c_uint32), ("launches_shade", C.c_uint32),
-                ("launches_wavefront", C.c_uint32)]
+                ("launches_wavefront", C.c_uint32), ("invalid_samples", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -8,6 +8,8 @@
 #include "msk_serial.h"
 #include "msk_bvh.h"
 #include "msk_lbvh.h"
+#define MSK_WATCHDOG_SYNC
+#include "msk_watchdog.h"
 #include "../../include/msk_gpu.h"
 #include <hip/hip_ext.h>
 
@@ -42,6 +44,7 @@ struct msk_ctx {
     std::vector<hipEvent_t> events, more_events[MSK_MAX_STREAMS - 1];
     uint32_t timing_phase = 0;         // which sync groups carry timing events rotates from render to render (MSK_TIMING_EVERY);
                                        // a context is used by one host thread at a time (msk_gpu.h), so a plain counter
+    bool lost = false;                 // the watchdog gave up on a render (msk_watchdog.h): every later call fails at once, shutdown releases host memory only
     uint32_t device_sharers = 1;       // member contexts of a group that sit on this context's device (repeated ordinals): their
                                        // renders run side by side, each plans its record buffers within 1 / device_sharers of the free HBM
 };
@@ -71,6 +74,9 @@ static int fail_to(std::string *slot, int code, const char *fmt, ...) {
         return fail(ctx, e_ == hipErrorOutOfMemory ? MSK_ERR_OOM : MSK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
                     hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
+// a context the watchdog gave up on (msk_watchdog.h): nothing runs on it any more
+#define MSK_REFUSE_LOST(ctx) do { if ((ctx) && (ctx)->lost) return fail(ctx, MSK_ERR_HIP, "this context is lost: an earlier render made no progress " \
+                                                                         "(msk_watchdog.h); shut it down and start over in a new process"); } while (0)
 struct DevBuf {
     void *p = nullptr; size_t bytes = 0;
     ~DevBuf() { if (p) (void) hipFree(p); }
@@ -160,6 +166,7 @@ extern "C" int msk_gpu_init(const int *device_ids, int n, msk_ctx **out_ctx) {
 extern "C" void msk_gpu_shutdown(msk_ctx *ctx) {
     if (!ctx) return;
     if (ctx->group) { group_shutdown(ctx); return; }
+    if (ctx->lost) { delete ctx; return; }          // a stream that holds a kernel which never finished: destroying it would wait for it
     (void) hipSetDevice(ctx->device);
     for (auto ev : ctx->events) (void) hipEventDestroy(ev);
     for (int k = 0; k < MSK_MAX_STREAMS - 1; ++k) {
@@ -195,6 +202,7 @@ static inline float h_dot(const float *a, const float *b) { return a[0] * b[0] +
 extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_scene **out) {
     if (!ctx || !d || !out) return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: NULL argument");
     *out = nullptr;
+    MSK_REFUSE_LOST(ctx);
     if (ctx->group) return group_scene_create(ctx, d, out);
     if (d->abi_version != MSK_ABI_VERSION)
         return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: abi_version %u != %u", d->abi_version, MSK_ABI_VERSION);
@@ -571,6 +579,7 @@ void free_workspace(msk_scene *scene);
 extern "C" void msk_gpu_scene_destroy(msk_scene *scene) {
     if (!scene) return;
     if (scene->ctx->group) { group_scene_destroy(scene); return; }
+    if (scene->ctx->lost) return;         // hipFree waits for the device: under a kernel that never finished it would wait for ever; the memory goes with the process
     (void) hipSetDevice(scene->ctx->device);
     free_workspace(scene);
     delete scene;
@@ -793,7 +802,8 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     // round), which one launch at a time leaves open at its start, its end and wherever its waves wait.  Measured with two
     // concurrent half-size renders before this was built: 49.3 against 55.0 ms for the bench step.
     struct Half { uint32_t first, count; hipStream_t stream; Ctrl *d_ctrl, *h_ctrl; EventPool ev; uint32_t *stack_ovf;
-                  msk_stats st; int rc; unsigned long long expected; std::string err; };
+                  msk_stats st; int rc; unsigned long long expected; std::string err; bool lost = false; };
+    const mskwd::Limits wd_limits = mskwd::limits_from_env();
     auto run_range = [&](Half &hf) -> int {
         (void) hipSetDevice(ctx->device);               // the current device is per host thread
         PassParams pp = pp0;
@@ -815,6 +825,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
         };
         uint32_t parity = 0;
         bool fused_now = fused_all;
+        mskwd::Progress watchdog(wd_limits);               // msk_watchdog.h: a wall limit per sync group + "the counters stand still"
         for (uint32_t gi = 0;; ++gi) {
             ev_h.next = ev_mark + (size_t) parity * 4 * group;
             const bool timed = timing && (gi + phase) % every == 0;
@@ -846,10 +857,23 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
                                sb.counts.as<RegionCtl>() + hf.first, hf.count, hf.d_ctrl);
             HIP_TRY_SLOT(&hf.err, hipGetLastError());
             HIP_TRY_SLOT(&hf.err, hipMemcpyAsync(hf.h_ctrl, hf.d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream_h));
-            HIP_TRY_SLOT(&hf.err, hipStreamSynchronize(stream_h));
+            {
+                const hipError_t es = mskwd::sync(stream_h, watchdog);
+                if (es == hipErrorNotReady) {
+                    hf.lost = true;
+                    return fail_to(&hf.err, MSK_ERR_HIP, "no progress: a sync group of the wavefront loop (iterations %u..%u, regions %u..%u) did not finish within "
+                                   "%g s (MSK_WATCHDOG_S); the context is lost", it - (fused_now ? fused_iters : group), it, hf.first, hf.first + hf.count, watchdog.limits().wall_s);
+                }
+                HIP_TRY_SLOT(&hf.err, es);
+            }
             pend_shade.swap(cur_shade); pend_trace.swap(cur_trace); cur_shade.clear(); cur_trace.clear(); parity ^= 1u;
             const Ctrl &h = *hf.h_ctrl;
             if (h.remaining == 0 && h.live == 0) break;
+            if (watchdog.group_done(mskwd::Counters{h.samples_done, h.segments, h.remaining, h.live}) == mskwd::STALLED) {
+                hf.lost = true;
+                return fail_to(&hf.err, MSK_ERR_HIP, "no progress: %u sync groups of the wavefront loop changed nothing (%llu samples finished, %llu live paths, "
+                               "%llu samples not started; MSK_WATCHDOG_GROUPS); the context is lost", watchdog.stalled(), h.samples_done, h.live, h.remaining);
+            }
             if (fused_ok && !fused_now && h.remaining == 0 && h.live * 100ull < (unsigned long long) fused_tail_pct * hf.count * region_size)
                 fused_now = true;                       // the thinning end of the pass: no more launches and host round trips per sweep
             if (it > 100000000u) return fail_to(&hf.err, MSK_ERR_HIP, "wavefront loop did not terminate");
@@ -857,6 +881,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
         read_pending();
         ev_h.next = ev_mark;                            // every timestamp has been read: the events are free again
         st->samples = hf.h_ctrl->samples_done; st->segments = hf.h_ctrl->segments; st->shadow_rays = hf.h_ctrl->shadow_rays;
+        st->invalid_samples = hf.h_ctrl->invalid;
         st->iterations = it;
         if (hf.h_ctrl->samples_done != hf.expected)
             return fail_to(&hf.err, MSK_ERR_HIP, "internal error: %llu of %llu samples finished", hf.h_ctrl->samples_done, hf.expected);
@@ -906,10 +931,12 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     } else {
         parts[0].rc = run_range(parts[0]);
     }
+    for (auto &hf : parts) if (hf.lost) ctx->lost = true;                                 // the watchdog gave up on a part: the context is done
     for (auto &hf : parts) if (hf.rc) return fail(ctx, hf.rc, "%s", hf.err.c_str());     // first failing part, after the join
     if (stats) {
         for (const Half &hf : parts) {
             stats->samples += hf.st.samples; stats->segments += hf.st.segments; stats->shadow_rays += hf.st.shadow_rays;
+            stats->invalid_samples += hf.st.invalid_samples;
             stats->iterations += hf.st.iterations;
             stats->ms_trace += hf.st.ms_trace; stats->ms_shade += hf.st.ms_shade;
             stats->n_trace_launches += hf.st.n_trace_launches; stats->n_shade_launches += hf.st.n_shade_launches;
@@ -1010,7 +1037,7 @@ static int render_serial(msk_scene *sc, const msk_render_params *prm, float *d_f
     HIP_TRY(ctx, hipMemsetAsync(ws.block_buf.p, 0, buf_bytes, stream));
     DevBuf counters, ovf;
     HIP_TRY(ctx, counters.reserve(32));
-    HIP_TRY(ctx, hipMemsetAsync(counters.p, 0, 24, stream));
+    HIP_TRY(ctx, hipMemsetAsync(counters.p, 0, 32, stream));
     // few blocks (BASELINE config 1 has 64): one block per WAVE — the GPU holds ~2000 of this kernel's waves at once, and a wave that
     // runs one scalar loop does not pay for the branches of 63 others (config 1: 3.0 s -> see profiles/r04_pcg_block_config1.txt)
     const bool per_wave = owned.size() <= env_u32("MSK_SERIAL_PER_WAVE_MAX", 16384);
@@ -1038,11 +1065,11 @@ static int render_serial(msk_scene *sc, const msk_render_params *prm, float *d_f
                        ws.block_buf.as<float>(), buf_stride, fo);
     if (t_end) (void) hipEventRecord(t_end, stream);
     HIP_TRY(ctx, hipGetLastError());
-    unsigned long long h[3] = {0, 0, 0};
-    HIP_TRY(ctx, hipMemcpyAsync(h, counters.p, 24, hipMemcpyDeviceToHost, stream));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(h, counters.p, 32, hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     if (stats) {
-        stats->samples = h[0]; stats->segments = h[1]; stats->shadow_rays = h[2]; stats->passes = 1;
+        stats->samples = h[0]; stats->segments = h[1]; stats->shadow_rays = h[2]; stats->invalid_samples = h[3]; stats->passes = 1;
         if (t_begin && t_end) (void) hipEventElapsedTime(&stats->ms_total, t_begin, t_end);
     }
     return MSK_OK;
@@ -1257,12 +1284,14 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
 extern "C" int msk_gpu_render_device(msk_scene *scene, const msk_render_params *params, float *d_film_xyzaw, void *hip_stream,
                                      msk_stats *stats) {
     if (!scene || !d_film_xyzaw) return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_render_device: NULL argument");
+    MSK_REFUSE_LOST(scene->ctx);
     if (scene->ctx->group) return group_render_device(scene, params, d_film_xyzaw, (hipStream_t) hip_stream, stats);
     return render_impl(scene, params, d_film_xyzaw, (hipStream_t) hip_stream, stats);
 }
 
 extern "C" int msk_gpu_render(msk_scene *scene, const msk_render_params *params, float *film_xyzaw, msk_stats *stats) {
     if (!scene || !film_xyzaw) return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_render: NULL argument");
+    MSK_REFUSE_LOST(scene->ctx);
     if (scene->ctx->group) return group_render(scene, params, film_xyzaw, stats);
     msk_ctx *ctx = scene->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1305,6 +1334,7 @@ extern "C" int msk_gpu_render_aov(msk_scene *scene, const msk_render_params *par
                                   float *film, msk_stats *stats) {
     if (!scene || !film || !params || (n_aovs && !aov_types))
         return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_render_aov: NULL argument");
+    MSK_REFUSE_LOST(scene->ctx);
     if (scene->ctx->group) return group_render_aov(scene, params, aov_types, n_aovs, film, stats);
     msk_ctx *ctx = scene->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1350,6 +1380,7 @@ extern "C" int msk_gpu_render_aov(msk_scene *scene, const msk_render_params *par
 extern "C" int msk_gpu_sample_pixels(msk_scene *scene, const msk_render_params *prm, uint64_t n_pixels, const int32_t *pixels,
                                      float *out_xyz, float *out_pos) {
     if (!scene || !pixels || !out_xyz) return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_sample_pixels: NULL argument");
+    MSK_REFUSE_LOST(scene->ctx);
     if (scene->ctx->group) {             // sub-stage entry points of a group run on its first member
         const int rc = msk_gpu_sample_pixels(scene->parts[0], prm, n_pixels, pixels, out_xyz, out_pos);
         return rc ? group_fail(scene->ctx, 0, rc) : MSK_OK;
@@ -1409,6 +1440,7 @@ extern "C" int msk_gpu_sample_pixels(msk_scene *scene, const msk_render_params *
 
 static int trace_batch(msk_scene *scene, uint64_t n, const float *rays, float *out_hit, uint8_t *out_any) {
     msk_ctx *ctx = scene->ctx;
+    MSK_REFUSE_LOST(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (n == 0) return MSK_OK;
     DevBuf d_rays, d_out;

@@ -113,8 +113,9 @@ struct RegionCtl {
     unsigned long long segments, shadow_rays, samples_done;
     uint32_t count;                               // live slots
     uint32_t half_ns;                             // bit 0: which half of the region holds them; bits 1..: how many of them carry a shadow ray
-    uint32_t n_new, pad;                          // the last n_new live slots are camera samples the last sweep started: their throughput is 1
+    uint32_t n_new;                               // the last n_new live slots are camera samples the last sweep started: their throughput is 1
                                                   // and their radiance 0 by definition — neither written nor read
+    uint32_t invalid;                             // records ImageBlock::put would have warned about (imageblock.cpp:57-81; msk_stats::invalid_samples)
 };
 // A region is two halves of region_size slots.  A shading sweep reads the live paths from one half and writes the survivors
 // (and the new camera samples) to the other, so nothing it writes can land on a slot it has not read yet, in whatever order
@@ -134,7 +135,7 @@ MSK_DEV RegionView region_view(uint32_t region, uint32_t region_size, uint32_t c
     return v;
 }
 struct Ctrl {                                     // written by k_reduce_ctl, read by the host
-    unsigned long long live, remaining, segments, shadow_rays, samples_done;
+    unsigned long long live, remaining, segments, shadow_rays, samples_done, invalid;
 };
 
 struct PassParams {
@@ -1578,8 +1579,16 @@ MSK_DEV uint32_t nonfinite_flag(float a, float b, float c) {
 }
 
 // render_sample's tail for one finished path (integrator.cpp:115-125): ray weight, XYZ, film position -> sample record
+// ImageBlock::put's validity test (imageblock.cpp:57-81): every value finite and, unless the block carries AOV channels
+// (integrator.cpp:59-60: warn_negative = !has_aovs), not below -1e-5
+MSK_DEV bool invalid_value(float a, float b, float c, bool warn_negative) {
+    const bool fin = fabsf(a) < MSK_INF_F && fabsf(b) < MSK_INF_F && fabsf(c) < MSK_INF_F;
+    const bool neg = warn_negative && !(a >= -1e-5f && b >= -1e-5f && c >= -1e-5f);
+    return !fin || neg;
+}
+// returns how many of the wave's records ImageBlock::put would have warned about
 template <bool DIFFUSE_ONLY>
-MSK_DEV void emit_record(const DeviceScene &sc, const SceneTables &tb, const PassParams &pp, spec wl, spec res, uint32_t pix, uint32_t si) {
+MSK_DEV uint32_t emit_record(const DeviceScene &sc, const SceneTables &tb, const PassParams &pp, spec wl, spec res, uint32_t pix, uint32_t si) {
     // what only this function needs of the kernel's arguments (MSK_COLD_KARGS above)
     struct Cold { const uint32_t *pix_to_j; const uint4 *pix_table; float4 *rec_a; float *rec_b; float4 *aov_rgb; uint32_t spp_owned, packed;
                   float filter_radius, filter_scale; int filter_border; } k;
@@ -1614,6 +1623,7 @@ MSK_DEV void emit_record(const DeviceScene &sc, const SceneTables &tb, const Pas
     }
     st4<2>(k.rec_a + r, make_float4(X, Y, Z, wx));
     if (MSK_NT >= 2) __builtin_nontemporal_store(wy, k.rec_b + r); else k.rec_b[r] = wy;
+    bool invalid = invalid_value(X, Y, Z, DIFFUSE_ONLY || !k.aov_rgb);
     if (!DIFFUSE_ONLY && k.aov_rgb) {                              // aov.cpp:124-136: the sample before ray_weight
         float x0, y0, z0;
         spectrum_to_xyz(tb.cie, res, wl, &x0, &y0, &z0);
@@ -1621,7 +1631,9 @@ MSK_DEV void emit_record(const DeviceScene &sc, const SceneTables &tb, const Pas
                     B = 0.055648f * x0 + (-0.204043f * y0 + 1.057311f * z0);
         if (k.packed) wx = __uint_as_float((__float_as_uint(wx) & MSK_W_FIELDS) | nonfinite_flag(R, G, B));
         k.aov_rgb[r] = make_float4(R, G, B, wx);
+        invalid = invalid || invalid_value(R, G, B, false);
     }
+    return (uint32_t) __popcll(__ballot(invalid));
 }
 
 // Finished paths are parked in a wave-local LDS queue and turned into records 64 at a time: the record arithmetic (four
@@ -1689,7 +1701,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
     uint32_t cur_s = 0, cur_n = 0;                // survivors written so far: with a shadow ray (upwards from slot 0), without (downwards from `last`)
     const uint32_t n_em = sc.n_emitters;
     const bool one_emitter = n_em == 1 && (DIFFUSE_ONLY || sc.env_emitter < 0);      // one AREA emitter
-    uint32_t n_done = 0;
+    uint32_t n_done = 0, n_invalid = 0;
 
     // A chunk's state as it is loaded.  (Measured and rejected: issuing the NEXT chunk's loads before this one is shaded — legal
     // with two-half regions — costs 30 VGPRs = one wave per SIMD and is slower, 21.6 vs 20.7 ms of shading per bench step.  Round 3:
@@ -1936,7 +1948,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
                 if (n_queued >= MSK_WAVE) {
                     const spec qwl = from4(dq.wl[lane]), qres = from4(dq.res[lane]);
                     const uint2 qid = dq.id[lane];
-                    emit_record<DIFFUSE_ONLY>(sc, tb, pp, qwl, qres, qid.x, qid.y);
+                    n_invalid += emit_record<DIFFUSE_ONLY>(sc, tb, pp, qwl, qres, qid.x, qid.y);
                     // move the rest (< 64 entries) to the front
                     const uint32_t rem = n_queued - MSK_WAVE;
                     float4 a = make_float4(0, 0, 0, 0), b = a; uint2 c4 = make_uint2(0, 0);
@@ -1967,7 +1979,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
     if (lane < n_queued) {
         const spec qwl = from4(dq.wl[lane]), qres = from4(dq.res[lane]);
         const uint2 qid = dq.id[lane];
-        emit_record<DIFFUSE_ONLY>(sc, tb, pp, qwl, qres, qid.x, qid.y);
+        n_invalid += emit_record<DIFFUSE_ONLY>(sc, tb, pp, qwl, qres, qid.x, qid.y);       // (lane 0, which writes the counters back, is in here whenever anything is)
     }
     // ---- regeneration: fill the free tail with new camera samples (integrator.cpp:103-116)
     const uint32_t n_free = pp.region_size - (cur_s + cur_n);
@@ -2035,7 +2047,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
     rc.count = n_out; rc.half_ns = (cur_s << 1) | ((rc.half_ns & 1u) ^ 1u); rc.n_new = got;
     if (lane == 0) {
         rc.next_sample = first + got;
-        rc.segments += n_out; rc.shadow_rays += cur_s; rc.samples_done += n_done;
+        rc.segments += n_out; rc.shadow_rays += cur_s; rc.samples_done += n_done; rc.invalid += n_invalid;
         pp.regions[wave] = rc;
     }
     return region_view(wave, pp.region_size, rc.count, rc.half_ns);
@@ -2201,24 +2213,24 @@ k_aov_primary(DeviceScene sc, PathState st, PassParams pp, AovParams ap) {
     }
 }
 
-// sums the per-region records for the host (termination test + statistics): each block reduces its slice and adds five
-// totals to *out (zeroed by the host before the launch) — 5 atomics per block, a few dozen per launch
+// sums the per-region records for the host (termination test + statistics): each block reduces its slice and adds six
+// totals to *out (zeroed by the host before the launch) — 6 atomics per block, a few dozen per launch
 __global__ void __launch_bounds__(MSK_BLOCK) k_reduce_ctl(const RegionCtl *regions, uint32_t n_regions, Ctrl *out) {
-    __shared__ unsigned long long sh[5][MSK_BLOCK];
-    unsigned long long a[5] = {0, 0, 0, 0, 0};
+    __shared__ unsigned long long sh[6][MSK_BLOCK];
+    unsigned long long a[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * MSK_BLOCK + threadIdx.x; i < n_regions; i += gridDim.x * MSK_BLOCK) {
         const RegionCtl r = regions[i];
-        a[0] += r.count; a[1] += r.end_sample - r.next_sample; a[2] += r.segments; a[3] += r.shadow_rays; a[4] += r.samples_done;
+        a[0] += r.count; a[1] += r.end_sample - r.next_sample; a[2] += r.segments; a[3] += r.shadow_rays; a[4] += r.samples_done; a[5] += r.invalid;
     }
-    for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] = a[k];
+    for (int k = 0; k < 6; ++k) sh[k][threadIdx.x] = a[k];
     __syncthreads();
     for (uint32_t s = MSK_BLOCK / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + s];
+        if (threadIdx.x < s) for (int k = 0; k < 6; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + s];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         atomicAdd(&out->live, sh[0][0]); atomicAdd(&out->remaining, sh[1][0]); atomicAdd(&out->segments, sh[2][0]);
-        atomicAdd(&out->shadow_rays, sh[3][0]); atomicAdd(&out->samples_done, sh[4][0]);
+        atomicAdd(&out->shadow_rays, sh[3][0]); atomicAdd(&out->samples_done, sh[4][0]); atomicAdd(&out->invalid, sh[5][0]);
     }
 }
 

@@ -67,6 +67,7 @@ static void group_shutdown(msk_ctx *g) {
 }
 
 static int group_fail(msk_ctx *g, size_t k, int rc) {
+    if (g->group->ctxs[k]->lost) g->lost = true;          // the watchdog gave up on a member: the group is done as well
     return fail(g, rc, "device %d (member %zu of %zu): %s", g->group->ctxs[k]->device, k, g->group->ctxs.size(),
                 g->group->ctxs[k]->last_error.c_str());
 }
@@ -96,6 +97,7 @@ static int group_scene_create(msk_ctx *g, const msk_scene_desc *d, msk_scene **o
 
 static void group_scene_destroy(msk_scene *s) {
     for (msk_scene *p : s->parts) if (p) msk_gpu_scene_destroy(p);
+    if (s->ctx->lost) return;                             // (as for a single context: device memory is not freed under a hung kernel)
     (void) hipSetDevice(s->ctx->device);
     delete s;
 }
@@ -121,7 +123,7 @@ static void group_merge_stats(msk_stats *out, const std::vector<msk_stats> &st, 
     if (!out) return;
     std::memset(out, 0, sizeof *out);
     for (const msk_stats &s : st) {
-        out->samples += s.samples; out->segments += s.segments; out->shadow_rays += s.shadow_rays;
+        out->samples += s.samples; out->segments += s.segments; out->shadow_rays += s.shadow_rays; out->invalid_samples += s.invalid_samples;
         out->iterations = std::max(out->iterations, s.iterations); out->passes = std::max(out->passes, s.passes);
         out->ms_trace += s.ms_trace; out->ms_shade += s.ms_shade; out->ms_resolve = std::max(out->ms_resolve, s.ms_resolve);
         out->n_trace_launches += s.n_trace_launches; out->n_shade_launches += s.n_shade_launches;

@@ -41,7 +41,7 @@ struct SerialParams {
     float *block_buf; uint32_t buf_stride;
     uint32_t *stack_ovf;
     uint32_t per_wave;          // 1: image block = wave index, only lane 0 works (see k_path_serial)
-    unsigned long long *counters;               // [0] samples [1] segments [2] shadow rays
+    unsigned long long *counters;               // [0] samples [1] segments [2] shadow rays [3] invalid samples (imageblock.cpp:57-81)
 };
 
 // ImageBlock::put(pos, value) (imageblock.cpp:55-114) into a bordered block buffer of sx x sy pixels, 5 channels
@@ -83,7 +83,7 @@ k_path_serial(DeviceScene sc, SerialParams prm) {
     rng.seed(0x853c49e6748fea9bULL + prm.seed, 0xda3e39cb94b95bdbULL);      // oracle D2; independent.cpp:20-26
     const uint32_t n_em = sc.n_emitters;
     const uint32_t sstride = prm.sample_stride ? prm.sample_stride : 1u;
-    unsigned long long n_samples = 0, n_segments = 0, n_shadow = 0;
+    unsigned long long n_samples = 0, n_segments = 0, n_shadow = 0, n_invalid = 0;
     auto closest = [&](f3 o, f3 d, float tmin, float tmax) {
         float t, u, v; uint32_t prim;
         traverse<false, true>(sc.nodes, sc.tris, sc.tri_pad, sc.root_ref, sc.n_tris, o, d, tmin, tmax, stack, &t, &u, &v, &prim);
@@ -268,9 +268,11 @@ k_path_serial(DeviceScene sc, SerialParams prm) {
                 float v5[5];
                 spectrum_to_xyz(tb.cie, result, wl, &v5[0], &v5[1], &v5[2]);
                 v5[3] = 1.f; v5[4] = 1.f;
+                if (invalid_value(v5[0], v5[1], v5[2], true)) n_invalid += 1;                    // imageblock.cpp:57-81: warned about, splatted all the same
                 serial_put(sc, data, sx, sy, b.off_x - border, b.off_y - border, px, py, v5);
             }
     atomicAdd(&prm.counters[0], n_samples); atomicAdd(&prm.counters[1], n_segments); atomicAdd(&prm.counters[2], n_shadow);
+    if (n_invalid) atomicAdd(&prm.counters[3], n_invalid);
 }
 
 }  // namespace msk

@@ -882,6 +882,9 @@ public:
         if (rc != MSK_OK) Throw("{}", msk_gpu_last_error(m_ctx));
         film->put(whole);
         m_last_stats = st;
+        // ImageBlock::put logs every such sample as it arrives (imageblock.cpp:57-81); the samples are splatted on the device, so
+        // the plugin reports how many there were
+        if (st.invalid_samples) Log(Warn, "Invalid sample value: {} of {} samples were negative or not finite", st.invalid_samples, st.samples);
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         Log(Info, "Rendering finished. (took {}s, device {} ms, {} Msamples/s)", secs, st.ms_total,
             st.ms_total > 0 ? st.samples / (st.ms_total * 1e3) : 0.0);
@@ -971,6 +974,7 @@ public:
         if (rc != MSK_OK) Throw("{}", msk_gpu_last_error(m_ctx));
         film->put(whole);
         m_last_stats = st;
+        if (st.invalid_samples) Log(Warn, "Invalid sample value: {} of {} samples were not finite", st.invalid_samples, st.samples);
         Log(Info, "Rendering finished. (device {} ms)", st.ms_total);
         return true;
     }

@@ -892,7 +892,7 @@ static const msk_bsdf_desc *bsdf_side(const Scene &sc, const msk_bsdf_desc &b, V
     return &b;
 }
 
-struct Counters { uint64_t samples = 0, segments = 0, shadow_rays = 0; };
+struct Counters { uint64_t samples = 0, segments = 0, shadow_rays = 0, invalid = 0; };
 
 // ===========================================================================
 // a5  PathTracer::sample (integrators/path.cpp:23-125) with a11 diffuse BSDF
@@ -1001,6 +1001,8 @@ struct ImageBlock {
     int off_x = 0, off_y = 0, size_x = 0, size_y = 0, border = 0, channels = 5;
     std::vector<float> data;
     float radius = 0, scale_factor = 0; const float *lut = nullptr;
+    bool warn_negative = true, warn_invalid = true;                     // imageblock.h:16
+    uint64_t invalid = 0;                                               // how often put() would have logged "Invalid sample value"
     void init(int sx, int sy, const msk_film_desc *filter, bool with_border) {
         if (filter) {
             radius = filter->filter_radius; lut = filter->filter_lut;
@@ -1014,6 +1016,12 @@ struct ImageBlock {
         return lut[std::min((int) std::fabs(x * scale_factor), MSK_FILTER_RESOLUTION)];
     }
     void put(V2 pos_, const float *value) {                             // imageblock.cpp:55-114
+        if (warn_negative || warn_invalid) {                            // :57-81 — the sample is warned about and splatted all the same
+            bool is_valid = true;
+            if (warn_negative) for (int k = 0; k < channels; ++k) is_valid &= value[k] >= -1e-5f;
+            if (warn_invalid) for (int k = 0; k < channels; ++k) is_valid &= (bool) std::isfinite(value[k]);
+            if (!is_valid) ++invalid;
+        }
         int sx = size_x + 2 * border, sy = size_y + 2 * border;
         const V2 pos{pos_.x - 0.5f - (off_x - border), pos_.y - 0.5f - (off_y - border)};
         int lo_x = std::max((int) std::ceil(pos.x - radius), 0), lo_y = std::max((int) std::ceil(pos.y - radius), 0);
@@ -1156,6 +1164,7 @@ static void render(const Scene &sc, const msk_render_params &prm, float *film, C
             if (bd.off_x - border >= CX + CW || bd.off_x + bd.size_x + border <= CX || bd.off_y - border >= CY + CH || bd.off_y + bd.size_y + border <= CY) continue;
             ImageBlock blk;
             blk.off_x = bd.off_x; blk.off_y = bd.off_y; blk.channels = n_ch;
+            blk.warn_negative = aov == nullptr;                    // integrator.cpp:59-60: !has_aovs
             blk.init(bd.size_x, bd.size_y, &sc.film, true);
             std::vector<float> v((size_t) n_ch);
             Sampler sampler; sampler.mode = prm.rng_mode;
@@ -1174,10 +1183,11 @@ static void render(const Scene &sc, const msk_render_params &prm, float *film, C
                         blk.put(ps, v.data());
                     }
                 }
+            cnt.invalid += blk.invalid;
             done[id] = std::move(blk);
         }
         std::lock_guard<std::mutex> g(mtx);
-        total->samples += cnt.samples; total->segments += cnt.segments; total->shadow_rays += cnt.shadow_rays;
+        total->samples += cnt.samples; total->segments += cnt.segments; total->shadow_rays += cnt.shadow_rays; total->invalid += cnt.invalid;
         isect_flush();
     };
     std::vector<std::thread> pool;
@@ -1224,7 +1234,7 @@ int msk_oracle_render(void *s, const msk_render_params *prm, float *film, msk_st
     auto t1 = std::chrono::steady_clock::now();
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
-        stats->samples = c.samples; stats->segments = c.segments; stats->shadow_rays = c.shadow_rays;
+        stats->samples = c.samples; stats->segments = c.segments; stats->shadow_rays = c.shadow_rays; stats->invalid_samples = c.invalid;
         stats->ms_total = std::chrono::duration<float, std::milli>(t1 - t0).count();
     }
     return 0;
@@ -1240,7 +1250,7 @@ int msk_oracle_render_aov(void *s, const msk_render_params *prm, const int32_t *
     }
     Counters c;
     render(*(Scene *) s, *prm, film, &c, n_threads, &spec);
-    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->samples = c.samples; stats->segments = c.segments; stats->shadow_rays = c.shadow_rays; }
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->samples = c.samples; stats->segments = c.segments; stats->shadow_rays = c.shadow_rays; stats->invalid_samples = c.invalid; }
     return 0;
 }
 

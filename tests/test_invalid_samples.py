@@ -1,0 +1,76 @@
+"""msk_stats::invalid_samples (ABI v6): the samples ImageBlock::put would have logged as "Invalid sample value: [...]"
+(imageblock.cpp:57-81: a value below -1e-5 — unless the block carries AOV channels, integrator.cpp:59-60 — or not finite).  The
+reference warns and splats the sample all the same; so do both sides here, and the count comes back with the statistics (the
+plugin logs it at Warn level).  A descriptor that passes validation and still produces such samples: an emitter whose D65 scale
+is negative (negative radiance) or overflows (inf -> nan)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(hostmirror, golden_lookup, scale, size=48):
+    flat = hostmirror.cbox_scene(size, size, coeff_lookup=golden_lookup)
+    flat.desc.emitters[0].d65_scale *= scale
+    return flat
+
+
+@pytest.mark.parametrize("scale,kind", [(1.0, "valid"), (-1.0, "negative"), (1e36, "overflow")])
+def test_count_equals_the_scalar_loops(gpu_ctx, abi, hostmirror, oracle, golden_lookup, scale, kind):
+    flat = _scene(hostmirror, golden_lookup, scale)
+    g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+    for prm in (abi.render_params(spp=6, seed=4), abi.render_params(spp=3, seed=4, rng_mode=abi.MSK_RNG_PCG_BLOCK)):
+        film, st = g.render(prm)
+        ref, rst = o.render(prm, threads=8)
+        assert st.samples == rst.samples == 48 * 48 * prm.spp
+        assert st.invalid_samples == rst.invalid_samples, (kind, prm.rng_mode)
+        if kind == "valid":
+            assert st.invalid_samples == 0
+        else:
+            assert 0 < st.invalid_samples <= st.samples
+        if kind == "negative":
+            assert np.array_equal(film.view(np.uint32), ref.view(np.uint32)) and film[..., :3].min() < 0
+        elif kind == "overflow":                  # the samples are splatted all the same: non-finite pixels on both sides, in the same places
+            assert np.array_equal(np.isfinite(film), np.isfinite(ref)) and not np.isfinite(film).all()
+            ok = np.isfinite(ref)
+            assert np.array_equal(film[ok].view(np.uint32), ref[ok].view(np.uint32))
+    g.close()
+    o.close()
+
+
+def test_the_aov_integrator_only_counts_what_is_not_finite(gpu_ctx, abi, hostmirror, oracle, golden_lookup):
+    """Blocks with AOV channels do not warn about negative values (integrator.cpp:59-60): positions and normals are signed."""
+    neg = _scene(hostmirror, golden_lookup, -1.0, 32)
+    g, o = abi.Scene(gpu_ctx, neg), oracle.scene(neg)
+    types = [abi.MSK_AOV_POSITION, abi.MSK_AOV_PATH_RGBA]
+    film, st = g.render_aov(abi.render_params(spp=4, seed=2), types)
+    ref, rst = o.render_aov(abi.render_params(spp=4, seed=2), types)
+    assert st.invalid_samples == rst.invalid_samples == 0 and film[..., :3].min() < 0        # negative XYZ, no warning
+    assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+    g.close(); o.close()
+    inf = _scene(hostmirror, golden_lookup, 1e36, 32)
+    g, o = abi.Scene(gpu_ctx, inf), oracle.scene(inf)
+    film, st = g.render_aov(abi.render_params(spp=4, seed=2), types)
+    ref, rst = o.render_aov(abi.render_params(spp=4, seed=2), types)
+    assert st.invalid_samples == rst.invalid_samples > 0
+    g.close(); o.close()
+
+
+def test_the_plugin_warns(hostmirror, tmp_path, capfd):
+    """The "path" plugin logs the count as the reference's ImageBlock::put logs each sample: `Log(Warn, "Invalid sample value ...")`."""
+    import importlib
+    import __graft_entry__ as ge
+    ge.build_host_library()
+    hostlib = importlib.import_module("misaki-render_amd.hostlib")
+    meshes = hostmirror.cbox_meshes()
+    meshes[0].radiance = (3e36, 3e36, 3e36)              # overflows in the spectral upsampling's scale: inf radiance
+    xml = hostmirror.write_scene_xml(meshes, str(tmp_path), 32, 32, 2)
+    hostlib.load().msk_host_set_log_level(1)
+    try:
+        sc = hostlib.HostScene(xml)
+        film, rgba, st = sc.render()
+        sc.close()
+    finally:
+        hostlib.load().msk_host_set_log_level(3)
+    out = capfd.readouterr()
+    assert st.invalid_samples > 0 and "Invalid sample value" in (out.out + out.err)

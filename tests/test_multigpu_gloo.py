@@ -88,6 +88,25 @@ def test_two_rank_sample_shard_and_film_reduce(tmp_path):
     assert err.max() < 1e-4                                           # the north star's per-pixel L2 tolerance
 
 
+def test_tile_shard_and_sample_shard_reduce_to_the_same_film(tmp_path):
+    """BASELINE config 4 words its decomposition "pixel-tile shard", bench.py defaults to the sample shard (`--shard`): the two
+    world-size-2 runs must reduce to films within the north star's 1e-4 per-pixel L2 of EACH OTHER (they already are of the
+    single-rank film, separately) — whichever axis a node's ranks split, the film on rank 0 is the same film."""
+    import torch.multiprocessing as mp
+    films = {}
+    for k, mode in enumerate(("tiles", "samples")):
+        out = str(tmp_path / ("film_%s.npz" % mode))
+        mp.spawn(_worker, args=(2, 35500 + (os.getpid() % 2000) + k, out, mode), nprocs=2, join=True)
+        d = np.load(out)
+        assert d["samples"][0] == d["full_samples"] == 96 * 64 * 4
+        films[mode] = d["reduced"]
+    hm = importlib.import_module("misaki-render_amd.hostmirror")
+    a, b = hm.develop(films["tiles"])[..., :3], hm.develop(films["samples"])[..., :3]
+    err = np.linalg.norm(a.astype(np.float64) - b.astype(np.float64), axis=-1)
+    assert err.max() < 1e-4 and np.allclose(films["tiles"], films["samples"], rtol=3e-6, atol=1e-6)
+    assert np.array_equal(films["tiles"][..., 4] > 0, films["samples"][..., 4] > 0)
+
+
 def test_two_rank_speed_proportional_ranges(tmp_path):
     """Unequal shares (3 : 1) as contiguous sample ranges: every sample still rendered exactly once."""
     import torch.multiprocessing as mp
