@@ -116,6 +116,7 @@ struct RegionCtl {
     uint32_t n_new;                               // the last n_new live slots are camera samples the last sweep started: their throughput is 1
                                                   // and their radiance 0 by definition — neither written nor read
     uint32_t invalid;                             // records ImageBlock::put would have warned about (imageblock.cpp:57-81; msk_stats::invalid_samples)
+    uint32_t part_s, part_n;                      // a sweep split over two kernels (shade_region<.., PART>): the survivors the first one wrote
 };
 // A region is two halves of region_size slots.  A shading sweep reads the live paths from one half and writes the survivors
 // (and the new camera samples) to the other, so nothing it writes can land on a slot it has not read yet, in whatever order
@@ -1546,8 +1547,13 @@ static_assert(sizeof(DeviceScene) % 8 == 0 && sizeof(PathState) % 8 == 0, "the t
 // discretisation (rfilter.h:13-16: min(int(|t - pos| * scale), 32)) of target column lx + i, or MSK_W_OUT when that column is
 // outside [ceil(pos - r), floor(pos + r)]; the y word likewise.  Same fp32 expressions as the replay kernels evaluate per target.
 #define MSK_W_OUT 33u                       /* lut[33] = 0 in the replay kernel's copy of the table */
-#define MSK_W_FIELDS 0x3fffffffu
-#define MSK_W_NONFINITE 0x40000000u         /* bit 30 of the x word: a value of this record is inf / nan (see k_resolve_rows) */
+// Field i sits at bits 2 + 6 i .. 7 + 6 i (round 5; bits 6 i .. before): `(word >> 6 i) & 0xfc` is then the BYTE offset of the
+// table entry — a shift and a mask of the fast class (2.7 SIMD cycles each) where index extraction + address scaling were
+// v_bfe_u32 + v_lshlrev_b32 (4.1 each) per lookup of the film replay, whose inner loop is a third lookups.  Bits 0-1 are free.
+#define MSK_W_SHIFT 2
+#define MSK_W_FIELDS 0xfffffffcu
+#define MSK_W_NONFINITE 0x1u                /* bit 0 of the x word: a value of this record is inf / nan (see k_resolve_rows) */
+#define MSK_W_ALL_OUT ((MSK_W_OUT * 0x1041041u) << MSK_W_SHIFT)      /* five fields of MSK_W_OUT */
 struct SampleWeights { uint32_t x, y; };
 MSK_DEV uint32_t weight_word(float pos, uint32_t l, float radius, float scale) {
     const float lo = pos - radius, hi = pos + radius;
@@ -1556,7 +1562,7 @@ MSK_DEV uint32_t weight_word(float pos, uint32_t l, float radius, float scale) {
     for (int i = 0; i < 5; ++i) {
         const float ft = (float) (l + (uint32_t) i);
         const int idx = min((int) fabsf((ft - pos) * scale), 32);
-        w |= ((ft >= lo && ft <= hi) ? (uint32_t) idx : MSK_W_OUT) << (6 * i);
+        w |= ((ft >= lo && ft <= hi) ? (uint32_t) idx : MSK_W_OUT) << (6 * i + MSK_W_SHIFT);
     }
     return w;
 }
@@ -1652,7 +1658,10 @@ struct DoneQueue { float4 *wl, *res; uint2 *id; };      // id: {film pixel, samp
 // a path's arithmetic is its own and its record is addressed by (pixel, sample).  What makes reading in any order legal
 // is the two-half region (RegionView): nothing this sweep writes is something it still has to read.
 struct SortScratch { uint16_t *perm; uint8_t *cls; };        // per wave: region_size entries each, or {nullptr, nullptr}
-MSK_DEV bool sort_by_class(const PathState &st, const RegionView &in, const SortScratch &ss, uint32_t lane) {
+// `always`: build the permutation whatever the region holds (a sweep split by class walks class ranges of it); cnt_out: the
+// class counts (sorted position p belongs to class q for start[q] <= p < start[q] + cnt[q])
+MSK_DEV bool sort_by_class(const PathState &st, const RegionView &in, const SortScratch &ss, uint32_t lane, bool always = false,
+                           uint32_t *cnt_out = nullptr) {
     uint32_t cnt[MSK_N_CLASSES] = {0u, 0u, 0u, 0u};
     for (uint32_t c0 = 0; c0 < in.n; c0 += MSK_WAVE) {
         const uint32_t c = c0 + lane;
@@ -1667,7 +1676,11 @@ MSK_DEV bool sort_by_class(const PathState &st, const RegionView &in, const Sort
     uint32_t n_present = 0;
 #pragma unroll
     for (uint32_t q = 0; q + 1 < MSK_N_CLASSES; ++q) n_present += cnt[q] ? 1u : 0u;
-    if (n_present <= 1u) return false;                        // one material (misses aside): the region is read in slot order
+    if (cnt_out) {
+#pragma unroll
+        for (uint32_t q = 0; q < MSK_N_CLASSES; ++q) cnt_out[q] = cnt[q];
+    }
+    if (n_present <= 1u && !always) return false;             // one material (misses aside): the region is read in slot order
     uint32_t start[MSK_N_CLASSES];
     start[0] = 0;
 #pragma unroll
@@ -1689,7 +1702,21 @@ MSK_DEV bool sort_by_class(const PathState &st, const RegionView &in, const Sort
 }
 
 // One shading sweep of region `wave` by its owner wave (see the file header); returns the region as the sweep leaves it.
-template <bool DIFFUSE_ONLY>
+//
+// A sweep split by material class (round 5; PART 1 + PART 2 instead of PART 0).  The general variant holds the microfacet code's
+// registers (157 VGPRs, three waves per SIMD) for every chunk, although the class sort has already made the chunks uniform
+// and most of a mesh scene's hits are on its diffuse room.  With `PassParams::split` the sweep runs as TWO kernels:
+//   PART 1  k_shade_gen<*, true> compiled with AUX (124-VGPR diffuse code, four waves): the sorted region's class-0 range — hits
+//           on plain diffuse BSDFs (not two-sided, not textured: those are filed under class 1 at scene creation) — and, in a
+//           scene without an environment emitter, its misses (class 3: the path just ends); survivors are appended to the other
+//           half as always, how many is left in RegionCtl::part_s / part_n; count / half_ns still describe the input;
+//   PART 2  the general variant: the classes in between, starting from those counters, then the parked records, the regeneration
+//           and the region's bookkeeping.
+// Both sort the region themselves (two passes of ballots over 4 bytes per slot: cheaper than handing the permutation on).  A
+// path's arithmetic is its own and its record is addressed by (pixel, sample), so neither the split nor the order in which
+// the survivors land can change a bit (test_material_sorted_shading_changes_no_bit, the parity suite).  AUX: the state carries
+// {eta, nee pdf} (scenes with non-diffuse BSDFs): Russian roulette uses eta, and the pair is copied through.
+template <bool DIFFUSE_ONLY, bool AUX = !DIFFUSE_ONLY, int PART = 0>
 MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, const DoneQueue &dq, const SortScratch &ss, const PathState &st,
                                 const PassParams &pp, uint32_t wave, uint32_t lane) {
     uint32_t n_queued = 0;
@@ -1699,8 +1726,9 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
     const uint32_t base_out = (wave * 2u + ((rc.half_ns & 1u) ^ 1u)) * pp.region_size;      // the other half
     const uint32_t last = pp.region_size - 1u;
     uint32_t cur_s = 0, cur_n = 0;                // survivors written so far: with a shadow ray (upwards from slot 0), without (downwards from `last`)
+    if (PART == 2) { cur_s = rc.part_s; cur_n = rc.part_n; }
     const uint32_t n_em = sc.n_emitters;
-    const bool one_emitter = n_em == 1 && (DIFFUSE_ONLY || sc.env_emitter < 0);      // one AREA emitter
+    const bool one_emitter = n_em == 1 && (DIFFUSE_ONLY || sc.env_emitter < 0);      // one AREA emitter (a split sweep: no environment in the scene)
     uint32_t n_done = 0, n_invalid = 0;
 
     // A chunk's state as it is loaded.  (Measured and rejected: issuing the NEXT chunk's loads before this one is shaded — legal
@@ -1711,14 +1739,21 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
     struct ChunkIn { uint2 id; float4 wl, thr, res, rd4, hit, contrib; float2 aux; };
     const uint32_t first_new = n_in - rc.n_new;      // live index of the first camera sample the last sweep started
     bool sorted = false;
-    if (!DIFFUSE_ONLY && ss.perm) sorted = sort_by_class(st, in, ss, lane);
-    // live index of this lane in the chunk that starts at c0 (the slot order, or the material order)
-    auto live_index = [&](uint32_t c0) {
-        const uint32_t p = c0 + lane;
-        return (!DIFFUSE_ONLY && sorted && p < n_in) ? (uint32_t) ss.perm[p] : p;
+    // sorted positions this kernel shades: [p_begin, p_end) (+ [q_begin, n_in) for PART 1: the misses behind the other classes)
+    uint32_t p_begin = 0, p_end = n_in, q_begin = n_in;
+    if (PART != 0) {
+        uint32_t cnt[MSK_N_CLASSES];
+        sorted = sort_by_class(st, in, ss, lane, true, cnt);
+        const uint32_t misses_to_1 = sc.env_emitter < 0 ? cnt[3] : 0u;            // (a miss into an environment is the general variant's)
+        if (PART == 1) { p_end = cnt[0]; q_begin = n_in - misses_to_1; }
+        else { p_begin = cnt[0]; p_end = n_in - misses_to_1; }
+    } else if (!DIFFUSE_ONLY && ss.perm) sorted = sort_by_class(st, in, ss, lane);
+    // live index of the path at sorted position p (the slot order, or the material order); >= n_in: no path
+    auto live_index_at = [&](uint32_t p, uint32_t end) {
+        if (p >= end) return n_in;
+        return ((PART != 0 || !DIFFUSE_ONLY) && sorted) ? (uint32_t) ss.perm[p] : p;
     };
-    auto load_chunk = [&](uint32_t c0) {
-        const uint32_t c = live_index(c0);
+    auto load_chunk = [&](uint32_t c) {
         const uint32_t i = in.slot(c < n_in ? c : 0u);
         ChunkIn k;
         k.id = ld2<1>(st.id + i); k.wl = ld4<1>(st.wl + i); k.rd4 = ld4<2>(st.ray_d + i); k.hit = ld4<2>(st.hit + i);
@@ -1727,15 +1762,17 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
         k.contrib = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < in.ns) k.contrib = ld4<1>(st.contrib + i);                          // (whole chunks, but for the one the boundary falls in)
         k.aux = make_float2(1.f, 0.f);
-        if (!DIFFUSE_ONLY) k.aux = st.aux[i];
+        if (AUX) k.aux = st.aux[i];
         return k;
     };
-    for (uint32_t c0 = 0; c0 < n_in; c0 += MSK_WAVE) {
-        const uint32_t c = live_index(c0);
+    // the chunks of [p_begin, p_end), then (PART 1) those of [q_begin, n_in)
+    for (uint32_t range = 0; range < (PART == 1 ? 2u : 1u); ++range)
+    for (uint32_t c0 = range ? q_begin : p_begin, c_end = range ? n_in : p_end; c0 < c_end; c0 += MSK_WAVE) {
+        const uint32_t c = live_index_at(c0 + lane, c_end);
         const bool active = c < n_in;
         const bool shadow_in = c < in.ns;          // this path's last bounce sent a shadow ray (ns <= n_in)
         // ---- load
-        const ChunkIn cur = load_chunk(c0);
+        const ChunkIn cur = load_chunk(c);
         const uint2 id = cur.id;
         spec wl = from4(cur.wl), thr = from4(cur.thr), res = from4(cur.res);
         const float4 rd4 = cur.rd4;
@@ -1745,7 +1782,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
             res = res + from4(cur.contrib);
         hit.w = __uint_as_float(__float_as_uint(hit.w) & MSK_PRIM_ID);
         float bs_pdf = -rd4.w;                                             // meaningful for depth > 1 (PathState::ray_d)
-        float eta = cur.aux.x, nee_pdf = cur.aux.y;                        // carried only by the general variant
+        float eta = cur.aux.x, nee_pdf = cur.aux.y;                        // carried only with AUX
         uint32_t depth = id.y >> MSK_DEPTH_SHIFT;
         const uint32_t s_own = id.y & MSK_SI_MASK;
         const f3 rd = mk3(rd4.x, rd4.y, rd4.z);
@@ -1802,7 +1839,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
                 }
                 // ---- Russian roulette (path.cpp:116-122)
                 if ((int) depth >= pp.rr_depth) {
-                    const float q = fmin_std(DIFFUSE_ONLY ? max4(thr) : max4(thr) * eta * eta, 0.95f);
+                    const float q = fmin_std(AUX ? max4(thr) * eta * eta : max4(thr), 0.95f);
                     const float u = counter_pair(key, 3 + 3 * (depth - 2) + 1).y;
                     if (u >= q) alive = false;
                     else thr = thr / q;
@@ -1878,7 +1915,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
                     d = d / dist;
                     const float dp = fabsf(dot(d, ln));
                     pdf *= (dp != 0.f) ? dist2 / dp : 0.f;
-                    if (!DIFFUSE_ONLY) nee_pdf = e0.w * ((dp != 0.f) ? (dist * dist) / dp : 0.f);   // shape.cpp:80-86
+                    if (AUX) nee_pdf = e0.w * ((dp != 0.f) ? (dist * dist) / dp : 0.f);   // shape.cpp:80-86
                     if (dot(d, ln) < 0.f && pdf != 0.f) {                  // area.cpp:39-44
                         emitter_val = (one_emitter ? le_one : emitter_radiance(tb, (int) e, wl)) / pdf;
                     } else {
@@ -1970,7 +2007,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
             st4<1>(st.wl + o, to4(wl)); st4<1>(st.thr + o, to4(thr)); st4<1>(st.res + o, to4(res));
             st4<4>(st.ray_o + o, new_o); st4<4>(st.ray_d + o, new_d);
             if (has_shadow) { st4<4>(st.sh + o, new_sh); st4<1>(st.contrib + o, to4(contrib)); }
-            if (!DIFFUSE_ONLY) st.aux[o] = make_float2(eta, nee_pdf);
+            if (AUX) st.aux[o] = make_float2(eta, nee_pdf);
         }
         cur_s += (uint32_t) __popcll(m_s); cur_n += (uint32_t) __popcll(m_n);
     }
@@ -1980,6 +2017,14 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
         const spec qwl = from4(dq.wl[lane]), qres = from4(dq.res[lane]);
         const uint2 qid = dq.id[lane];
         n_invalid += emit_record<DIFFUSE_ONLY>(sc, tb, pp, qwl, qres, qid.x, qid.y);       // (lane 0, which writes the counters back, is in here whenever anything is)
+    }
+    if constexpr (PART == 1) {
+        // the first kernel of a split sweep: the survivors so far; count / half_ns / n_new / next_sample stay the INPUT's for the second
+        if (lane == 0) {
+            rc.part_s = cur_s; rc.part_n = cur_n; rc.samples_done += n_done; rc.invalid += n_invalid;
+            pp.regions[wave] = rc;
+        }
+        return in;
     }
     // ---- regeneration: fill the free tail with new camera samples (integrator.cpp:103-116)
     const uint32_t n_free = pp.region_size - (cur_s + cur_n);
@@ -2040,7 +2085,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
         st4<1>(st.wl + o, to4(wl));                                      // thr = 1, res = 0: RegionCtl::n_new
         st4<4>(st.ray_o + o, make_float4(ow.x, ow.y, ow.z, k.near_clip * inv_z));
         st4<4>(st.ray_d + o, make_float4(dw.x, dw.y, dw.z, k.far_clip * inv_z));
-        if (!DIFFUSE_ONLY) st.aux[o] = make_float2(1.f, 0.f);
+        if (AUX) st.aux[o] = make_float2(1.f, 0.f);
     }
     }
     const uint32_t n_out = cur_s + cur_n + got;
@@ -2061,7 +2106,7 @@ MSK_DEV DoneQueue done_queue(float4 *base) {
     return dq;
 }
 
-template <bool LDS_TABLES, bool DIFFUSE_ONLY>
+template <bool LDS_TABLES, bool DIFFUSE_ONLY, int PART = 0>
 MSK_DEV void shade_gen_body(const DeviceScene &sc, const PathState &st, const PassParams &pp) {
     extern __shared__ float4 lds_dyn[];
     const SceneTables tb = stage_tables<LDS_TABLES>(sc, lds_dyn);
@@ -2069,12 +2114,12 @@ MSK_DEV void shade_gen_body(const DeviceScene &sc, const PathState &st, const Pa
     const uint32_t queue_f4 = LDS_TABLES ? tables_lds_float4s(sc) : 0u;                         // after the staged tables
     const DoneQueue dq = done_queue(lds_dyn + queue_f4);
     SortScratch ss{nullptr, nullptr};
-    if (!DIFFUSE_ONLY && pp.sort_scratch) {         // after the queues: per wave, 3 bytes per slot of a region (host: shade LDS plan)
+    if ((!DIFFUSE_ONLY || PART != 0) && pp.sort_scratch) {         // after the queues: per wave, 3 bytes per slot of a region (host: shade LDS plan)
         uint8_t *p = (uint8_t *) (lds_dyn + queue_f4 + (MSK_BLOCK / MSK_WAVE) * MSK_DONE_Q_F4) + (size_t) (threadIdx.x / MSK_WAVE) * 3u * pp.region_size;
         ss.perm = (uint16_t *) p; ss.cls = p + 2u * pp.region_size;
     }
     if (lwave >= pp.region_count) return;
-    shade_region<DIFFUSE_ONLY>(sc, tb, dq, ss, st, pp, pp.region_first + lwave, threadIdx.x & (MSK_WAVE - 1));
+    shade_region<DIFFUSE_ONLY, PART != 0 || !DIFFUSE_ONLY, PART>(sc, tb, dq, ss, st, pp, pp.region_first + lwave, threadIdx.x & (MSK_WAVE - 1));
 }
 template <bool LDS_TABLES, bool DIFFUSE_ONLY>
 __global__ void __launch_bounds__(MSK_BLOCK)
@@ -2100,6 +2145,18 @@ template <>
 __global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_shade_gen<true, true>(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<true, true>(sc, st, pp); }
 #endif
+
+// The two kernels of a sweep split by material class (shade_region, PART 1 / PART 2): the diffuse code at four waves per SIMD for
+// the sorted region's plain-diffuse range (and its misses), the general variant at three for the classes in between + the sweep's tail.
+#ifndef MSK_SHADE_SPLIT1_WAVES
+#define MSK_SHADE_SPLIT1_WAVES 4, 4
+#endif
+template <bool LDS_TABLES>
+__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_SHADE_SPLIT1_WAVES)))
+k_shade_split1(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<LDS_TABLES, true, 1>(sc, st, pp); }
+template <bool LDS_TABLES>
+__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_SHADE_GEN_WAVES)))
+k_shade_split2(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<LDS_TABLES, false, 2>(sc, st, pp); }
 
 // ------------------------------------------------------------------------------------------
 // k_wavefront: the iteration loop itself on the device, for scenes whose tree is staged in LDS.  A region is private to
@@ -2382,20 +2439,20 @@ MSK_DEV void rr_accumulate(const float4 *la, const uint2 *lw, const float *lut, 
         for (int k = 0; k < G; ++k) { na[k] = la[s1 + k]; nw[k] = lw[s1 + k]; }
         float wy[G];
 #pragma unroll
-        for (int k = 0; k < G; ++k) wy[k] = lut[(rw[k].y >> shy) & 63u];
+        for (int k = 0; k < G; ++k) wy[k] = *(const float *) ((const char *) lut + ((rw[k].y >> shy) & 0xfcu));
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int f = j + 4 - kx;
             if (f < 0 || f > 4) continue;
             float wx[G];
 #pragma unroll
-            for (int k = 0; k < G; ++k) wx[k] = lut[(rw[k].x >> (6 * f)) & 63u];
+            for (int k = 0; k < G; ++k) wx[k] = *(const float *) ((const char *) lut + ((rw[k].x >> (6 * f)) & 0xfcu));
 #pragma unroll
             for (int k = 0; k < G; ++k) {
                 const float w = wx[k] * wy[k];
                 if (SAFE) {
                     // a record with inf / nan values: the scalar loop never multiplies them for targets outside the footprint
-                    if (((rw[k].x >> (6 * f)) & 63u) == MSK_W_OUT || ((rw[k].y >> shy) & 63u) == MSK_W_OUT) continue;
+                    if (((rw[k].x >> (6 * f)) & 0xfcu) == (MSK_W_OUT << MSK_W_SHIFT) || ((rw[k].y >> shy) & 0xfcu) == (MSK_W_OUT << MSK_W_SHIFT)) continue;
                 }
                 const msk_f2 ww = {w, w}, xy = {ra[k].x, ra[k].y}, z1 = {ra[k].z, ra[k].w};
                 acc[j][0] += ww * xy; acc[j][1] += ww * z1;
@@ -2469,8 +2526,8 @@ k_resolve_rows(DeviceScene sc, const BlockInfo *blocks, const RowBand *bands, ui
             const int sx = 3 * q - 4 + p_kx;
             float4 va = pa[q]; uint32_t vb = pb[q];
             if (!(p_lane_ok && sx >= 0 && sx < b.size_x)) {   // no such column / sample: zero weights (five fields of MSK_W_OUT), zero values
-                va = make_float4(0.f, 0.f, 0.f, __uint_as_float(MSK_W_OUT * 0x1041041u));
-                vb = MSK_W_OUT * 0x1041041u;
+                va = make_float4(0.f, 0.f, 0.f, __uint_as_float(MSK_W_ALL_OUT));
+                vb = MSK_W_ALL_OUT;
             }
             const uint32_t wxw = __float_as_uint(va.w);
             flags |= wxw;

@@ -62,9 +62,8 @@ def test_the_plugin_warns(hostmirror, tmp_path, capfd):
     import __graft_entry__ as ge
     ge.build_host_library()
     hostlib = importlib.import_module("misaki-render_amd.hostlib")
-    meshes = hostmirror.cbox_meshes()
-    meshes[0].radiance = (3e36, 3e36, 3e36)              # overflows in the spectral upsampling's scale: inf radiance
-    xml = hostmirror.write_scene_xml(meshes, str(tmp_path), 32, 32, 2)
+    # a `constant` emitter of D65 x -1000 (<spectrum name="radiance" value="-1000"/>) around the open box: negative radiance
+    xml = hostmirror.write_scene_xml(hostmirror.cbox_meshes(), str(tmp_path), 32, 32, 2, env={"scale": -1000.0})
     hostlib.load().msk_host_set_log_level(1)
     try:
         sc = hostlib.HostScene(xml)
