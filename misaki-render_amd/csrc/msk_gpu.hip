@@ -106,8 +106,6 @@ struct msk_scene {
     DeviceScene dev;
     DevBuf nodes, nodes4, nodes4q, nodes8, tris, tris3, tri_bounds, tri_verts, tri_frames, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
     bool lds_scene = false, lds_tables = false, all_diffuse = true;
-    bool split_classes = false;        // a shading sweep may run as two kernels, the plain-diffuse class apart (shade_region PART 1 / 2): the scene mixes
-                                       // plain diffuse BSDFs with others and has no environment emitter
     int trace_mode = 0;                // 0 binary tree in LDS, 1 binary tree in HBM/L2, 2 4-wide tree in HBM/L2, 4 8-wide quantised tree in HBM/L2,
                                        // 5 4-wide tree with quantised boxes in HBM/L2 (64-byte nodes; the default for trees in HBM)
     size_t trace_lds_bytes = 0, shade_lds_bytes = 0;
@@ -309,7 +307,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         o[4] = td.color1[0]; o[5] = td.color1[1]; o[6] = td.color1[2]; o[7] = td.to_uv[5];
         o[8] = td.to_uv[0]; o[9] = td.to_uv[1]; o[10] = td.to_uv[3]; o[11] = td.to_uv[4];
     }
-    bool all_diffuse = true, any_plain_diffuse = false;
+    bool all_diffuse = true;
     for (uint32_t b = 0; b < d->n_bsdfs; ++b) {
         const msk_bsdf_desc &bd = d->bsdfs[b];
         if (bd.type != MSK_BSDF_DIFFUSE && bd.type != MSK_BSDF_ROUGHCONDUCTOR && bd.type != MSK_BSDF_ROUGHDIELECTRIC)
@@ -328,7 +326,6 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         if (bd.reflectance_texture && bd.type != MSK_BSDF_DIFFUSE)
             return fail(ctx, MSK_ERR_UNSUPPORTED, "bsdf %u: only the diffuse reflectance can be textured", b);
         if (bd.type != MSK_BSDF_DIFFUSE || bd.back_bsdf >= 0 || bd.reflectance_texture) all_diffuse = false;
-        else any_plain_diffuse = true;
         msk_bsdf_desc rec = bd;                                    // device form: the texture's float4 offset in the table
         if (bd.reflectance_texture) rec.reflectance_texture = std::max(1u, d->n_bsdfs) * MSK_BSDF_F4 + (bd.reflectance_texture - 1) * 3;
         std::memcpy(&bsdfs[(size_t) b * 4 * MSK_BSDF_F4], &rec, sizeof rec);
@@ -403,10 +400,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
             std::memcpy(&w, &bvh.tris[k * 16 + 3], 4);
             std::memcpy(&mesh, &tv[(size_t) w * 12 + 3], 4);
             const int32_t b = mesh_info[(size_t) mesh * 4];
-            // MSK_BSDF_* = 0, 1, 2; class 0 is the PLAIN diffuse BSDF (what the diffuse shading code handles: the first kernel of a
-            // sweep split by class, shade_region): a two-sided or textured one is filed under class 1, with the general variant's
-            uint32_t cls = (b >= 0 && (uint32_t) b < d->n_bsdfs) ? (uint32_t) d->bsdfs[b].type : 0u;
-            if (cls == 0u && b >= 0 && (uint32_t) b < d->n_bsdfs && (d->bsdfs[b].back_bsdf >= 0 || d->bsdfs[b].reflectance_texture)) cls = 1u;
+            const uint32_t cls = (b >= 0 && (uint32_t) b < d->n_bsdfs) ? (uint32_t) d->bsdfs[b].type : 0u;      // MSK_BSDF_* = 0, 1, 2
             w |= (cls & (MSK_N_CLASSES - 1u)) << MSK_CLASS_SHIFT;
             std::memcpy(&bvh.tris[k * 16 + 3], &w, 4);
         }
@@ -481,7 +475,6 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         ds.env_radius = std::max(MSK_RAY_EPS_F, radius * (1.f + MSK_RAY_EPS_F));
         s->all_diffuse = false;             // the environment terms live in the general shading variant
     }
-    s->split_classes = !s->all_diffuse && any_plain_diffuse && env_emitter < 0;
     // LDS plan of k_trace: per-lane stack + (when it fits) the whole BVH
     const size_t stack_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4;
     const size_t scene_bytes = (size_t) ds.n_nodes * 64 + (size_t) ds.n_tris * 96;
@@ -783,8 +776,6 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     const bool sort_on = !diffuse_only && (!sc->all_diffuse || force_general) && region_size <= 4096 && env_u32("MSK_SORT", 1) &&
                          sc->shade_lds_bytes + sort_lds <= 64 * 1024;
     pp0.sort_scratch = sort_on ? 1u : 0u;
-    // the sweep as two kernels, the plain-diffuse class apart (shade_region PART 1 / 2; MSK_SHADE_SPLIT=0: one general kernel)
-    const bool split = sort_on && sc->split_classes && !aov_rgb && !force_general && env_u32("MSK_SHADE_SPLIT", 1) != 0;
     const size_t shade_lds = sc->shade_lds_bytes + (sort_on ? sort_lds : 0);
     const uint32_t group = env_u32("MSK_SYNC_GROUP", 8);
     static const size_t shade_pad_lds = (size_t) env_u32("MSK_SHADE_PAD_LDS_KB", 0) * 1024;   // occupancy experiments only
@@ -852,15 +843,8 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
                 if (timed) { a = ev_h.get(); b = ev_h.get(); c = ev_h.get(); d = ev_h.get(); }
                 const bool have_ev = a && b && c && d;
 #define MSK_SHADE(L, D) hipExtLaunchKernelGGL((k_shade_gen<L, D>), dim3(grid), dim3(MSK_BLOCK), shade_lds + shade_pad_lds, stream_h, a, b, 0, sc->dev, sb.st, pp)
-#define MSK_SPLIT(K, L, A, B) hipExtLaunchKernelGGL((K<L>), dim3(grid), dim3(MSK_BLOCK), shade_lds + shade_pad_lds, stream_h, A, B, 0, sc->dev, sb.st, pp)
-                if (split) {         // (the timing events: from the first kernel's start to the second one's end)
-                    if (sc->lds_tables) { MSK_SPLIT(k_shade_split1, true, a, nullptr); MSK_SPLIT(k_shade_split2, true, nullptr, b); }
-                    else { MSK_SPLIT(k_shade_split1, false, a, nullptr); MSK_SPLIT(k_shade_split2, false, nullptr, b); }
-                    st->launches_shade += 1;
-                }
-                else if (sc->lds_tables) { if (diffuse_only) MSK_SHADE(true, true); else MSK_SHADE(true, false); }
+                if (sc->lds_tables) { if (diffuse_only) MSK_SHADE(true, true); else MSK_SHADE(true, false); }
                 else { if (diffuse_only) MSK_SHADE(false, true); else MSK_SHADE(false, false); }
-#undef MSK_SPLIT
 #undef MSK_SHADE
                 launch_trace(sc, stream_h, sb.st, pp, c, d);
                 st->launches_shade += 1; st->launches_trace += 1;

@@ -116,7 +116,7 @@ struct RegionCtl {
     uint32_t n_new;                               // the last n_new live slots are camera samples the last sweep started: their throughput is 1
                                                   // and their radiance 0 by definition — neither written nor read
     uint32_t invalid;                             // records ImageBlock::put would have warned about (imageblock.cpp:57-81; msk_stats::invalid_samples)
-    uint32_t part_s, part_n;                      // a sweep split over two kernels (shade_region<.., PART>): the survivors the first one wrote
+    uint32_t pad[2];
 };
 // A region is two halves of region_size slots.  A shading sweep reads the live paths from one half and writes the survivors
 // (and the new camera samples) to the other, so nothing it writes can land on a slot it has not read yet, in whatever order
@@ -220,8 +220,10 @@ MSK_DEV float xor_sign(float a, uint32_t s) { return __uint_as_float(__float_as_
 // precomputed with the oracle's arithmetic): acceptance is then a property of the ray and the triangle, not of the tree —
 // Moeller-Trumbore alone accepts points well outside sliver triangles and, for near-parallel rays, at meaningless t.
 // The bounds are read only for hits the test above accepted.
-// tri_mt: the Moeller-Trumbore part; *p = the hit point o + t d the bounds predicate looks at
-MSK_DEV bool tri_mt(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, float tmin, float tmax, float *t, float *u, float *v, f3 *p) {
+// The test in two halves (tri_mt runs one after the other).
+// tri_candidate: everything up to the distance-range test — what almost every test of a leaf fails in; T, U, V still carry |den|
+struct TriCand { float T, U, V, den; };
+MSK_DEV bool tri_candidate(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, float tmin, float tmax, TriCand &c) {
     const f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z),
              ng = mk3(q3.x, q3.y, q3.z);
     const f3 C = v0 - o;
@@ -234,18 +236,38 @@ MSK_DEV bool tri_mt(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, floa
     if (!(den != 0.f && U >= 0.f && V >= 0.f && U + V <= abs_den)) return false;
     const float T = xor_sign(dot(ng, C), sgn);
     if (!(abs_den * tmin < T && T <= abs_den * tmax)) return false;
-    const float rcp = 1.f / abs_den;
-    *t = T * rcp;
-    *u = fmin_std(U * rcp, 1.f);
-    *v = fmin_std(V * rcp, 1.f);
-    *p = mk3(o.x + *t * d.x, o.y + *t * d.y, o.z + *t * d.z);
+    c.T = T; c.U = U; c.V = V; c.den = den;
     return true;
+}
+// tri_hit_point: the division; *p = the hit point o + t d the bounds predicate looks at
+MSK_DEV void tri_hit_point(const TriCand &c, f3 o, f3 d, float *t, float *u, float *v, f3 *p) {
+    const float rcp = 1.f / fabsf(c.den);
+    *t = c.T * rcp;
+    *u = fmin_std(c.U * rcp, 1.f);
+    *v = fmin_std(c.V * rcp, 1.f);
+    *p = mk3(o.x + *t * d.x, o.y + *t * d.y, o.z + *t * d.z);
+}
+// tri_mt: the Moeller-Trumbore part; *p = the hit point o + t d the bounds predicate looks at
+MSK_DEV bool tri_mt(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, float tmin, float tmax, float *t, float *u, float *v, f3 *p) {
+    TriCand c;
+    if (!tri_candidate(q0, q1, q2, q3, o, d, tmin, tmax, c)) return false;
+    tri_hit_point(c, o, d, t, u, v, p);
+    return true;
+}
+// the D10 predicate of a tree in HBM/L2: the hit point inside the triangle's padded bounds, recomputed from the record (see tri_test)
+MSK_DEV bool tri_in_bounds(float4 q0, float4 q1, float4 q2, f3 p, float pad) {
+    const f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);
+    const float px = p.x, py = p.y, pz = p.z;
+    const f3 w1 = v0 - e1, w2 = v0 + e2;
+    const float lox = fminf(fminf(v0.x, w1.x), w2.x) - pad, hix = fmaxf(fmaxf(v0.x, w1.x), w2.x) + pad;
+    const float loy = fminf(fminf(v0.y, w1.y), w2.y) - pad, hiy = fmaxf(fmaxf(v0.y, w1.y), w2.y) + pad;
+    const float loz = fminf(fminf(v0.z, w1.z), w2.z) - pad, hiz = fmaxf(fmaxf(v0.z, w1.z), w2.z) + pad;
+    return (px >= lox) & (px <= hix) & (py >= loy) & (py <= hiy) & (pz >= loz) & (pz <= hiz);
 }
 MSK_DEV bool tri_test(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, float tmin, float tmax,
                       float *t, float *u, float *v, const float4 *bounds, float pad) {
     f3 p;
     if (!tri_mt(q0, q1, q2, q3, o, d, tmin, tmax, t, u, v, &p)) return false;
-    const f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);
     const float px = p.x, py = p.y, pz = p.z;
     if (bounds) {                           // LDS-resident scene: precomputed, two LDS reads
         const float4 lo = bounds[0], hi = bounds[1];
@@ -255,11 +277,7 @@ MSK_DEV bool tri_test(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d, fl
     // (a compare + select pair each, 6.3 against 4.2 SIMD cycles): the two differ only in the sign of a zero result, which the
     // -/+ pad that follows erases (pad > 0; with pad == 0 the comparison against -0 is the one against +0).  The six comparisons
     // are combined without branches (as `&&` the compiler nests six exec regions: 19 VALU and 11 SALU instructions more per step).
-    const f3 w1 = v0 - e1, w2 = v0 + e2;
-    const float lox = fminf(fminf(v0.x, w1.x), w2.x) - pad, hix = fmaxf(fmaxf(v0.x, w1.x), w2.x) + pad;
-    const float loy = fminf(fminf(v0.y, w1.y), w2.y) - pad, hiy = fmaxf(fmaxf(v0.y, w1.y), w2.y) + pad;
-    const float loz = fminf(fminf(v0.z, w1.z), w2.z) - pad, hiz = fmaxf(fmaxf(v0.z, w1.z), w2.z) + pad;
-    return (px >= lox) & (px <= hix) & (py >= loy) & (py <= hiy) & (pz >= loz) & (pz <= hiz);
+    return tri_in_bounds(q0, q1, q2, p, pad);
 }
 
 // Reciprocal direction of the slab test: v_rcp_f32 (1 ulp) instead of an IEEE division (11 instructions each).  The slab
@@ -1090,6 +1108,11 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
     if (t.cur != DONE && (t.cur & MSK_LEAF_BIT)) {
         const uint32_t first = (t.cur & 0x7fffffffu) >> 5, cnt = t.cur & 31u;
         MSK_CNT(7, 1);
+        // (Round 5, measured and taken out again — commit 767b33c + the one after it hold the code: the two triangles of a leaf in two
+        // phases, tri_candidate for both and then ONE tail — division, hit point, D10 bounds, (t, prim) update: half of a triangle
+        // step's instructions, which a wave runs whenever one of its ~27 lanes gets that far — on whichever was a candidate, its
+        // record fetched again.  Same hits; 22 % fewer VALU instructions per leaf visit, three more loads: config-5 / config-3
+        // class renders +3.8 % / +1.8 %.)
         for (uint32_t i = 0; i < cnt; ++i) {
             MSK_CNT_WAVE(5); MSK_CNT(6, 1);
             const float4 *q = g.tris + (size_t) (first + i) * (MSK_OVF(MODE) ? 4 : 6);
@@ -1658,10 +1681,7 @@ struct DoneQueue { float4 *wl, *res; uint2 *id; };      // id: {film pixel, samp
 // a path's arithmetic is its own and its record is addressed by (pixel, sample).  What makes reading in any order legal
 // is the two-half region (RegionView): nothing this sweep writes is something it still has to read.
 struct SortScratch { uint16_t *perm; uint8_t *cls; };        // per wave: region_size entries each, or {nullptr, nullptr}
-// `always`: build the permutation whatever the region holds (a sweep split by class walks class ranges of it); cnt_out: the
-// class counts (sorted position p belongs to class q for start[q] <= p < start[q] + cnt[q])
-MSK_DEV bool sort_by_class(const PathState &st, const RegionView &in, const SortScratch &ss, uint32_t lane, bool always = false,
-                           uint32_t *cnt_out = nullptr) {
+MSK_DEV bool sort_by_class(const PathState &st, const RegionView &in, const SortScratch &ss, uint32_t lane) {
     uint32_t cnt[MSK_N_CLASSES] = {0u, 0u, 0u, 0u};
     for (uint32_t c0 = 0; c0 < in.n; c0 += MSK_WAVE) {
         const uint32_t c = c0 + lane;
@@ -1676,11 +1696,7 @@ MSK_DEV bool sort_by_class(const PathState &st, const RegionView &in, const Sort
     uint32_t n_present = 0;
 #pragma unroll
     for (uint32_t q = 0; q + 1 < MSK_N_CLASSES; ++q) n_present += cnt[q] ? 1u : 0u;
-    if (cnt_out) {
-#pragma unroll
-        for (uint32_t q = 0; q < MSK_N_CLASSES; ++q) cnt_out[q] = cnt[q];
-    }
-    if (n_present <= 1u && !always) return false;             // one material (misses aside): the region is read in slot order
+    if (n_present <= 1u) return false;                        // one material (misses aside): the region is read in slot order
     uint32_t start[MSK_N_CLASSES];
     start[0] = 0;
 #pragma unroll
@@ -1702,21 +1718,11 @@ MSK_DEV bool sort_by_class(const PathState &st, const RegionView &in, const Sort
 }
 
 // One shading sweep of region `wave` by its owner wave (see the file header); returns the region as the sweep leaves it.
-//
-// A sweep split by material class (round 5; PART 1 + PART 2 instead of PART 0).  The general variant holds the microfacet code's
-// registers (157 VGPRs, three waves per SIMD) for every chunk, although the class sort has already made the chunks uniform
-// and most of a mesh scene's hits are on its diffuse room.  With `PassParams::split` the sweep runs as TWO kernels:
-//   PART 1  k_shade_gen<*, true> compiled with AUX (124-VGPR diffuse code, four waves): the sorted region's class-0 range — hits
-//           on plain diffuse BSDFs (not two-sided, not textured: those are filed under class 1 at scene creation) — and, in a
-//           scene without an environment emitter, its misses (class 3: the path just ends); survivors are appended to the other
-//           half as always, how many is left in RegionCtl::part_s / part_n; count / half_ns still describe the input;
-//   PART 2  the general variant: the classes in between, starting from those counters, then the parked records, the regeneration
-//           and the region's bookkeeping.
-// Both sort the region themselves (two passes of ballots over 4 bytes per slot: cheaper than handing the permutation on).  A
-// path's arithmetic is its own and its record is addressed by (pixel, sample), so neither the split nor the order in which
-// the survivors land can change a bit (test_material_sorted_shading_changes_no_bit, the parity suite).  AUX: the state carries
-// {eta, nee pdf} (scenes with non-diffuse BSDFs): Russian roulette uses eta, and the pair is copied through.
-template <bool DIFFUSE_ONLY, bool AUX = !DIFFUSE_ONLY, int PART = 0>
+// (Round 5, measured and taken out again — commit 767b33c holds the code: the sweep as TWO kernels by material class, the sorted
+// region's plain-diffuse range and its misses by the diffuse code at four waves per SIMD, the classes in between + the sweep's
+// tail by the general variant.  Bit-identical, and slower: config-5 / config-3 class renders +4.5 % / +3.7 % — every region is
+// visited, sorted and its counters read and written twice, and two thin launches drain twice.)
+template <bool DIFFUSE_ONLY>
 MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, const DoneQueue &dq, const SortScratch &ss, const PathState &st,
                                 const PassParams &pp, uint32_t wave, uint32_t lane) {
     uint32_t n_queued = 0;
@@ -1726,9 +1732,8 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
     const uint32_t base_out = (wave * 2u + ((rc.half_ns & 1u) ^ 1u)) * pp.region_size;      // the other half
     const uint32_t last = pp.region_size - 1u;
     uint32_t cur_s = 0, cur_n = 0;                // survivors written so far: with a shadow ray (upwards from slot 0), without (downwards from `last`)
-    if (PART == 2) { cur_s = rc.part_s; cur_n = rc.part_n; }
     const uint32_t n_em = sc.n_emitters;
-    const bool one_emitter = n_em == 1 && (DIFFUSE_ONLY || sc.env_emitter < 0);      // one AREA emitter (a split sweep: no environment in the scene)
+    const bool one_emitter = n_em == 1 && (DIFFUSE_ONLY || sc.env_emitter < 0);      // one AREA emitter
     uint32_t n_done = 0, n_invalid = 0;
 
     // A chunk's state as it is loaded.  (Measured and rejected: issuing the NEXT chunk's loads before this one is shaded — legal
@@ -1739,20 +1744,9 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
     struct ChunkIn { uint2 id; float4 wl, thr, res, rd4, hit, contrib; float2 aux; };
     const uint32_t first_new = n_in - rc.n_new;      // live index of the first camera sample the last sweep started
     bool sorted = false;
-    // sorted positions this kernel shades: [p_begin, p_end) (+ [q_begin, n_in) for PART 1: the misses behind the other classes)
-    uint32_t p_begin = 0, p_end = n_in, q_begin = n_in;
-    if (PART != 0) {
-        uint32_t cnt[MSK_N_CLASSES];
-        sorted = sort_by_class(st, in, ss, lane, true, cnt);
-        const uint32_t misses_to_1 = sc.env_emitter < 0 ? cnt[3] : 0u;            // (a miss into an environment is the general variant's)
-        if (PART == 1) { p_end = cnt[0]; q_begin = n_in - misses_to_1; }
-        else { p_begin = cnt[0]; p_end = n_in - misses_to_1; }
-    } else if (!DIFFUSE_ONLY && ss.perm) sorted = sort_by_class(st, in, ss, lane);
-    // live index of the path at sorted position p (the slot order, or the material order); >= n_in: no path
-    auto live_index_at = [&](uint32_t p, uint32_t end) {
-        if (p >= end) return n_in;
-        return ((PART != 0 || !DIFFUSE_ONLY) && sorted) ? (uint32_t) ss.perm[p] : p;
-    };
+    if (!DIFFUSE_ONLY && ss.perm) sorted = sort_by_class(st, in, ss, lane);
+    // live index of the path at position p of the sweep (the slot order, or the material order)
+    auto live_index = [&](uint32_t p) { return (!DIFFUSE_ONLY && sorted && p < n_in) ? (uint32_t) ss.perm[p] : p; };
     auto load_chunk = [&](uint32_t c) {
         const uint32_t i = in.slot(c < n_in ? c : 0u);
         ChunkIn k;
@@ -1762,13 +1756,11 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
         k.contrib = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < in.ns) k.contrib = ld4<1>(st.contrib + i);                          // (whole chunks, but for the one the boundary falls in)
         k.aux = make_float2(1.f, 0.f);
-        if (AUX) k.aux = st.aux[i];
+        if (!DIFFUSE_ONLY) k.aux = st.aux[i];
         return k;
     };
-    // the chunks of [p_begin, p_end), then (PART 1) those of [q_begin, n_in)
-    for (uint32_t range = 0; range < (PART == 1 ? 2u : 1u); ++range)
-    for (uint32_t c0 = range ? q_begin : p_begin, c_end = range ? n_in : p_end; c0 < c_end; c0 += MSK_WAVE) {
-        const uint32_t c = live_index_at(c0 + lane, c_end);
+    for (uint32_t c0 = 0; c0 < n_in; c0 += MSK_WAVE) {
+        const uint32_t c = live_index(c0 + lane);
         const bool active = c < n_in;
         const bool shadow_in = c < in.ns;          // this path's last bounce sent a shadow ray (ns <= n_in)
         // ---- load
@@ -1782,7 +1774,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
             res = res + from4(cur.contrib);
         hit.w = __uint_as_float(__float_as_uint(hit.w) & MSK_PRIM_ID);
         float bs_pdf = -rd4.w;                                             // meaningful for depth > 1 (PathState::ray_d)
-        float eta = cur.aux.x, nee_pdf = cur.aux.y;                        // carried only with AUX
+        float eta = cur.aux.x, nee_pdf = cur.aux.y;                        // carried only by the general variant
         uint32_t depth = id.y >> MSK_DEPTH_SHIFT;
         const uint32_t s_own = id.y & MSK_SI_MASK;
         const f3 rd = mk3(rd4.x, rd4.y, rd4.z);
@@ -1839,7 +1831,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
                 }
                 // ---- Russian roulette (path.cpp:116-122)
                 if ((int) depth >= pp.rr_depth) {
-                    const float q = fmin_std(AUX ? max4(thr) * eta * eta : max4(thr), 0.95f);
+                    const float q = fmin_std(DIFFUSE_ONLY ? max4(thr) : max4(thr) * eta * eta, 0.95f);
                     const float u = counter_pair(key, 3 + 3 * (depth - 2) + 1).y;
                     if (u >= q) alive = false;
                     else thr = thr / q;
@@ -1915,7 +1907,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
                     d = d / dist;
                     const float dp = fabsf(dot(d, ln));
                     pdf *= (dp != 0.f) ? dist2 / dp : 0.f;
-                    if (AUX) nee_pdf = e0.w * ((dp != 0.f) ? (dist * dist) / dp : 0.f);   // shape.cpp:80-86
+                    if (!DIFFUSE_ONLY) nee_pdf = e0.w * ((dp != 0.f) ? (dist * dist) / dp : 0.f);   // shape.cpp:80-86
                     if (dot(d, ln) < 0.f && pdf != 0.f) {                  // area.cpp:39-44
                         emitter_val = (one_emitter ? le_one : emitter_radiance(tb, (int) e, wl)) / pdf;
                     } else {
@@ -2007,7 +1999,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
             st4<1>(st.wl + o, to4(wl)); st4<1>(st.thr + o, to4(thr)); st4<1>(st.res + o, to4(res));
             st4<4>(st.ray_o + o, new_o); st4<4>(st.ray_d + o, new_d);
             if (has_shadow) { st4<4>(st.sh + o, new_sh); st4<1>(st.contrib + o, to4(contrib)); }
-            if (AUX) st.aux[o] = make_float2(eta, nee_pdf);
+            if (!DIFFUSE_ONLY) st.aux[o] = make_float2(eta, nee_pdf);
         }
         cur_s += (uint32_t) __popcll(m_s); cur_n += (uint32_t) __popcll(m_n);
     }
@@ -2017,14 +2009,6 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
         const spec qwl = from4(dq.wl[lane]), qres = from4(dq.res[lane]);
         const uint2 qid = dq.id[lane];
         n_invalid += emit_record<DIFFUSE_ONLY>(sc, tb, pp, qwl, qres, qid.x, qid.y);       // (lane 0, which writes the counters back, is in here whenever anything is)
-    }
-    if constexpr (PART == 1) {
-        // the first kernel of a split sweep: the survivors so far; count / half_ns / n_new / next_sample stay the INPUT's for the second
-        if (lane == 0) {
-            rc.part_s = cur_s; rc.part_n = cur_n; rc.samples_done += n_done; rc.invalid += n_invalid;
-            pp.regions[wave] = rc;
-        }
-        return in;
     }
     // ---- regeneration: fill the free tail with new camera samples (integrator.cpp:103-116)
     const uint32_t n_free = pp.region_size - (cur_s + cur_n);
@@ -2085,7 +2069,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
         st4<1>(st.wl + o, to4(wl));                                      // thr = 1, res = 0: RegionCtl::n_new
         st4<4>(st.ray_o + o, make_float4(ow.x, ow.y, ow.z, k.near_clip * inv_z));
         st4<4>(st.ray_d + o, make_float4(dw.x, dw.y, dw.z, k.far_clip * inv_z));
-        if (AUX) st.aux[o] = make_float2(1.f, 0.f);
+        if (!DIFFUSE_ONLY) st.aux[o] = make_float2(1.f, 0.f);
     }
     }
     const uint32_t n_out = cur_s + cur_n + got;
@@ -2106,7 +2090,7 @@ MSK_DEV DoneQueue done_queue(float4 *base) {
     return dq;
 }
 
-template <bool LDS_TABLES, bool DIFFUSE_ONLY, int PART = 0>
+template <bool LDS_TABLES, bool DIFFUSE_ONLY>
 MSK_DEV void shade_gen_body(const DeviceScene &sc, const PathState &st, const PassParams &pp) {
     extern __shared__ float4 lds_dyn[];
     const SceneTables tb = stage_tables<LDS_TABLES>(sc, lds_dyn);
@@ -2114,12 +2098,12 @@ MSK_DEV void shade_gen_body(const DeviceScene &sc, const PathState &st, const Pa
     const uint32_t queue_f4 = LDS_TABLES ? tables_lds_float4s(sc) : 0u;                         // after the staged tables
     const DoneQueue dq = done_queue(lds_dyn + queue_f4);
     SortScratch ss{nullptr, nullptr};
-    if ((!DIFFUSE_ONLY || PART != 0) && pp.sort_scratch) {         // after the queues: per wave, 3 bytes per slot of a region (host: shade LDS plan)
+    if (!DIFFUSE_ONLY && pp.sort_scratch) {         // after the queues: per wave, 3 bytes per slot of a region (host: shade LDS plan)
         uint8_t *p = (uint8_t *) (lds_dyn + queue_f4 + (MSK_BLOCK / MSK_WAVE) * MSK_DONE_Q_F4) + (size_t) (threadIdx.x / MSK_WAVE) * 3u * pp.region_size;
         ss.perm = (uint16_t *) p; ss.cls = p + 2u * pp.region_size;
     }
     if (lwave >= pp.region_count) return;
-    shade_region<DIFFUSE_ONLY, PART != 0 || !DIFFUSE_ONLY, PART>(sc, tb, dq, ss, st, pp, pp.region_first + lwave, threadIdx.x & (MSK_WAVE - 1));
+    shade_region<DIFFUSE_ONLY>(sc, tb, dq, ss, st, pp, pp.region_first + lwave, threadIdx.x & (MSK_WAVE - 1));
 }
 template <bool LDS_TABLES, bool DIFFUSE_ONLY>
 __global__ void __launch_bounds__(MSK_BLOCK)
@@ -2145,18 +2129,6 @@ template <>
 __global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_shade_gen<true, true>(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<true, true>(sc, st, pp); }
 #endif
-
-// The two kernels of a sweep split by material class (shade_region, PART 1 / PART 2): the diffuse code at four waves per SIMD for
-// the sorted region's plain-diffuse range (and its misses), the general variant at three for the classes in between + the sweep's tail.
-#ifndef MSK_SHADE_SPLIT1_WAVES
-#define MSK_SHADE_SPLIT1_WAVES 4, 4
-#endif
-template <bool LDS_TABLES>
-__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_SHADE_SPLIT1_WAVES)))
-k_shade_split1(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<LDS_TABLES, true, 1>(sc, st, pp); }
-template <bool LDS_TABLES>
-__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_SHADE_GEN_WAVES)))
-k_shade_split2(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<LDS_TABLES, false, 2>(sc, st, pp); }
 
 // ------------------------------------------------------------------------------------------
 // k_wavefront: the iteration loop itself on the device, for scenes whose tree is staged in LDS.  A region is private to

@@ -174,13 +174,7 @@ k_tris(const unsigned long long *keys, uint32_t n, const float4 *tri_verts, cons
     uint32_t word = prim;
     if (class_shift) {                      // material class of the triangle's BSDF (msk_kernels.h: MSK_CLASS_SHIFT)
         const int bsdf = mesh_info[__float_as_uint(a.w)].x;
-        uint32_t cls = 0u;
-        if (bsdf >= 0 && (uint32_t) bsdf < n_bsdfs) {
-            const float4 r0 = bsdfs[(size_t) bsdf * bsdf_f4], r6 = bsdfs[(size_t) bsdf * bsdf_f4 + 6];
-            cls = (uint32_t) __float_as_int(r0.x);
-            // a diffuse BSDF that is two-sided or textured is the general shading variant's: filed under class 1 (msk_gpu.hip: shading_class)
-            if (cls == 0u && (__float_as_int(r0.y) >= 0 || __float_as_uint(r6.z) != 0u)) cls = 1u;
-        }
+        const uint32_t cls = (bsdf >= 0 && (uint32_t) bsdf < n_bsdfs) ? (uint32_t) __float_as_int(bsdfs[(size_t) bsdf * bsdf_f4].x) : 0u;
         word |= (cls & 3u) << class_shift;
     }
     float4 *t = tris + (size_t) k * 4;

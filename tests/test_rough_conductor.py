@@ -144,29 +144,24 @@ def test_material_sorted_shading_changes_no_bit(gpu_ctx, oracle, hostmirror, gol
     """k_shade_gen reads a region through its material-class permutation (MSK_SORT=1, the default) or in slot order
     (MSK_SORT=0): a path's arithmetic is its own and its record is addressed by (pixel, sample), so both give the
     oracle's film bit for bit — on a scene where conductors, diffuse walls and misses share every region, at a spp
-    that runs the multi-stream loop with full regions.  Sorted, the sweep runs as TWO kernels by default since round 5 (the plain
-    diffuse class and the misses by the diffuse code at four waves per SIMD, the rest by the general variant: shade_region
-    PART 1 / 2); MSK_SHADE_SPLIT=0 keeps it in one: three ways to the same bits."""
+    that runs the multi-stream loop with full regions."""
     flat = conductor_scene(hostmirror, golden_lookup, 96, 96, blob_res=40)
     g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
     prm = abi.render_params(spp=16, seed=3)
     ref, rst = o.render(prm, threads=8)
     films = {}
-    for sort, split in (("1", "1"), ("1", "0"), ("0", "1")):
+    for sort in ("1", "0"):
         monkeypatch.setenv("MSK_SORT", sort)
-        monkeypatch.setenv("MSK_SHADE_SPLIT", split)
-        films[sort + split], st = g.render(prm)
+        films[sort], st = g.render(prm)
         assert st.samples == rst.samples
-        assert np.array_equal(films[sort + split].view(np.uint32), ref.view(np.uint32)), (sort, split)
+        assert np.array_equal(films[sort].view(np.uint32), ref.view(np.uint32)), sort
     # many more samples than slots: every region full, sorted every sweep (the film of the unsorted run is the reference)
     big = abi.render_params(spp=700, seed=8)
     monkeypatch.setenv("MSK_SORT", "0")
     a, sa = g.render(big)
     monkeypatch.setenv("MSK_SORT", "1")
-    for split in ("1", "0"):
-        monkeypatch.setenv("MSK_SHADE_SPLIT", split)
-        b, sb = g.render(big)
-        assert sa.segments == sb.segments and sa.shadow_rays == sb.shadow_rays and sa.samples == sb.samples
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), split
+    b, sb = g.render(big)
+    assert sa.segments == sb.segments and sa.shadow_rays == sb.shadow_rays
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     g.close()
     o.close()
