@@ -1108,7 +1108,7 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
     if (t.cur != DONE && (t.cur & MSK_LEAF_BIT)) {
         const uint32_t first = (t.cur & 0x7fffffffu) >> 5, cnt = t.cur & 31u;
         MSK_CNT(7, 1);
-        // (Round 5, measured and taken out again — commit 767b33c + the one after it hold the code: the two triangles of a leaf in two
+        // (Round 5, built, measured and taken out again: the two triangles of a leaf in two
         // phases, tri_candidate for both and then ONE tail — division, hit point, D10 bounds, (t, prim) update: half of a triangle
         // step's instructions, which a wave runs whenever one of its ~27 lanes gets that far — on whichever was a candidate, its
         // record fetched again.  Same hits; 22 % fewer VALU instructions per leaf visit, three more loads: config-5 / config-3
