@@ -65,8 +65,9 @@ struct Built {
     //   dw 0-2 origin (low corner of the node's box), dw 3 scale (ONE power of two: the largest extent / scale lies in [1024, 2048))
     //   dw 4-5 lo.x, dw 6-7 lo.y, dw 8-9 lo.z, dw 10-11 hi.x, dw 12-13 hi.y, dw 14-15 hi.z: four fp16 each (slot s = half s),
     //          child box = [origin + lo * scale, origin + hi * scale], rounded OUTWARDS around the padded box of nodes4 (lo down,
-    //          hi up and never a subnormal; checked in exact arithmetic); dw 16-19 child refs; an unused slot holds lo = 65504, hi = 0
-    //          and the reference of an empty leaf.  Empty if a box cannot be represented.
+    //          hi up and never a subnormal; checked in exact arithmetic); dw 16-19 child refs — a leaf's as everywhere, an inner
+    //          child's as the BYTE offset of its node (index x 80); an unused slot holds lo = 65504, hi = 0 and the reference of an
+    //          empty leaf.  Empty if a box cannot be represented (or the tree has 2^31 / 80 nodes or more).
     std::vector<uint32_t> nodes4h;
     // 8-wide form with QUANTISED child boxes (collapse8): 32 dwords (128 B = one L2 line) per node,
     //   dw 0-2  origin (the low corner of the node's box)      dw 3  meta: bits 0-1 ordering axis, bits 8-15 mask of used slots
@@ -438,7 +439,9 @@ inline void Collapser::quantise_h(uint32_t me, const Slot *s, int ns, const uint
         }
     std::memcpy(&q[0], origin, 12); std::memcpy(&q[3], &scale, 4);
     for (int p = 0; p < 6; ++p) { q[4 + 2 * p] = (uint32_t) h[p][0] | ((uint32_t) h[p][1] << 16); q[5 + 2 * p] = (uint32_t) h[p][2] | ((uint32_t) h[p][3] << 16); }
-    for (int i = 0; i < 4; ++i) q[16 + i] = refs[i] == kEmpty4 ? 0x80000000u : refs[i];
+    // an inner child's reference is the BYTE offset of its node (index x 80: the visit's address without a multiplication);
+    // collapse4 drops the half-float twin for a tree of 2^31 / 80 nodes or more
+    for (int i = 0; i < 4; ++i) q[16 + i] = refs[i] == kEmpty4 ? 0x80000000u : (refs[i] & 0x80000000u) ? refs[i] : refs[i] * 80u;
 }
 static inline void collapse4(Built &b, bool optimal = true) {
     b.nodes4.clear(); b.nodes4q.clear(); b.nodes4h.clear(); b.root_ref4 = b.root_ref; b.max_depth4 = 0;
@@ -448,7 +451,7 @@ static inline void collapse4(Built &b, bool optimal = true) {
     b.root_ref4 = c.collapse(b.root_ref, 1);
     b.nodes4 = std::move(c.out);
     if (c.ok_q) b.nodes4q = std::move(c.out_q);
-    if (c.ok_h) b.nodes4h = std::move(c.out_h);
+    if (c.ok_h && c.out_h.size() / 20 < (1u << 31) / 80u) b.nodes4h = std::move(c.out_h);
     b.max_depth4 = c.max_depth;
 }
 

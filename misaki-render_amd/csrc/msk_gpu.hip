@@ -514,6 +514,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
             hipError_t eq = s->nodes4q.upload(bvh.nodes4h);
             if (eq != hipSuccess) { delete s; return fail(ctx, MSK_ERR_OOM, "scene upload: %s", hipGetErrorString(eq)); }
             ds.nodes4q = s->nodes4q.as<float4>();
+            if (!(ds.root_ref4 & MSK_LEAF_BIT)) ds.root_ref4 *= 80u;     // inner references of this form are byte offsets (msk_bvh.h: quantise_h)
             s->trace_mode = 6;
             s->tree_bytes = bvh.nodes4h.size() * 4;
         } else if (env_u32("MSK_QUANT_BVH", 2) && !bvh.nodes4q.empty()) {

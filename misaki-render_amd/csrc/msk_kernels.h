@@ -524,7 +524,7 @@ MSK_DEV __amdgpu_buffer_rsrc_t nodes4h_rsrc(const DeviceScene &sc) {
 template <bool OVF>
 MSK_DEV uint32_t node4h_step(__amdgpu_buffer_rsrc_t rsrc, uint32_t node, const Sel4q &sel, f3 idir, f3 oi, float tmin, float tcur,
                              const LaneStack<OVF> &stack, int &sp) {
-    const uint32_t base = node * 80u;
+    const uint32_t base = node;             // an inner node's reference IS its byte offset in this form (msk_bvh.h: quantise_h)
     const msk_u4 h0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base, 0, 0), h1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 16u, 0, 0);
     const msk_u4 h2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 32u, 0, 0), h3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 48u, 0, 0);
     const msk_u4 rf = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 64u, 0, 0);
