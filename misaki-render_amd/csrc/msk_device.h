@@ -65,14 +65,17 @@ MSK_DEV uint64_t msk_bits(double x) { return (uint64_t) __double_as_longlong(x);
 MSK_DEV double msk_from_bits(uint64_t b) { return __longlong_as_double((long long) b); }
 // The polynomial coefficients.  A v_fma_f64 takes its constant from an SGPR pair, and where the 41 of them come from decides
 // the shading kernel's register budget: as plain immediates the compiler hoists their materialisation out of the chunk loop
-// (~90 SGPRs live across the sweep: three waves instead of four); from constant memory (rounds 3-4: msk_det_* tables read by
-// scalar loads) the LOADS are hoisted the same way and the allocator parks them in VGPR lanes — 82 v_writelane before the loop
-// and two v_readlane, VALU instructions both, at every use inside it.  MSK_DET_CONST=1 (default since round 5): every use
-// materialises its constant on the spot with two s_mov_b32 of a literal (SALU: no VALU slot, no memory, two SGPRs for the
-// length of one fma) behind an `asm volatile`, which is what keeps it from being hoisted.  Same values as oracle_math.h's
-// literals either way (the compiler's correctly rounded quotients).
+// (~90 SGPRs live across the sweep: three waves instead of four); from constant memory (MSK_DET_CONST=0, the default: msk_det_*
+// tables read by scalar loads) the LOADS are hoisted the same way — in rounds 3-4 the allocator then parked them in VGPR lanes,
+// 82 v_writelane before the loop and two v_readlane, VALU instructions both, at every use inside it; since the kernel's cold
+// arguments are read where they are used (msk_kernels.h: MSK_COLD_KARGS, round 5) most of them stay in SGPRs: 50 + 63 spill
+// moves in k_shade_gen<true, true>, 3 690 VALU instructions.  Built and measured in round 5, not the default: MSK_DET_CONST=1
+// materialises every constant on the spot with two s_mov_b32 of a literal (SALU) behind an `asm volatile` (29 + 29 spill moves,
+// but 3 826 VALU instructions and the volatile statements pin the schedule: bench step 32.1-32.5 ms against 32.0), =2 the
+// same as a plain asm that takes the polynomial's variable as an unused input (cannot be hoisted, may be scheduled: 45 + 49
+// spill moves, 3 898 VALU).  Same values as oracle_math.h's literals either way (the compiler's correctly rounded quotients).
 #ifndef MSK_DET_CONST
-#define MSK_DET_CONST 1
+#define MSK_DET_CONST 0
 #endif
 __constant__ double msk_det_sin[8] = {-1.0 / 355687428096000.0, 1.0 / 1307674368000.0, -1.0 / 6227020800.0, 1.0 / 39916800.0,
                                       -1.0 / 362880.0, 1.0 / 5040.0, -1.0 / 120.0, 1.0 / 6.0};
@@ -81,39 +84,45 @@ __constant__ double msk_det_cos[8] = {1.0 / 20922789888000.0, -1.0 / 87178291200
 __constant__ double msk_det_ath[9] = {1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0, 1.0 / 5.0, 1.0 / 3.0};
 __constant__ double msk_det_che[6] = {1.0 / 479001600.0, 1.0 / 3628800.0, 1.0 / 40320.0, 1.0 / 720.0, 1.0 / 24.0, 0.5};
 __constant__ double msk_det_cho[6] = {1.0 / 6227020800.0, 1.0 / 39916800.0, 1.0 / 362880.0, 1.0 / 5040.0, 1.0 / 120.0, 1.0 / 6.0};
-template <uint64_t BITS> MSK_DEV double det_lit() {
+template <uint64_t BITS> MSK_DEV double det_lit(double dep) {
     if constexpr (BITS == 0x3fe0000000000000ull || BITS == 0xbfe0000000000000ull) return __builtin_bit_cast(double, BITS);     // +-0.5: inline constants
     int lo, hi;
-    asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "i"((int) (uint32_t) BITS), "i"((int) (uint32_t) (BITS >> 32)));
+    if (MSK_DET_CONST == 2) {
+        const int dep_lo = __double2loint(dep);
+        asm("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "i"((int) (uint32_t) BITS), "i"((int) (uint32_t) (BITS >> 32)), "v"(dep_lo));
+    } else {
+        asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "i"((int) (uint32_t) BITS), "i"((int) (uint32_t) (BITS >> 32)));
+    }
     return __hiloint2double(hi, lo);
 }
-// coefficient I of table T, whose value is the constant expression E (the same expression the table is initialised with)
-#define MSK_K(T, I, E) (MSK_DET_CONST ? det_lit<__builtin_bit_cast(uint64_t, (double) (E))>() : T[I])
+// coefficient I of table T, whose value is the constant expression E (the same expression the table is initialised with); D: the
+// polynomial's variable (see det_lit)
+#define MSK_K(T, I, E, D) (MSK_DET_CONST ? det_lit<__builtin_bit_cast(uint64_t, (double) (E))>(D) : T[I])
 // Every polynomial step is ONE fused multiply-add (IEEE fma: one rounding, the same bits from std::fma on the host and
 // v_fma_f64 on the device, whatever -ffp-contract says); the series are cut where the next term is below 2e-16 of the result on
 // the reduced range, i.e. the fp64 value is accurate to a few ulps of a double before its single rounding to fp32.
 MSK_DEV double det_sin_poly(double y) {   // |y| <= pi/4 (+ulps): y - y z (1/3! - z/5! + ... ), z = y^2; next term (pi/4)^19/19! = 8e-20
     const double z = y * y;
-    double p = MSK_K(msk_det_sin, 0, -1.0 / 355687428096000.0);                    // -1/17!
-    p = __builtin_fma(p, z, MSK_K(msk_det_sin, 1, 1.0 / 1307674368000.0));                 //  1/15!
-    p = __builtin_fma(p, z, MSK_K(msk_det_sin, 2, -1.0 / 6227020800.0));                   // -1/13!
-    p = __builtin_fma(p, z, MSK_K(msk_det_sin, 3, 1.0 / 39916800.0));                      //  1/11!
-    p = __builtin_fma(p, z, MSK_K(msk_det_sin, 4, -1.0 / 362880.0));                       // -1/9!
-    p = __builtin_fma(p, z, MSK_K(msk_det_sin, 5, 1.0 / 5040.0));                          //  1/7!
-    p = __builtin_fma(p, z, MSK_K(msk_det_sin, 6, -1.0 / 120.0));                          // -1/5!
-    p = __builtin_fma(p, z, MSK_K(msk_det_sin, 7, 1.0 / 6.0));                             //  1/3!   (sign folded below)
+    double p = MSK_K(msk_det_sin, 0, -1.0 / 355687428096000.0, z);                    // -1/17!
+    p = __builtin_fma(p, z, MSK_K(msk_det_sin, 1, 1.0 / 1307674368000.0, z));                 //  1/15!
+    p = __builtin_fma(p, z, MSK_K(msk_det_sin, 2, -1.0 / 6227020800.0, z));                   // -1/13!
+    p = __builtin_fma(p, z, MSK_K(msk_det_sin, 3, 1.0 / 39916800.0, z));                      //  1/11!
+    p = __builtin_fma(p, z, MSK_K(msk_det_sin, 4, -1.0 / 362880.0, z));                       // -1/9!
+    p = __builtin_fma(p, z, MSK_K(msk_det_sin, 5, 1.0 / 5040.0, z));                          //  1/7!
+    p = __builtin_fma(p, z, MSK_K(msk_det_sin, 6, -1.0 / 120.0, z));                          // -1/5!
+    p = __builtin_fma(p, z, MSK_K(msk_det_sin, 7, 1.0 / 6.0, z));                             //  1/3!   (sign folded below)
     return __builtin_fma(-(y * z), p, y);
 }
 MSK_DEV double det_cos_poly(double y) {   // next term (pi/4)^18/18! = 2e-18
     const double z = y * y;
-    double p = MSK_K(msk_det_cos, 0, 1.0 / 20922789888000.0);                      //  1/16!
-    p = __builtin_fma(p, z, MSK_K(msk_det_cos, 1, -1.0 / 87178291200.0));                  // -1/14!
-    p = __builtin_fma(p, z, MSK_K(msk_det_cos, 2, 1.0 / 479001600.0));                     //  1/12!
-    p = __builtin_fma(p, z, MSK_K(msk_det_cos, 3, -1.0 / 3628800.0));                      // -1/10!
-    p = __builtin_fma(p, z, MSK_K(msk_det_cos, 4, 1.0 / 40320.0));                         //  1/8!
-    p = __builtin_fma(p, z, MSK_K(msk_det_cos, 5, -1.0 / 720.0));                          // -1/6!
-    p = __builtin_fma(p, z, MSK_K(msk_det_cos, 6, 1.0 / 24.0));                            //  1/4!
-    p = __builtin_fma(p, z, MSK_K(msk_det_cos, 7, -0.5));                                  // -1/2!
+    double p = MSK_K(msk_det_cos, 0, 1.0 / 20922789888000.0, z);                      //  1/16!
+    p = __builtin_fma(p, z, MSK_K(msk_det_cos, 1, -1.0 / 87178291200.0, z));                  // -1/14!
+    p = __builtin_fma(p, z, MSK_K(msk_det_cos, 2, 1.0 / 479001600.0, z));                     //  1/12!
+    p = __builtin_fma(p, z, MSK_K(msk_det_cos, 3, -1.0 / 3628800.0, z));                      // -1/10!
+    p = __builtin_fma(p, z, MSK_K(msk_det_cos, 4, 1.0 / 40320.0, z));                         //  1/8!
+    p = __builtin_fma(p, z, MSK_K(msk_det_cos, 5, -1.0 / 720.0, z));                          // -1/6!
+    p = __builtin_fma(p, z, MSK_K(msk_det_cos, 6, 1.0 / 24.0, z));                            //  1/4!
+    p = __builtin_fma(p, z, MSK_K(msk_det_cos, 7, -0.5, z));                                  // -1/2!
     return __builtin_fma(z, p, 1.0);
 }
 // quadrant reduction of an fp32 angle (|phi| < 2^20 pi/2): phi = k pi/2 + y, |y| <= pi/4
@@ -152,15 +161,15 @@ MSK_DEV double det_atanh_d(double xd) {
     if (n > r2 * d) { n = n * 0.5; e += 1; }
     else if (d > r2 * n) { d = d * 0.5; e -= 1; }
     const double s = (n - d) / (n + d), z = s * s;
-    double p = MSK_K(msk_det_ath, 0, 1.0 / 19.0);
-    p = __builtin_fma(p, z, MSK_K(msk_det_ath, 1, 1.0 / 17.0));
-    p = __builtin_fma(p, z, MSK_K(msk_det_ath, 2, 1.0 / 15.0));
-    p = __builtin_fma(p, z, MSK_K(msk_det_ath, 3, 1.0 / 13.0));
-    p = __builtin_fma(p, z, MSK_K(msk_det_ath, 4, 1.0 / 11.0));
-    p = __builtin_fma(p, z, MSK_K(msk_det_ath, 5, 1.0 / 9.0));
-    p = __builtin_fma(p, z, MSK_K(msk_det_ath, 6, 1.0 / 7.0));
-    p = __builtin_fma(p, z, MSK_K(msk_det_ath, 7, 1.0 / 5.0));
-    p = __builtin_fma(p, z, MSK_K(msk_det_ath, 8, 1.0 / 3.0));
+    double p = MSK_K(msk_det_ath, 0, 1.0 / 19.0, z);
+    p = __builtin_fma(p, z, MSK_K(msk_det_ath, 1, 1.0 / 17.0, z));
+    p = __builtin_fma(p, z, MSK_K(msk_det_ath, 2, 1.0 / 15.0, z));
+    p = __builtin_fma(p, z, MSK_K(msk_det_ath, 3, 1.0 / 13.0, z));
+    p = __builtin_fma(p, z, MSK_K(msk_det_ath, 4, 1.0 / 11.0, z));
+    p = __builtin_fma(p, z, MSK_K(msk_det_ath, 5, 1.0 / 9.0, z));
+    p = __builtin_fma(p, z, MSK_K(msk_det_ath, 6, 1.0 / 7.0, z));
+    p = __builtin_fma(p, z, MSK_K(msk_det_ath, 7, 1.0 / 5.0, z));
+    p = __builtin_fma(p, z, MSK_K(msk_det_ath, 8, 1.0 / 3.0, z));
     p = __builtin_fma(p, z, 1.0);
     return __builtin_fma((double) e, 0.5 * 0.69314718055994528623, s * p);
 }
@@ -173,19 +182,19 @@ MSK_DEV double det_cosh_d(double xd) {
     const double ln2_lo  = 1.90821492927058770002e-10;
     const double k = __builtin_rint(xd * inv_ln2);
     const double r = __builtin_fma(-k, ln2_lo, __builtin_fma(-k, ln2_hi, xd)), w = r * r;
-    double E = MSK_K(msk_det_che, 0, 1.0 / 479001600.0);             // 1/12!
-    E = __builtin_fma(E, w, MSK_K(msk_det_che, 1, 1.0 / 3628800.0));
-    E = __builtin_fma(E, w, MSK_K(msk_det_che, 2, 1.0 / 40320.0));
-    E = __builtin_fma(E, w, MSK_K(msk_det_che, 3, 1.0 / 720.0));
-    E = __builtin_fma(E, w, MSK_K(msk_det_che, 4, 1.0 / 24.0));
-    E = __builtin_fma(E, w, MSK_K(msk_det_che, 5, 0.5));
+    double E = MSK_K(msk_det_che, 0, 1.0 / 479001600.0, w);             // 1/12!
+    E = __builtin_fma(E, w, MSK_K(msk_det_che, 1, 1.0 / 3628800.0, w));
+    E = __builtin_fma(E, w, MSK_K(msk_det_che, 2, 1.0 / 40320.0, w));
+    E = __builtin_fma(E, w, MSK_K(msk_det_che, 3, 1.0 / 720.0, w));
+    E = __builtin_fma(E, w, MSK_K(msk_det_che, 4, 1.0 / 24.0, w));
+    E = __builtin_fma(E, w, MSK_K(msk_det_che, 5, 0.5, w));
     E = __builtin_fma(E, w, 1.0);
-    double O = MSK_K(msk_det_cho, 0, 1.0 / 6227020800.0);            // 1/13!
-    O = __builtin_fma(O, w, MSK_K(msk_det_cho, 1, 1.0 / 39916800.0));
-    O = __builtin_fma(O, w, MSK_K(msk_det_cho, 2, 1.0 / 362880.0));
-    O = __builtin_fma(O, w, MSK_K(msk_det_cho, 3, 1.0 / 5040.0));
-    O = __builtin_fma(O, w, MSK_K(msk_det_cho, 4, 1.0 / 120.0));
-    O = __builtin_fma(O, w, MSK_K(msk_det_cho, 5, 1.0 / 6.0));
+    double O = MSK_K(msk_det_cho, 0, 1.0 / 6227020800.0, w);            // 1/13!
+    O = __builtin_fma(O, w, MSK_K(msk_det_cho, 1, 1.0 / 39916800.0, w));
+    O = __builtin_fma(O, w, MSK_K(msk_det_cho, 2, 1.0 / 362880.0, w));
+    O = __builtin_fma(O, w, MSK_K(msk_det_cho, 3, 1.0 / 5040.0, w));
+    O = __builtin_fma(O, w, MSK_K(msk_det_cho, 4, 1.0 / 120.0, w));
+    O = __builtin_fma(O, w, MSK_K(msk_det_cho, 5, 1.0 / 6.0, w));
     O = __builtin_fma(O, w, 1.0);
     const double ro = r * O;
     const long long ki = (long long) k;
