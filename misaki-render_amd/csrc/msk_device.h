@@ -70,10 +70,10 @@ MSK_DEV double msk_from_bits(uint64_t b) { return __longlong_as_double((long lon
 // 82 v_writelane before the loop and two v_readlane, VALU instructions both, at every use inside it; since the kernel's cold
 // arguments are read where they are used (msk_kernels.h: MSK_COLD_KARGS, round 5) most of them stay in SGPRs: 50 + 63 spill
 // moves in k_shade_gen<true, true>, 3 690 VALU instructions.  Built and measured in round 5, not the default: MSK_DET_CONST=1
-// materialises every constant on the spot with two s_mov_b32 of a literal (SALU) behind an `asm volatile` (29 + 29 spill moves,
-// but 3 826 VALU instructions and the volatile statements pin the schedule: bench step 32.1-32.5 ms against 32.0), =2 the
-// same as a plain asm that takes the polynomial's variable as an unused input (cannot be hoisted, may be scheduled: 45 + 49
-// spill moves, 3 898 VALU).  Same values as oracle_math.h's literals either way (the compiler's correctly rounded quotients).
+// materialises every constant on the spot with two s_mov_b32 of a literal (SALU) behind an `asm volatile` (45 + 49 spill moves,
+// but 3 898 VALU instructions and the volatile statements pin the schedule: bench step 32.1-32.5 ms against 32.0), =2 the
+// same as a plain asm that takes the polynomial's variable as an unused input (cannot be hoisted, may be scheduled: the same
+// counts).  Same values as oracle_math.h's literals either way (the compiler's correctly rounded quotients).
 #ifndef MSK_DET_CONST
 #define MSK_DET_CONST 0
 #endif

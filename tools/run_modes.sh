@@ -1,10 +1,11 @@
 #!/bin/bash
-# tools/run_modes.sh : the whole `-m gpu` suite once per optional mode of the GPU library (greedy collapse, 128-byte nodes, 8-wide
-# tree, device-built tree, no material sort + one stream, nothing staged in LDS), ON THE GPU BOX from the repo root:
+# tools/run_modes.sh : the whole `-m gpu` suite once per optional mode of the GPU library (greedy collapse, 128-byte nodes, rounds
+# 3-4's byte-quantised 64-byte nodes with the binned builder, 8-wide tree, device-built tree, no material sort + one stream, nothing
+# staged in LDS, the det_* coefficients as literals is a BUILD variant and not in this list), ON THE GPU BOX from the repo root:
 #   gpurun --timeout 1200 -- 'bash tools/run_modes.sh'      -> gpurun_out/modes.txt (two lines per mode)
 mkdir -p gpurun_out
 : > gpurun_out/modes.txt
-for m in "MSK_COLLAPSE_OPTIMAL=0" "MSK_QUANT_BVH=0" "MSK_WIDE_BVH=8" "MSK_BVH_BUILD=gpu" "MSK_SORT=0 MSK_STREAMS=1" "MSK_LDS_SCENE_KB=0"; do
+for m in "MSK_COLLAPSE_OPTIMAL=0" "MSK_QUANT_BVH=0" "MSK_QUANT_BVH=1 MSK_BVH_SWEEP=0 MSK_TRACE_QUANTUM=4" "MSK_WIDE_BVH=8" "MSK_BVH_BUILD=gpu" "MSK_SORT=0 MSK_STREAMS=1" "MSK_LDS_SCENE_KB=0"; do
   echo "== $m" >> gpurun_out/modes.txt
   env $m timeout -k 10 400 python -m pytest tests -x -q -m gpu > gpurun_out/modes_last.txt 2>&1
   rc=$?
