@@ -555,7 +555,10 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
                                 (ds.n_emitters * 95 + 3) / 4 + (ds.cdf_len + 3) / 4 + 72) * 16;
     s->lds_tables = table_bytes <= 40 * 1024;
     // + the waves' done-queues (k_shade_gen: MSK_DONE_Q_F4 float4 per wave)
-    s->shade_lds_bytes = (s->lds_tables ? table_bytes : 0) + (size_t) (MSK_BLOCK / MSK_WAVE) * MSK_DONE_Q_F4 * 16;
+    // (a scene whose per-triangle tables stay in HBM still stages the small ones: msk_kernels.h, small_tables_float4s — the same formula)
+    const size_t small_bytes = ((size_t) ds.n_meshes + ds.n_bsdf_f4 + ds.n_emitters * 2 + (ds.n_emitters * 95 + 3) / 4 + (ds.cdf_len + 3) / 4 + 72) * 16;
+    const size_t small_staged = small_bytes <= (size_t) MSK_SMALL_TABLES_KB * 1024 ? small_bytes : 0;
+    s->shade_lds_bytes = (s->lds_tables ? table_bytes : small_staged) + (size_t) (MSK_BLOCK / MSK_WAVE) * MSK_DONE_Q_F4 * 16;
     if (s->trace_lds_bytes > ctx->prop.sharedMemPerBlock) {
         delete s;
         return fail(ctx, MSK_ERR_UNSUPPORTED, "BVH depth %d needs %zu B of traversal stack per block", bvh.max_depth, stack_bytes);

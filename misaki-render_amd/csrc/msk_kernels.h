@@ -1282,26 +1282,41 @@ struct SceneTables {
 MSK_DEV uint32_t tables_lds_float4s(const DeviceScene &sc) {
     return sc.n_tris * 6 + sc.n_meshes + sc.n_bsdf_f4 + sc.n_emitters * 2 + (sc.n_emitters * 95 + 3) / 4 + (sc.cdf_len + 3) / 4 + 72;
 }
+// A scene whose per-triangle tables do not fit LDS can still keep the SMALL ones there (mesh / BSDF / texture / emitter records, the
+// emitters' D65 tables and area CDFs, the CIE table: every bounce and every finished sample looks several of them up through
+// dependent indices): MSK_SMALL_TABLES_KB (compile time, default 16; 0 = all tables from HBM/L2 as in rounds 1-4).  0: not staged.
+#ifndef MSK_SMALL_TABLES_KB
+#define MSK_SMALL_TABLES_KB 16
+#endif
+MSK_DEV uint32_t small_tables_float4s(const DeviceScene &sc) {
+    const uint32_t n = sc.n_meshes + sc.n_bsdf_f4 + sc.n_emitters * 2 + (sc.n_emitters * 95 + 3) / 4 + (sc.cdf_len + 3) / 4 + 72;
+    return n * 16u <= MSK_SMALL_TABLES_KB * 1024u ? n : 0u;
+}
 template <bool LDS_TABLES>
 MSK_DEV SceneTables stage_tables(const DeviceScene &sc, float4 *lds) {
     SceneTables t;
     t.tri_normals = sc.tri_normals; t.tri_uvs = sc.tri_uvs;
-    if (!LDS_TABLES) {
-        t.tri_verts = sc.tri_verts; t.tri_frames = sc.tri_frames; t.mesh_info = sc.mesh_info; t.bsdfs = sc.bsdfs; t.emitters = sc.emitters;
-        t.emitter_d65 = sc.emitter_d65; t.cdf = sc.cdf; t.cie = sc.cie;
-        return t;
-    }
     float4 *p = lds;
     auto copy4 = [&](const float4 *src, uint32_t n) { for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) p[i] = src[i]; float4 *r = p; p += n; return r; };
     auto copy1 = [&](const float *src, uint32_t n) { float *d = (float *) p; for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = src[i]; p += (n + 3) / 4; return d; };
-    t.tri_verts = copy4(sc.tri_verts, sc.n_tris * 3);
-    t.tri_frames = copy4(sc.tri_frames, sc.n_tris * 3);
+    if (!LDS_TABLES) {
+        t.tri_verts = sc.tri_verts; t.tri_frames = sc.tri_frames;
+        if (lds == nullptr || small_tables_float4s(sc) == 0u) {
+            t.mesh_info = sc.mesh_info; t.bsdfs = sc.bsdfs; t.emitters = sc.emitters;
+            t.emitter_d65 = sc.emitter_d65; t.cdf = sc.cdf; t.cie = sc.cie;
+            return t;
+        }
+    } else {
+        t.tri_verts = copy4(sc.tri_verts, sc.n_tris * 3);
+        t.tri_frames = copy4(sc.tri_frames, sc.n_tris * 3);
+    }
     t.mesh_info = (const int4 *) copy4((const float4 *) sc.mesh_info, sc.n_meshes);
     t.bsdfs = copy4(sc.bsdfs, sc.n_bsdf_f4);
     t.emitters = copy4(sc.emitters, sc.n_emitters * 2);
     t.emitter_d65 = copy1(sc.emitter_d65, sc.n_emitters * 95);
     t.cdf = copy1(sc.cdf, sc.cdf_len);
     t.cie = copy1(sc.cie, 285);
+    // (Round 5, measured and taken out: the area emitters' triangles — what every NEE sample reads — staged beside them: +-0.)
     __syncthreads();
     return t;
 }
@@ -2095,7 +2110,7 @@ MSK_DEV void shade_gen_body(const DeviceScene &sc, const PathState &st, const Pa
     extern __shared__ float4 lds_dyn[];
     const SceneTables tb = stage_tables<LDS_TABLES>(sc, lds_dyn);
     const uint32_t lwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
-    const uint32_t queue_f4 = LDS_TABLES ? tables_lds_float4s(sc) : 0u;                         // after the staged tables
+    const uint32_t queue_f4 = LDS_TABLES ? tables_lds_float4s(sc) : small_tables_float4s(sc);   // after the staged tables
     const DoneQueue dq = done_queue(lds_dyn + queue_f4);
     SortScratch ss{nullptr, nullptr};
     if (!DIFFUSE_ONLY && pp.sort_scratch) {         // after the queues: per wave, 3 bytes per slot of a region (host: shade LDS plan)
