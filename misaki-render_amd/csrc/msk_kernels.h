@@ -213,6 +213,8 @@ MSK_DEV void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 MSK_DEV float xor_sign(float a, uint32_t s) { return __uint_as_float(__float_as_uint(a) ^ s); }
+MSK_DEV float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+MSK_DEV float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 // Embree 3 Moeller-Trumbore, restated (see oracle/oracle.cpp header for the derivation);
 // tmax is the ray's ORIGINAL far bound.
@@ -909,6 +911,11 @@ k_trace(DeviceScene sc, PathState st, PassParams pp) { trace_chunks<MODE>(sc, st
 // stream for both.  The shadow results wait in an LDS bit per slot until the slot's extension ray writes the hit record.
 // Same per-ray arithmetic as traverse(): same hits, bit for bit.
 // ------------------------------------------------------------------------------------------
+// MSK_TQ_SEL: the LDS-resident tree's slabs ordered by address instead of by v_min / v_max (see the inner-node loop)
+#ifndef MSK_TQ_SEL
+#define MSK_TQ_SEL 1
+#endif
+
 template <bool ANY>
 MSK_DEV void trace_queue(const DeviceScene &sc, const TraceLds &g, const PathState &st, const RegionView &rv, const LaneStack<false> &stack,
                          uint32_t n_jobs, uint32_t sub, uint32_t split, uint32_t *unocc_bits, uint32_t lane, uint32_t refill) {
@@ -926,6 +933,8 @@ MSK_DEV void trace_queue(const DeviceScene &sc, const TraceLds &g, const PathSta
     uint32_t bp = MSK_NO_PRIM, cur = DONE;
     int sp = 0;
     bool occluded = false;
+    struct { uint32_t nx, ny, nz, fx, fy, fz; } sel = {0u, 8u, 16u, 24u, 32u, 40u};
+    (void) sel;
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         if (next < my_total && ((uint32_t) __popcll(idle) >= refill || idle == ~0ull)) {
@@ -939,6 +948,12 @@ MSK_DEV void trace_queue(const DeviceScene &sc, const TraceLds &g, const PathSta
                     o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z);
                     tmin = ro.w; tfar = ANY ? rd.w : slot_tmax(rd.w);
                     idir = slab_idir(d); oi = mk3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
+#if MSK_TQ_SEL
+                    // node = [lo.x pair, lo.y pair | lo.z pair, hi.x pair | hi.y pair, hi.z pair | refs]: byte offsets 0 8 16 24 32 40
+                    sel.nx = idir.x < 0.f ? 24u : 0u; sel.fx = sel.nx ^ 24u;
+                    sel.ny = idir.y < 0.f ? 32u : 8u; sel.fy = sel.ny ^ 40u;
+                    sel.nz = idir.z < 0.f ? 40u : 16u; sel.fz = sel.nz ^ 56u;
+#endif
                     bt = tfar; bu = 0.f; bv = 0.f; bp = MSK_NO_PRIM; sp = 0; occluded = false;
                     cur = sc.n_tris ? sc.root_ref : DONE;
                     active = true;
@@ -955,14 +970,36 @@ MSK_DEV void trace_queue(const DeviceScene &sc, const TraceLds &g, const PathSta
             // -1.5 % alone and unchanged beside the shading kernel.  Round 4, with registers to spare (58 VGPRs since the build
             // stopped pairing scalar arithmetic, __graft_entry__.HIPCC_FLAGS): the stack's top entry in a register, refilled
             // from LDS behind the pop — 59 VGPRs, trace alone 16.4 vs 15.9 ms, step unchanged.)
-            const float4 *n = g.nodes + (size_t) cur * 4;
-            const float4 a = n[0], b = n[1], cc = n[2], m = n[3];
-            float t0, t1;
-            const bool h0 = box_test(a.x, a.z, b.x, b.z, cc.x, cc.z, idir, oi, tmin, bt, &t0);
-            const bool h1 = box_test(a.y, a.w, b.y, b.w, cc.y, cc.w, idir, oi, tmin, bt, &t1);
-            const uint32_t c0 = __float_as_uint(m.x), c1 = __float_as_uint(m.y);
+            float t0, t1; bool h0, h1; uint32_t c0, c1;
+#if MSK_TQ_SEL
+            // near / far plane PAIRS by LDS address (round 5): the node's 12 planes are six float pairs {child 0, child 1}; the ray
+            // holds, per axis, the byte offset of its near pair (lo or hi, by the sign of its direction) and of its far pair: six
+            // 8-byte reads instead of three 16-byte ones, and no v_min / v_max to order the slabs (12 of a visit's ~56 VALU instructions)
+            {
+                const char *nb = (const char *) g.nodes + ((size_t) cur << 6);
+                const float2 nx = *(const float2 *) (nb + sel.nx), ny = *(const float2 *) (nb + sel.ny), nz = *(const float2 *) (nb + sel.nz);
+                const float2 fx = *(const float2 *) (nb + sel.fx), fy = *(const float2 *) (nb + sel.fy), fz = *(const float2 *) (nb + sel.fz);
+                const uint2 m = *(const uint2 *) (nb + 48);
+                // (max_raw / min_raw: v_max_f32 / v_min_f32 as they are — fmaxf against a value that came from memory makes the compiler
+                // quiet a possible signalling NaN first, one more v_max per use; tmin and bt are never NaN)
+                t0 = fmaxf(fmaxf(__fmaf_rn(nx.x, idir.x, -oi.x), __fmaf_rn(ny.x, idir.y, -oi.y)), max_raw(__fmaf_rn(nz.x, idir.z, -oi.z), tmin));
+                t1 = fmaxf(fmaxf(__fmaf_rn(nx.y, idir.x, -oi.x), __fmaf_rn(ny.y, idir.y, -oi.y)), max_raw(__fmaf_rn(nz.y, idir.z, -oi.z), tmin));
+                const float e0 = fminf(fminf(__fmaf_rn(fx.x, idir.x, -oi.x), __fmaf_rn(fy.x, idir.y, -oi.y)), min_raw(__fmaf_rn(fz.x, idir.z, -oi.z), bt));
+                const float e1 = fminf(fminf(__fmaf_rn(fx.y, idir.x, -oi.x), __fmaf_rn(fy.y, idir.y, -oi.y)), min_raw(__fmaf_rn(fz.y, idir.z, -oi.z), bt));
+                h0 = t0 <= e0 * 1.0000004f; h1 = t1 <= e1 * 1.0000004f;
+                c0 = m.x; c1 = m.y;
+            }
+#else
+            {
+                const float4 *n = g.nodes + (size_t) cur * 4;
+                const float4 a = n[0], b = n[1], cc = n[2], m = n[3];
+                h0 = box_test(a.x, a.z, b.x, b.z, cc.x, cc.z, idir, oi, tmin, bt, &t0);
+                h1 = box_test(a.y, a.w, b.y, b.w, cc.y, cc.w, idir, oi, tmin, bt, &t1);
+                c0 = __float_as_uint(m.x); c1 = __float_as_uint(m.y);
+            }
+#endif
             if (h0 && h1) {
-                const bool swap = t1 < t0;
+                const bool swap = t1 < t0;            // (nearest first for the any-hit queue too: node order instead measured +-0, round 5)
                 cur = swap ? c1 : c0;
                 stack.push(sp, swap ? c0 : c1);
             } else if (h0) { cur = c0; }
