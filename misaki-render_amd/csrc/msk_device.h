@@ -14,6 +14,46 @@
 
 namespace msk {
 
+// 1.f / sqrtf(x), the two correctly rounded operations of render/srgb.h:16, for 1 <= x < 2^100 WITHOUT the compiler's expansions
+// (v_sqrt_f32 + two next-up / next-down residual checks + denormal scaling = 16 instructions, then v_div_scale x 2, v_rcp_f32, five
+// fma, v_div_fmas, v_div_fixup = 11: ~105 SIMD cycles by tools/micro/valu_ops.hip): one v_rsq_f32 seeds BOTH the square root
+// (Markstein's coupled iteration, the last fma rounds) and the reciprocal of that root (two residual steps, the last fma rounds)
+// — 1 transcendental + 2 multiplies + 1 add + 10 fma, ~40 cycles.  x = v * v + 1 is never below 1, so nothing here can be subnormal.
+// Correct rounding is not argued but CHECKED: tools/micro/ieee_fast_check.hip compares this function with the compiler's
+// 1.f / __builtin_sqrtf(x) on every one of the 2^32 bit patterns (tests/test_ieee_fast.py, -m gpu), the guard included.
+#ifndef MSK_FAST_RSQRT
+#define MSK_FAST_RSQRT 1
+#endif
+MSK_DEV float rsqrt_ieee_1_to_2p100(float x) {
+    const float r = __builtin_amdgcn_rsqf(x);
+    float s = x * r, h = .5f * r;
+    const float e = __fmaf_rn(-h, s, .5f);
+    s = __fmaf_rn(s, e, s); h = __fmaf_rn(h, e, h);
+    s = __fmaf_rn(__fmaf_rn(-s, s, x), h, s);                  // = sqrtf(x)
+    float y = h + h;
+    y = __fmaf_rn(__fmaf_rn(-s, y, 1.f), y, y);
+    // the last step: for a root with an all-ones mantissa (one x per binade) y is a power of two, the residual 2^-24 exactly and
+    // y + e y an exact tie that rounds to even, while the true quotient y (1 + e + e^2 ...) lies just above it: that root takes
+    // the next float up.  (Feeding the product y's successor instead — no compare — breaks 2 400 other inputs.)
+    y = __fmaf_rn(__fmaf_rn(-s, y, 1.f), y, y);
+    y = __uint_as_float(__float_as_uint(y) + (((__float_as_uint(s) & 0x7fffffu) == 0x7fffffu) ? 1u : 0u));
+    return y;                                                   // = 1.f / sqrtf(x)
+}
+// (Round 5, measured and taken out again: sqrtf alone the same way for 2^-40 <= x < 2^40 — the first half of the above, exact on
+// every bit pattern —, and a vector / float or spectrum / float as ONE reciprocal + refinement and five instructions per numerator
+// for operands in [2^-40, 2^40), where v_div_scale / v_div_fmas / v_div_fixup do nothing, so that the compiler's own expansion
+// is reproduced — exact on 2^32 random and 4 x 10^8 structured operand sets.  Bench step, config-3 / config-5 class renders with
+// this function alone: 31.5 / 142.0 / 116.9 ms; with the square root as well: 31.5 / 141.6 / 118.1; with all three: 31.5 / 141.8 /
+// 118.4 (nothing compiled by hand: 31.9 / 142.6 / 117.5): their guards — six or seven compares — eat what they save.)
+// any x: the fast form where it is proven, the compiler's otherwise (a NaN fails the comparison)
+MSK_DEV float rsqrt_ieee(float x) {
+#if MSK_FAST_RSQRT
+    if (x >= 1.f && x < 0x1p100f) return rsqrt_ieee_1_to_2p100(x);
+#endif
+    return 1.f / __builtin_sqrtf(x);
+}
+
+
 struct f3 { float x, y, z; };
 struct f2 { float x, y; };
 struct spec { float v[4]; };   // Spectrum / Wavelength (core/fwd.h:40-41)
@@ -316,11 +356,22 @@ MSK_DEV float wavelength_weight(float lam) {
 MSK_DEV spec srgb_model_eval(float c0, float c1, float c2, spec wl) {
     if (__builtin_isinf(c2)) return splat(__builtin_copysignf(1.f, c2) * .5f + .5f);
     spec r;
+    float x[4], v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = (c0 * wl.v[i] + c1) * wl.v[i] + c2; x[i] = v[i] * v[i] + 1.f; }
+#if MSK_FAST_RSQRT
+    // one guard for the four wavelengths: every x is >= 1 or a NaN (v * v >= 0), so their sum is below 2^100 exactly when none is
+    // a NaN, an infinity or that large — the slow form is compiled once, behind a branch no lane of a sane scene takes
+    if ((x[0] + x[1]) + (x[2] + x[3]) < 0x1p100f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.v[i] = fmax_std(.5f * v[i] * rsqrt_ieee_1_to_2p100(x[i]) + .5f, 0.f);
+        return r;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float v = (c0 * wl.v[i] + c1) * wl.v[i] + c2;
-        float rsqrt = 1.f / __builtin_sqrtf(v * v + 1.f);
-        r.v[i] = fmax_std(.5f * v * rsqrt + .5f, 0.f);
+        float rsqrt = 1.f / __builtin_sqrtf(x[i]);
+        r.v[i] = fmax_std(.5f * v[i] * rsqrt + .5f, 0.f);
     }
     return r;
 }
@@ -369,7 +420,7 @@ MSK_DEV f3 sample_ggx(f2 sample, float au, float av, float *pdf_out) {
     float cs = cos_phi_m / au, sn = sin_phi_m / av;
     float alpha_sqr = 1.f / (cs * cs + sn * sn);
     float tan_theta_m_sqr = alpha_sqr * sample.x / (1.f - sample.x);
-    float cos_theta_m = 1.f / __builtin_sqrtf(1.f + tan_theta_m_sqr);
+    float cos_theta_m = rsqrt_ieee(1.f + tan_theta_m_sqr);
     float tmp = 1 + tan_theta_m_sqr / alpha_sqr;
     float pdf = MSK_INV_PI_F / (au * av * cos_theta_m * cos_theta_m * cos_theta_m * tmp * tmp);
     if (pdf < 1e-20f) pdf = 0;
