@@ -1792,7 +1792,11 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
     // with two-half regions — costs 30 VGPRs = one wave per SIMD and is slower, 21.6 vs 20.7 ms of shading per bench step.  Round 3:
     // the same through LDS-DMA (global_load_lds_dwordx4 of wl / thr / res into 3 KB of LDS per wave while the current chunk is
     // shaded, read back before the chunk's stores): the 12 registers that carry the values across the loop edge push the kernel
-    // to 145 VGPRs, and held at 128 it spills 80 bytes: shading 21.8 vs 17.7 ms alone, step 39.4 vs 36.1 ms; films identical.)
+    // to 145 VGPRs, and held at 128 it spills 80 bytes: shading 21.8 vs 17.7 ms alone, step 39.4 vs 36.1 ms; films identical.
+    // Round 5: the next chunk's lines only PULLED INTO L2 while this one is shaded — one discarded dword per lane and array, six
+    // more load instructions and one register (128 VGPRs, four waves, no scratch): shading 22.8 vs 20.8 ms alone, step 34.2 vs
+    // 32.5 ms, config-5 class 122.7 vs 119.8 ms.  More requests make it slower, earlier ones do not make it faster: what the
+    // kernel waits for is the memory system's throughput on this read / write mix, not the latency of its loads.)
     struct ChunkIn { uint2 id; float4 wl, thr, res, rd4, hit, contrib; float2 aux; };
     const uint32_t first_new = n_in - rc.n_new;      // live index of the first camera sample the last sweep started
     bool sorted = false;
