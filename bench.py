@@ -326,6 +326,34 @@ def profile_single_stream(pm):
     return out
 
 
+def stream_yardstick(roof):
+    """What THIS box's HBM gives plain streaming kernels, measured now (misaki-render_amd/lib/msk_hbm_stream, built by
+    __graft_entry__.build from tools/micro/hbm_stream.hip; a child process, 0.3 s): read-only, write-only, copy, and `soa7` — a
+    kernel of the shading sweep's access shape (one wave per region, 1 KB per step from each of seven arrays and to each of
+    seven others, non-temporal) without any arithmetic.  `roofline.peak` stays the guide's 8 TB/s; this is the practical ceiling
+    next to it: `shade_vs_soa7` = the shading kernel's single-stream HBM rate of the committed profile / soa7's."""
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "misaki-render_amd", "lib", "msk_hbm_stream")
+    if not os.path.exists(exe):
+        return None
+    try:
+        p = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+        rates = {}
+        for line in p.stdout.splitlines():
+            f = line.split()
+            if len(f) >= 3 and f[2] == "GB/s" and f[0] not in rates:
+                rates[f[0]] = float(f[1])
+        if p.returncode != 0 or "soa7" not in rates:
+            return {"error": (p.stdout + p.stderr)[-200:]}
+        y = {"unit": "GB/s", "read": rates.get("read"), "write": rates.get("write"), "copy": rates.get("copy"), "soa7": rates["soa7"],
+             "what": "streaming kernels without arithmetic on this box, measured in this run; soa7 = the shading sweep's access shape"}
+        shade = ((roof.get("per_kernel_single_stream_profile") or {}).get("k_shade_gen") or {}).get("achieved")
+        if shade:
+            y["shade_vs_soa7"] = round(shade / rates["soa7"], 3)
+        return y
+    except Exception as e:                      # never let the yardstick cost the bench line
+        return {"error": str(e)[:200]}
+
+
 def roofline(stats, args):
     """`roofline` of the JSON line from the HIP events the library records around its launches on its own streams.
     Algorithmic bytes of the SoA path state each kernel must move; a "segment" is a slot that is live after a
@@ -579,6 +607,8 @@ def main():
         if dt_hbm is not None:
             out["ms_per_step_film_in_hbm"] = round(dt_hbm / args.steps * 1e3, 3)
             out["value_film_in_hbm"] = round(samples_step * args.steps / dt_hbm / 1e6, 2)
+        if n_gpus == 1 and not rehearsal:
+            out["roofline"]["stream_yardstick"] = stream_yardstick(out["roofline"])
         # the measured headline is safe on stderr before anything slower or riskier runs (CPU baselines, other configs)
         print("bench.py headline (extras follow on stdout): " + json.dumps(out), file=sys.stderr, flush=True)
         compact = {}                    # scalars that ride in `config`: the driver's parser keeps `config`, `roofline` and `cpu_baseline`
