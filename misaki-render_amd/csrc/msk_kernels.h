@@ -1735,6 +1735,13 @@ struct DoneQueue { float4 *wl, *res; uint2 *id; };      // id: {film pixel, samp
 // selection — instead of every chunk paying for every BSDF some lane of it needs.  Results do not depend on the order:
 // a path's arithmetic is its own and its record is addressed by (pixel, sample).  What makes reading in any order legal
 // is the two-half region (RegionView): nothing this sweep writes is something it still has to read.
+// (Round 5, measured and taken out: the sort inside consecutive WINDOWS of 128 / 256 / 512 live paths instead of over the whole
+// region — so that a window's chunks read the same few KB of every state array one after the other instead of every second
+// or third 16-byte piece of the region's 32 KB per array (the general variant fetches 2.4x the bytes it writes): config-3 /
+// config-5 class renders 145.2 / 145.7 / 144.3 and 118.5 / 118.5 / 118.4 ms against 144.6 and 117.4 — the pieces a chunk leaves
+// of a sector are L2 hits for the chunk that takes them, windows or not.  On these two scenes the sort itself is worth nothing any
+// more since the small tables moved to LDS (MSK_SORT=0: 146.1 / 117.8 ms; shading alone 65.8 vs 66.6 ms); it stays for the
+// scenes it was built for — several materials on surfaces of similar area: tools/divergence_probe.py)
 struct SortScratch { uint16_t *perm; uint8_t *cls; };        // per wave: region_size entries each, or {nullptr, nullptr}
 MSK_DEV bool sort_by_class(const PathState &st, const RegionView &in, const SortScratch &ss, uint32_t lane) {
     uint32_t cnt[MSK_N_CLASSES] = {0u, 0u, 0u, 0u};
