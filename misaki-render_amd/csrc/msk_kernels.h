@@ -1806,7 +1806,11 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
     // Round 5: the next chunk's lines only PULLED INTO L2 while this one is shaded — one discarded dword per lane and array, six
     // more load instructions and one register (128 VGPRs, four waves, no scratch): shading 22.8 vs 20.8 ms alone, step 34.2 vs
     // 32.5 ms, config-5 class 122.7 vs 119.8 ms.  More requests make it slower, earlier ones do not make it faster: what the
-    // kernel waits for is the memory system's throughput on this read / write mix, not the latency of its loads.)
+    // kernel waits for is the memory system's throughput on this read / write mix, not the latency of its loads.  The same for
+    // the per-triangle TABLES of a scene that keeps them in HBM: the next chunk's prim words loaded early (the traversal has
+    // written them) and its tri_verts / tri_frames / tri_normals records pulled towards L2 at the end of this chunk, so that the
+    // dependent gathers overlap the next chunk's state loads — 163 VGPRs, three waves, same films: config-5 / config-3 class
+    // 120.3 / 144.0 ms against 116.4 / 140.8, shading alone 40.0 vs 37.3 ms.)
     struct ChunkIn { uint2 id; float4 wl, thr, res, rd4, hit, contrib; float2 aux; };
     const uint32_t first_new = n_in - rc.n_new;      // live index of the first camera sample the last sweep started
     bool sorted = false;
