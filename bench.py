@@ -53,13 +53,18 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=SPP_PER_GPU, help="spp per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
-                    help="skip the config 3 / 4 / 5 class renders that N = 1 adds under `other_configs`")
+                    help="skip the config 3 / 4 / 5 class renders that N = 1 adds under `other_configs`, and the sharded config 4 / 5 runs of N > 1")
+    ap.add_argument("--c4-spp", type=int, default=4096, help="N > 1: total spp of the config-4 run that follows the headline (rehearsals use less)")
+    ap.add_argument("--c5-spp", type=int, default=1024, help="N > 1: total spp of the config-5-class run that follows the headline")
     ap.add_argument("--shard", choices=("samples", "tiles"), default="samples",
                     help="N > 1: which axis the ranks split (misaki-render_amd/multigpu.py); both end in one film reduce")
     ap.add_argument("--balance", action="store_true",
                     help="N > 1: after the warm-up, re-split the samples in proportion to the ranks' measured speed (default: equal split)")
     ap.add_argument("--in-process", type=int, default=0, metavar="N",
                     help="one process, N devices behind one msk_ctx (msk_gpu_init(ids, N) + k_film_sum) instead of one process per GPU")
+    ap.add_argument("--cpus", type=int, default=0, metavar="C",
+                    help="restrict this process (and the ranks it spawns: they share the set) to the first C CPUs of its affinity mask "
+                         "before anything touches a GPU — the host-side waits under a CPU quota (tools/cpu_contention.py, DESIGN.md §7)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: launch, rendezvous (gloo), reduce and timing only")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks (or --in-process members) that ALL render on cuda:0, the ranks reducing over gloo through host "
@@ -144,6 +149,24 @@ def _cgroup_cpu_quota():
         return None if quota[0] == "max" else round(int(quota[0]) / int(quota[1]), 2)
     except Exception:
         return None
+
+
+def _thread_cpu():
+    """{tid: (comm, cpu seconds)} of this process's threads (/proc/self/task): who burns the host CPU during a step."""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                f = open(f"/proc/self/task/{tid}/stat").read()
+                comm = f[f.index("(") + 1:f.rindex(")")]
+                rest = f[f.rindex(")") + 2:].split()
+                out[int(tid)] = (comm, (int(rest[11]) + int(rest[12])) / tick)
+            except Exception:
+                pass
+    except Exception:
+        pass
+    return out
 
 
 def _oracle():
@@ -289,6 +312,95 @@ def other_configs(abi, hm, ctx):
             sc.close()
         except Exception as e:                                       # reported, never fatal for the headline line
             out.append({"workload": name, "tag": tag or "c4_1gpu", "error": str(e)[:300]})
+    return out
+
+
+SHARDED_CONFIGS = (
+    # tag, workload, scene maker (hostmirror attribute, arguments), film (w, h), shard, option holding the total spp
+    ("c4", "BASELINE config 4: cbox 1920x1080 @ {spp} spp, pixel-tile shard across {n} ranks + one film reduce", ("cbox_scene", (1920, 1080)), (1920, 1080), "tiles", "c4_spp"),
+    ("c5", "BASELINE config 5 class: 146 k-triangle rough-dielectric mesh 1024x1024 @ {spp} spp, sample shard across {n} ranks + one film reduce",
+     ("teapot_class_scene", (1024,)), (1024, 1024), "samples", "c5_spp"),
+)
+
+
+def sharded_configs(args, abi, hm, mg, ctx, dist, rank, world, rehearsal, fence):
+    """N > 1 only, after the headline, EVERY rank: BASELINE configs 4 and 5 as BASELINE words them — config 4 (cbox 1920x1080,
+    4096 spp) as a pixel-tile shard (rank r renders the spiral blocks id = r mod N at the full sample count), config 5 class
+    (the 146 k-triangle dielectric mesh, 1024 x 1024, 1024 spp) as a sample shard — each ending in the same ONE film reduce
+    onto rank 0 and rank 0's copy-back as the headline step.  The total work is the config's (fixed): these are strong-scaling
+    points.  One untimed render (workspace, plan), then two timed steps between fences, the maximum over the ranks.  Returns
+    scalars for `config` on rank 0 (c4_msamples_per_s, c4_ms, c4_shard, ...), {} elsewhere.  --dry-run: the same sequence on
+    host tensors of the films' shapes, no render."""
+    import torch
+    out = {}
+    steps = 2
+    for tag, what, (maker, margs), (w, h), shard, opt in SHARDED_CONFIGS:
+        spp = getattr(args, opt)
+        scene, err = None, None
+        try:
+            if args.dry_run:
+                film = torch.ones((h, w, 5), dtype=torch.float32)
+            else:
+                import numpy as np
+                flat = getattr(hm, maker)(*margs)
+                scene = abi.Scene(ctx, flat)
+                prm = mg.shard_params(abi, spp, rank, world, mode=shard, seed=0)
+                film = torch.zeros((h, w, 5), dtype=torch.float32, device="cuda")
+                host_film = np.zeros((h, w, 5), np.float32)
+                host_t = torch.from_numpy(host_film)
+                scene.render_device(prm, film.data_ptr())        # untimed: workspace, plan (no collective: a failure here is local)
+        except Exception as e:
+            err = str(e)[:200]
+        # every rank learns whether every rank is ready BEFORE the first collective of this config: a rank that could not set
+        # the config up (out of memory, say) must not leave the others waiting inside a reduce
+        ready = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device="cpu" if (rehearsal or args.dry_run) else "cuda")
+        dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+        if float(ready.item()) < 1.0:
+            if rank == 0:
+                out[tag + "_error"] = err or "another rank could not set this config up"
+            if scene is not None:
+                scene.close()
+            continue
+
+        def step():
+            if args.dry_run:
+                film.fill_(1.0)
+                mg.reduce_film(film, dist)
+                return None
+            st = scene.render_device(prm, film.data_ptr())
+            if rehearsal:
+                host = film.cpu()
+                mg.reduce_film(host, dist)
+                if rank == 0:
+                    host_t.copy_(host)
+            else:
+                mg.reduce_film(film, dist)
+                if rank == 0:
+                    host_t.copy_(film)
+            return st
+        fence()
+        t0 = time.perf_counter()
+        sts = [step() for _ in range(steps)]
+        fence()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if (rehearsal or args.dry_run) else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        if rank == 0:
+            samples = w * h * spp
+            out[tag + "_msamples_per_s"] = None if args.dry_run else round(samples * steps / dt / 1e6, 1)
+            out[tag + "_ms"] = round(dt / steps * 1e3, 2)
+            out[tag + "_shard"] = shard
+            out[tag + "_spp"] = spp
+            out[tag + "_workload"] = what.format(spp=spp, n=world)[:118]
+            if args.dry_run:
+                out[tag + "_reduce_ok"] = bool((film == float(world)).all())
+            else:
+                out[tag + "_film_finite"] = bool(np.isfinite(host_film).all())
+                out[tag + "_rank0_passes"] = int(sts[-1].passes)
+                out[tag + "_weight_per_sample"] = round(float(host_film[..., 4].astype(np.float64).sum()) / samples, 6)
+        if scene is not None:
+            scene.close()
     return out
 
 
@@ -443,6 +555,8 @@ def roofline(stats, args):
 
 def main():
     args = parse_args()
+    if args.cpus > 0 and "WORLD_SIZE" not in os.environ:         # (a spawned rank inherits the launcher's set)
+        os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:args.cpus])
     if args.in_process and args.gpus > 1:
         print("bench.py: --in-process N and --gpus N are two different multi-GPU paths; give one", file=sys.stderr)
         sys.exit(2)
@@ -563,8 +677,24 @@ def main():
             prm = mg.shard_params(abi, spp_total, rank, world, mode="range", shares=shares, seed=0)
             step()                       # untimed: the new shares' plan and record buffers are set up here
             balance = {"equal_split_kernel_ms": [round(t, 2) for t in times], "spp_shares": shares}
+    import resource
+    ru0, th0 = resource.getrusage(resource.RUSAGE_SELF), _thread_cpu()
     dt, stats = timed(step, args.steps)
+    ru1, th1 = resource.getrusage(resource.RUSAGE_SELF), _thread_cpu()
+    by_thread = sorted(((round(c - th0.get(t, (n, 0.0))[1], 3), n, t == os.getpid()) for t, (n, c) in th1.items()), reverse=True)
+    # host CPU this rank's process spent inside the timed region (every thread: the library's loop, its waits, the runtime's helpers)
+    cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
+    host_side = {"cpus_allowed": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": _cgroup_cpu_quota(),
+                 "cpu_s_per_step": round(cpu_s / max(args.steps, 1), 5), "cpus_busy": round(cpu_s / max(dt, 1e-9), 3),
+                 "wait": os.environ.get("MSK_WAIT", "library default"), "host_threads": os.environ.get("MSK_HOST_THREADS", "library default"),
+                 "busiest_threads": [f"{n}{' (main)' if m else ''}: {c} s" for c, n, m in by_thread[:4] if c > 0],
+                 "what": "user + system CPU time of rank 0's process over the timed region / its wall time"}
 
+    # N > 1: the sharded config 4 / 5 runs — every rank takes part; rank 0 first puts the headline on stderr (below)
+    sharded = {}
+    run_sharded = world > 1 and not args.no_other_configs
+    if run_sharded and (rank != 0 or args.dry_run):
+        sharded = sharded_configs(args, abi, hm, mg, ctx, dist, rank, world, rehearsal, fence)
     if rank == 0 and args.dry_run:
         ok = bool((film == float(world)).all())
         print(json.dumps({"metric": "Msamples/s (paths x spp) on cbox@512spp", "value": None, "unit": "Msamples/s", "n_gpus": world,
@@ -573,7 +703,7 @@ def main():
                           "config": {"workload": "none (launch / rendezvous / reduce only)", "samples_per_step": WIDTH * HEIGHT * spp_total,
                                      "shard": args.shard if world > 1 else "none",
                                      "rccl_ranks": dist.get_world_size() if dist is not None else 1, "devices_seen": n_dev,
-                                     "balanced": balance is not None}, "balance": balance}),
+                                     "balanced": balance is not None, **sharded}, "balance": balance}),
               flush=True)
     elif not args.dry_run:
         # the same K steps with the film left in HBM (every rank takes part: the steps hold collectives)
@@ -601,7 +731,7 @@ def main():
                        "devices_seen": n_dev, "balanced": balance is not None},
             # what the step's clock covers (integrator.cpp:43-78 is the reference's scope): since round 4 `value` includes the film's
             # copy-back to the host (rounds 1-3: film left in HBM = `value_film_in_hbm`, the figure to compare across rounds)
-            "timing_scope": "incl_copyback", "balance": balance,
+            "timing_scope": "incl_copyback", "balance": balance, "host_side": host_side,
             "roofline": roofline(stats, args),
         }
         if dt_hbm is not None:
@@ -611,6 +741,8 @@ def main():
             out["roofline"]["stream_yardstick"] = stream_yardstick(out["roofline"])
         # the measured headline is safe on stderr before anything slower or riskier runs (CPU baselines, other configs)
         print("bench.py headline (extras follow on stdout): " + json.dumps(out), file=sys.stderr, flush=True)
+        if run_sharded:
+            sharded = sharded_configs(args, abi, hm, mg, ctx, dist, rank, world, rehearsal, fence)
         compact = {}                    # scalars that ride in `config`: the driver's parser keeps `config`, `roofline` and `cpu_baseline`
         if not args.no_cpu_baseline and n_gpus == 1:
             try:
@@ -639,6 +771,7 @@ def main():
                 if "value" in e:
                     compact[e["tag"] + "_msamples_per_s"] = e["value"]
         out["config"].update(compact)       # c3 / c5 / c4_1gpu _msamples_per_s, l2_max, cpu_config1_msamples_per_s
+        out["config"].update(sharded)       # N > 1: c4_* / c5_* of the sharded config 4 / 5 runs
         if "cpu_baseline_all_threads" in out:
             out["config"]["cpu_all_threads_msamples_per_s"] = out["cpu_baseline_all_threads"]["value"]
         print(json.dumps(out), flush=True)

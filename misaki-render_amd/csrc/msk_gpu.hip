@@ -45,6 +45,8 @@ struct msk_ctx {
     uint32_t timing_phase = 0;         // which sync groups carry timing events rotates from render to render (MSK_TIMING_EVERY);
                                        // a context is used by one host thread at a time (msk_gpu.h), so a plain counter
     bool lost = false;                 // the watchdog gave up on a render (msk_watchdog.h): every later call fails at once, shutdown releases host memory only
+    mskwd::Hub *hub = nullptr;         // what the host functions of MSK_WAIT=callback signal; leaked with a lost context (msk_watchdog.h)
+    hipEvent_t wait_events[MSK_MAX_STREAMS] = {};      // MSK_WAIT=event: hipEventBlockingSync events, one per part of the pool
     uint32_t device_sharers = 1;       // member contexts of a group that sit on this context's device (repeated ordinals): their
                                        // renders run side by side, each plans its record buffers within 1 / device_sharers of the free HBM
 };
@@ -88,6 +90,7 @@ struct DevBuf {
         return v.empty() ? hipSuccess : hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
     }
     template <typename T> T *as() const { return (T *) p; }
+    void leak() { p = nullptr; bytes = 0; }        // a lost context: hipFree would wait for a kernel that never finishes; the memory goes with the process
 };
 
 static uint32_t env_u32(const char *name, uint32_t def);
@@ -147,6 +150,8 @@ extern "C" int msk_gpu_init(const int *device_ids, int n, msk_ctx **out_ctx) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     for (int k = 0; k < MSK_MAX_STREAMS - 1; ++k) if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->more_streams[k], hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void **) &ctx->h_ctrl, MSK_MAX_STREAMS * sizeof(Ctrl), hipHostMallocDefault);
+    ctx->hub = new mskwd::Hub();
+    for (int k = 0; k < MSK_MAX_STREAMS; ++k) if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->wait_events[k], hipEventBlockingSync | hipEventDisableTiming);
     if (e != hipSuccess) {
         int rc = fail(nullptr, MSK_ERR_HIP, "msk_gpu_init: %s", hipGetErrorString(e));
         msk_gpu_shutdown(ctx);             // releases whichever of stream / pinned block exist
@@ -167,14 +172,17 @@ extern "C" void msk_gpu_shutdown(msk_ctx *ctx) {
     if (!ctx) return;
     if (ctx->group) { group_shutdown(ctx); return; }
     if (ctx->lost) { delete ctx; return; }          // a stream that holds a kernel which never finished: destroying it would wait for it
+                                                    // (ctx->hub stays: a host function queued behind that kernel may still fire)
     (void) hipSetDevice(ctx->device);
     for (auto ev : ctx->events) (void) hipEventDestroy(ev);
+    for (auto ev : ctx->wait_events) if (ev) (void) hipEventDestroy(ev);
     for (int k = 0; k < MSK_MAX_STREAMS - 1; ++k) {
         for (auto ev : ctx->more_events[k]) (void) hipEventDestroy(ev);
         if (ctx->more_streams[k]) (void) hipStreamDestroy(ctx->more_streams[k]);
     }
     if (ctx->h_ctrl) (void) hipHostFree(ctx->h_ctrl);
-    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);      // (waits for what the stream holds: every host function has fired)
+    delete ctx->hub;
     delete ctx;
 }
 
@@ -188,9 +196,11 @@ extern "C" int msk_gpu_describe(const msk_ctx *ctx, char *buf, uint64_t buf_size
         snprintf(buf, (size_t) buf_size, "%zu devices [%s], sample-sharded, film summed on device %d; each: %s", ctx->group->ctxs.size(), ids.c_str(), ctx->device, one);
         return MSK_OK;
     }
-    snprintf(buf, (size_t) buf_size, "%s (%s), %d CUs, %.1f GiB HBM, LDS/block %zu KiB; libmsk_gpu ABI %d, fp-contract off",
+    snprintf(buf, (size_t) buf_size, "%s (%s), %d CUs, %.1f GiB HBM, LDS/block %zu KiB; libmsk_gpu ABI %d, fp-contract off; host side: "
+             "%u loop thread(s) per render, wait = %s",
              ctx->prop.name, ctx->prop.gcnArchName, ctx->prop.multiProcessorCount,
-             ctx->prop.totalGlobalMem / 1073741824.0, ctx->prop.sharedMemPerBlock / 1024, MSK_ABI_VERSION);
+             ctx->prop.totalGlobalMem / 1073741824.0, ctx->prop.sharedMemPerBlock / 1024, MSK_ABI_VERSION,
+             std::max(1u, env_u32("MSK_HOST_THREADS", 1)), mskwd::wait_mode_name(mskwd::wait_mode_from_env()));
     return MSK_OK;
 }
 
@@ -636,6 +646,7 @@ struct StateBufs {
         st.contrib = contrib.as<float4>(); st.hit = hit.as<float4>(); st.aux = aux.as<float2>();
         return hipSuccess;
     }
+    void leak() { for (DevBuf *b : {&id, &wl, &thr, &res, &ray_o, &ray_d, &sh, &contrib, &hit, &aux, &counts, &ctrl}) b->leak(); for (DevBuf &b : stack_ovf) b.leak(); }
 };
 
 struct Workspace {
@@ -687,6 +698,28 @@ static void sum_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, float 
     for (auto &p : v) { float t = 0; if (p.first && p.second && hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) *ms += t; }
 }
 
+// Every wait of a render for its device outside the wavefront loop (which has wait_any): the wait mode of MSK_WAIT and the wall
+// limit of MSK_WATCHDOG_S x `limit_scale` (the loop's limit is per sync group — a few milliseconds of work; MSK_RNG_PCG_BLOCK
+// renders in ONE kernel that legitimately runs for as long as the job takes, and passes 30: an hour at the default).  A wait
+// that runs out loses the context exactly as one inside the loop does.  Calling thread only.
+static int ctx_sync(msk_ctx *ctx, hipStream_t stream, const char *what, double limit_scale = 1.0) {
+    mskwd::Limits lim = mskwd::limits_from_env();
+    lim.wall_s *= limit_scale;
+    const mskwd::Progress p(lim);
+    const mskwd::Waiter w{mskwd::wait_mode_from_env(), ctx->hub};
+    mskwd::Ticket t;
+    t.stream = stream; t.slot = 0; t.event = ctx->wait_events[0];
+    HIP_TRY(ctx, mskwd::arm(w, t));
+    mskwd::Ticket *tp = &t;
+    hipError_t es = hipSuccess;
+    if (mskwd::wait_any(w, &tp, 1, p, &es) < 0) {
+        ctx->lost = true;
+        return fail(ctx, MSK_ERR_HIP, "no progress: %s did not finish within %g s (MSK_WATCHDOG_S); the context is lost", what, lim.wall_s);
+    }
+    HIP_TRY(ctx, es);
+    return MSK_OK;
+}
+
 // t0 / t1: events that take the kernel's own start / end timestamps (hipExtLaunchKernelGGL: no extra packets in the queue,
 // unlike hipEventRecord, which cost 2 % of a bench step at three records per iteration), or nullptr
 static void launch_trace(msk_scene *sc, hipStream_t stream, const PathState &st, const PassParams &pp, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
@@ -736,6 +769,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
                          std::vector<std::pair<hipEvent_t, hipEvent_t>> &ev_shade,
                          const AovParams *aov = nullptr, float4 *aov_rgb = nullptr, bool packed = false) {
     msk_ctx *ctx = sc->ctx;
+    int rc_sync = MSK_OK;
     const unsigned long long total = (unsigned long long) n_pix * spp_owned;
     // static, interleaved partition of the pass's samples over the regions (see RegionCtl); the initial records are kept
     // on the device and copied from there when the next render has the same shape
@@ -756,7 +790,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
             wsp->counts_total = total; wsp->counts_regions = n_regions;
         } else {
             HIP_TRY(ctx, hipMemcpyAsync(sb.counts.p, init.data(), init.size() * sizeof(RegionCtl), hipMemcpyHostToDevice, stream));
-            HIP_TRY(ctx, hipStreamSynchronize(stream));
+            if ((rc_sync = ctx_sync(ctx, stream, "the upload of the regions' records"))) return rc_sync;
         }
     }
     if (wsp) HIP_TRY(ctx, hipMemcpyAsync(sb.counts.p, wsp->counts_init.p, (size_t) n_regions * sizeof(RegionCtl), hipMemcpyDeviceToDevice, stream));
@@ -805,91 +839,131 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     // its counters — and a shading launch of one half fills the gaps of a traversal launch of the other (and the other way
     // round), which one launch at a time leaves open at its start, its end and wherever its waves wait.  Measured with two
     // concurrent half-size renders before this was built: 49.3 against 55.0 ms for the bench step.
-    struct Half { uint32_t first, count; hipStream_t stream; Ctrl *d_ctrl, *h_ctrl; EventPool ev; uint32_t *stack_ovf;
-                  msk_stats st; int rc; unsigned long long expected; std::string err; bool lost = false; };
-    const mskwd::Limits wd_limits = mskwd::limits_from_env();
-    auto run_range = [&](Half &hf) -> int {
-        (void) hipSetDevice(ctx->device);               // the current device is per host thread
-        PassParams pp = pp0;
-        pp.region_first = hf.first; pp.region_count = hf.count; pp.stack_ovf = hf.stack_ovf;
-        hipStream_t stream_h = hf.stream;
-        EventPool &ev_h = hf.ev;
-        msk_stats *st = &hf.st;
-        const uint32_t grid = (hf.count * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
-        uint32_t it = 0;
+    // One part of the pool: the regions [first, first + count) and their wavefront loop on one stream.  The parts' loops run at the
+    // same time: regions are independent — each owns its slots, its share of the samples and its counters — and a shading
+    // launch of one part fills the gaps of a traversal launch of another (and the other way round), which one launch at a time
+    // leaves open at its start, its end and wherever its waves wait.  Measured with two concurrent half-size renders before
+    // this was built: 49.3 against 55.0 ms for the bench step.  WHO drives the loops is a separate choice (MSK_HOST_THREADS below).
+    struct Part {
+        uint32_t first = 0, count = 0; hipStream_t stream = nullptr; Ctrl *d_ctrl = nullptr, *h_ctrl = nullptr; EventPool ev{nullptr}; uint32_t *stack_ovf = nullptr;
+        msk_stats st; int rc = MSK_OK; unsigned long long expected = 0; std::string err; bool lost = false;
+        // the loop's state between two sync groups
+        PassParams pp; uint32_t grid = 0, it = 0, gi = 0, parity = 0, last_iters = 0; bool fused_now = false, done = false; size_t ev_mark = 0;
         // Two alternating sets of events: a group's timestamps are read (hipEventElapsedTime is a host call of a few
         // microseconds, 32 of them per group) after the NEXT group has been queued, not while the GPU waits for work.
-        const size_t ev_mark = ev_h.next;
         std::vector<std::pair<hipEvent_t, hipEvent_t>> cur_shade, cur_trace, pend_shade, pend_trace;
-        auto read_pending = [&]() {
-            if (!timing) return;
-            sum_events(pend_shade, &st->ms_shade); sum_events(pend_trace, &st->ms_trace);
-            st->n_shade_launches += (uint32_t) pend_shade.size(); st->n_trace_launches += (uint32_t) pend_trace.size();
-            pend_shade.clear(); pend_trace.clear();
-        };
-        uint32_t parity = 0;
-        bool fused_now = fused_all;
-        mskwd::Progress watchdog(wd_limits);               // msk_watchdog.h: a wall limit per sync group + "the counters stand still"
-        for (uint32_t gi = 0;; ++gi) {
-            ev_h.next = ev_mark + (size_t) parity * 4 * group;
-            const bool timed = timing && (gi + phase) % every == 0;
-            if (fused_now) {
-                // the iteration loop on the device (k_wavefront): one bounded launch = up to fused_iters sweeps of every region
-                // (not timed: msk_stats::ms_shade / ms_trace stay the sums of k_shade_gen / k_trace launches)
-                hipEvent_t a = nullptr, b = nullptr;
-                if (diffuse_only) hipExtLaunchKernelGGL((k_wavefront<true>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
-                else hipExtLaunchKernelGGL((k_wavefront<false>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
-                it += fused_iters;
-                st->launches_wavefront += 1;
-            } else
-            for (uint32_t g = 0; g < group; ++g, ++it) {
+        mskwd::Progress watchdog;                          // msk_watchdog.h: a wall limit per sync group + "the counters stand still"
+        mskwd::Ticket ticket;
+        explicit Part(const mskwd::Limits &l) : watchdog(l) { std::memset(&st, 0, sizeof st); }
+    };
+    const mskwd::Limits wd_limits = mskwd::limits_from_env();
+    const mskwd::Waiter waiter{mskwd::wait_mode_from_env(), ctx->hub};
+    auto read_pending = [&](Part &p) {
+        if (!timing) return;
+        sum_events(p.pend_shade, &p.st.ms_shade); sum_events(p.pend_trace, &p.st.ms_trace);
+        p.st.n_shade_launches += (uint32_t) p.pend_shade.size(); p.st.n_trace_launches += (uint32_t) p.pend_trace.size();
+        p.pend_shade.clear(); p.pend_trace.clear();
+    };
+    // queues one sync group of the part's loop: `group` iterations (or one k_wavefront launch), the counters' reduction and
+    // their copy to the host, and whatever the wait mode needs behind them
+    auto queue_group = [&](Part &p) -> int {
+        const PassParams &pp = p.pp;
+        hipStream_t stream_h = p.stream;
+        const uint32_t grid = p.grid;
+        p.ev.next = p.ev_mark + (size_t) p.parity * 4 * group;
+        const bool timed = timing && (p.gi + phase) % every == 0;
+        if (p.fused_now) {
+            // the iteration loop on the device (k_wavefront): one bounded launch = up to fused_iters sweeps of every region
+            // (not timed: msk_stats::ms_shade / ms_trace stay the sums of k_shade_gen / k_trace launches)
+            hipEvent_t a = nullptr, b = nullptr;
+            if (diffuse_only) hipExtLaunchKernelGGL((k_wavefront<true>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
+            else hipExtLaunchKernelGGL((k_wavefront<false>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
+            p.it += fused_iters; p.last_iters = fused_iters;
+            p.st.launches_wavefront += 1;
+        } else {
+            for (uint32_t g = 0; g < group; ++g, ++p.it) {
                 hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
-                if (timed) { a = ev_h.get(); b = ev_h.get(); c = ev_h.get(); d = ev_h.get(); }
+                if (timed) { a = p.ev.get(); b = p.ev.get(); c = p.ev.get(); d = p.ev.get(); }
                 const bool have_ev = a && b && c && d;
 #define MSK_SHADE(L, D) hipExtLaunchKernelGGL((k_shade_gen<L, D>), dim3(grid), dim3(MSK_BLOCK), shade_lds + shade_pad_lds, stream_h, a, b, 0, sc->dev, sb.st, pp)
                 if (sc->lds_tables) { if (diffuse_only) MSK_SHADE(true, true); else MSK_SHADE(true, false); }
                 else { if (diffuse_only) MSK_SHADE(false, true); else MSK_SHADE(false, false); }
 #undef MSK_SHADE
                 launch_trace(sc, stream_h, sb.st, pp, c, d);
-                st->launches_shade += 1; st->launches_trace += 1;
+                p.st.launches_shade += 1; p.st.launches_trace += 1;
                 if (aov && aov->n_groups) hipLaunchKernelGGL(k_aov_primary, dim3(grid), dim3(MSK_BLOCK), 0, stream_h, sc->dev, sb.st, pp, *aov);
-                if (timed && have_ev) { cur_shade.push_back({a, b}); cur_trace.push_back({c, d}); }
+                if (timed && have_ev) { p.cur_shade.push_back({a, b}); p.cur_trace.push_back({c, d}); }
             }
-            read_pending();                     // the previous group's, while this one runs
-            HIP_TRY_SLOT(&hf.err, hipMemsetAsync(hf.d_ctrl, 0, sizeof(Ctrl), stream_h));
-            hipLaunchKernelGGL(k_reduce_ctl, dim3(std::min(64u, (hf.count + MSK_BLOCK - 1) / MSK_BLOCK)), dim3(MSK_BLOCK), 0, stream_h,
-                               sb.counts.as<RegionCtl>() + hf.first, hf.count, hf.d_ctrl);
-            HIP_TRY_SLOT(&hf.err, hipGetLastError());
-            HIP_TRY_SLOT(&hf.err, hipMemcpyAsync(hf.h_ctrl, hf.d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream_h));
-            {
-                const hipError_t es = mskwd::sync(stream_h, watchdog);
-                if (es == hipErrorNotReady) {
-                    hf.lost = true;
-                    return fail_to(&hf.err, MSK_ERR_HIP, "no progress: a sync group of the wavefront loop (iterations %u..%u, regions %u..%u) did not finish within "
-                                   "%g s (MSK_WATCHDOG_S); the context is lost", it - (fused_now ? fused_iters : group), it, hf.first, hf.first + hf.count, watchdog.limits().wall_s);
-                }
-                HIP_TRY_SLOT(&hf.err, es);
-            }
-            pend_shade.swap(cur_shade); pend_trace.swap(cur_trace); cur_shade.clear(); cur_trace.clear(); parity ^= 1u;
-            const Ctrl &h = *hf.h_ctrl;
-            if (h.remaining == 0 && h.live == 0) break;
-            if (watchdog.group_done(mskwd::Counters{h.samples_done, h.segments, h.remaining, h.live}) == mskwd::STALLED) {
-                hf.lost = true;
-                return fail_to(&hf.err, MSK_ERR_HIP, "no progress: %u sync groups of the wavefront loop changed nothing (%llu samples finished, %llu live paths, "
-                               "%llu samples not started; MSK_WATCHDOG_GROUPS); the context is lost", watchdog.stalled(), h.samples_done, h.live, h.remaining);
-            }
-            if (fused_ok && !fused_now && h.remaining == 0 && h.live * 100ull < (unsigned long long) fused_tail_pct * hf.count * region_size)
-                fused_now = true;                       // the thinning end of the pass: no more launches and host round trips per sweep
-            if (it > 100000000u) return fail_to(&hf.err, MSK_ERR_HIP, "wavefront loop did not terminate");
+            p.last_iters = group;
         }
-        read_pending();
-        ev_h.next = ev_mark;                            // every timestamp has been read: the events are free again
-        st->samples = hf.h_ctrl->samples_done; st->segments = hf.h_ctrl->segments; st->shadow_rays = hf.h_ctrl->shadow_rays;
-        st->invalid_samples = hf.h_ctrl->invalid;
-        st->iterations = it;
-        if (hf.h_ctrl->samples_done != hf.expected)
-            return fail_to(&hf.err, MSK_ERR_HIP, "internal error: %llu of %llu samples finished", hf.h_ctrl->samples_done, hf.expected);
+        read_pending(p);                    // the previous group's, while this one runs
+        HIP_TRY_SLOT(&p.err, hipMemsetAsync(p.d_ctrl, 0, sizeof(Ctrl), stream_h));
+        hipLaunchKernelGGL(k_reduce_ctl, dim3(std::min(64u, (p.count + MSK_BLOCK - 1) / MSK_BLOCK)), dim3(MSK_BLOCK), 0, stream_h,
+                           sb.counts.as<RegionCtl>() + p.first, p.count, p.d_ctrl);
+        HIP_TRY_SLOT(&p.err, hipGetLastError());
+        HIP_TRY_SLOT(&p.err, hipMemcpyAsync(p.h_ctrl, p.d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream_h));
+        HIP_TRY_SLOT(&p.err, mskwd::arm(waiter, p.ticket));
         return MSK_OK;
+    };
+    // after the group's last command has completed: is the part done, stalled, or ready for its thin end?
+    auto finish_group = [&](Part &p) -> int {
+        p.pend_shade.swap(p.cur_shade); p.pend_trace.swap(p.cur_trace); p.cur_shade.clear(); p.cur_trace.clear(); p.parity ^= 1u; ++p.gi;
+        const Ctrl &h = *p.h_ctrl;
+        if (h.remaining == 0 && h.live == 0) {
+            read_pending(p);
+            p.ev.next = p.ev_mark;                            // every timestamp has been read: the events are free again
+            p.st.samples = h.samples_done; p.st.segments = h.segments; p.st.shadow_rays = h.shadow_rays;
+            p.st.invalid_samples = h.invalid;
+            p.st.iterations = p.it;
+            p.done = true;
+            if (h.samples_done != p.expected)
+                return fail_to(&p.err, MSK_ERR_HIP, "internal error: %llu of %llu samples finished", h.samples_done, p.expected);
+            return MSK_OK;
+        }
+        if (p.watchdog.group_done(mskwd::Counters{h.samples_done, h.segments, h.remaining, h.live}) == mskwd::STALLED) {
+            p.lost = true;
+            return fail_to(&p.err, MSK_ERR_HIP, "no progress: %u sync groups of the wavefront loop changed nothing (%llu samples finished, %llu live paths, "
+                           "%llu samples not started; MSK_WATCHDOG_GROUPS); the context is lost", p.watchdog.stalled(), h.samples_done, h.live, h.remaining);
+        }
+        if (fused_ok && !p.fused_now && h.remaining == 0 && h.live * 100ull < (unsigned long long) fused_tail_pct * p.count * region_size)
+            p.fused_now = true;                       // the thinning end of the pass: no more launches and host round trips per sweep
+        if (p.it > 100000000u) return fail_to(&p.err, MSK_ERR_HIP, "wavefront loop did not terminate");
+        return MSK_OK;
+    };
+    // One host thread drives n of the parts: queues a group on each, then serves whichever finishes (wait_any), oldest first.
+    auto drive = [&](Part *const *mine, int n) {
+        (void) hipSetDevice(ctx->device);               // the current device is per host thread
+        Part *active[MSK_MAX_STREAMS];
+        int n_active = 0;
+        for (int i = 0; i < n; ++i) {
+            mine[i]->rc = queue_group(*mine[i]);
+            if (mine[i]->rc == MSK_OK) active[n_active++] = mine[i];
+        }
+        while (n_active) {
+            mskwd::Ticket *tickets[MSK_MAX_STREAMS];
+            for (int i = 0; i < n_active; ++i) tickets[i] = &active[i]->ticket;
+            hipError_t es = hipSuccess;
+            const int hit = mskwd::wait_any(waiter, tickets, n_active, active[0]->watchdog, &es);
+            if (hit < 0) {                              // the wall limit: nothing this thread waits for will be waited for again
+                for (int i = 0; i < n_active; ++i) {
+                    Part &q = *active[i];
+                    q.lost = true;
+                    q.rc = fail_to(&q.err, MSK_ERR_HIP, "no progress: a sync group of the wavefront loop (iterations %u..%u, regions %u..%u) did not finish within "
+                                   "%g s (MSK_WATCHDOG_S); the context is lost", q.it - q.last_iters, q.it, q.first, q.first + q.count, q.watchdog.limits().wall_s);
+                }
+                return;
+            }
+            Part &p = *active[hit];
+            for (int i = hit; i + 1 < n_active; ++i) active[i] = active[i + 1];
+            --n_active;
+            if (es != hipSuccess) { p.rc = fail_to(&p.err, MSK_ERR_HIP, "the wavefront loop's stream reported: %s", hipGetErrorString(es)); continue; }
+            p.rc = finish_group(p);
+            if (p.lost) return;                         // (stalled: the context is done, the other parts are not driven further)
+            if (p.rc == MSK_OK && !p.done) {
+                p.rc = queue_group(p);
+                if (p.rc == MSK_OK) active[n_active++] = &p;
+            }
+        }
     };
 
     // samples the regions [first, first + count) own (the same static partition as the init above)
@@ -908,7 +982,8 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     uint32_t n_parts = std::min<uint32_t>(MSK_MAX_STREAMS, std::max(1u, env_u32("MSK_STREAMS", 4)));
     if (n_regions < 1024 || stream != ctx->stream) n_parts = 1;
     const uint32_t ovf_words = sc->dev.stack_total > sc->dev.stack_entries ? sc->dev.stack_total - sc->dev.stack_entries : 0;
-    std::vector<Half> parts;
+    std::vector<Part> parts;
+    parts.reserve(n_parts);
     // Parts of slightly different sizes: equal parts can fall into step (all launches starting and draining together, which
     // is one big launch again; measured as a bimodal 48 / 52 ms), unequal ones keep sliding past each other.
     const double skew = env_u32("MSK_STREAM_SKEW", 10) / 100.0;          // relative size step between neighbouring parts
@@ -916,29 +991,45 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     for (uint32_t k = 0; k < n_parts; ++k) cum[k + 1] = cum[k] + 1.0 + skew * ((double) (n_parts - 1) / 2.0 - k);
     for (uint32_t k = 0; k < n_parts; ++k) {
         const uint32_t first = (uint32_t) (n_regions * (cum[k] / cum[n_parts])), last = k + 1 == n_parts ? n_regions : (uint32_t) (n_regions * (cum[k + 1] / cum[n_parts]));
-        parts.push_back(Half{first, last - first, k ? ctx->more_streams[k - 1] : stream, sb.ctrl.as<Ctrl>() + k, ctx->h_ctrl + k,
-                             k ? EventPool{ctx, 0, &ctx->more_events[k - 1]} : EventPool{ctx, ev.next, ev.pool}, nullptr, msk_stats{}, MSK_OK,
-                             share(first, last - first), std::string()});
-        std::memset(&parts.back().st, 0, sizeof(msk_stats));
+        parts.emplace_back(wd_limits);
+        Part &p = parts.back();
+        p.first = first; p.count = last - first; p.stream = k ? ctx->more_streams[k - 1] : stream;
+        p.d_ctrl = sb.ctrl.as<Ctrl>() + k; p.h_ctrl = ctx->h_ctrl + k;
+        p.ev = k ? EventPool{ctx, 0, &ctx->more_events[k - 1]} : EventPool{ctx, ev.next, ev.pool};
+        p.ev_mark = p.ev.next;
+        p.expected = share(first, last - first);
+        p.pp = pp0; p.pp.region_first = first; p.pp.region_count = p.count;
+        p.grid = (p.count * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK;
+        p.fused_now = fused_all;
+        p.ticket.stream = p.stream; p.ticket.slot = (int) k; p.ticket.event = ctx->wait_events[k];
         if (ovf_words) {                                // LaneStack overflow: one word per lane per extra entry, per launch
             const size_t lanes = (size_t) (((last - first) * MSK_WAVE + MSK_BLOCK - 1) / MSK_BLOCK) * MSK_BLOCK;
             HIP_TRY(ctx, sb.stack_ovf[k].reserve((size_t) ovf_words * lanes * 4));
-            parts.back().stack_ovf = sb.stack_ovf[k].as<uint32_t>();
+            p.stack_ovf = sb.stack_ovf[k].as<uint32_t>();
         }
+        p.pp.stack_ovf = p.stack_ovf;
     }
+    // Who drives the parts' loops (MSK_HOST_THREADS): ONE host thread for all of them by default since round 6 — it queues a
+    // group on every stream and then serves whichever finishes; the device always holds the other streams' queued groups while
+    // the host turns one around.  Rounds 2-5 used one thread per part (MSK_HOST_THREADS=4): three more threads per context,
+    // spinning with the poll wait (DESIGN.md §7 has both under a CPU quota).
+    const uint32_t n_threads = std::min(n_parts, std::max(1u, env_u32("MSK_HOST_THREADS", 1)));
     if (n_parts > 1) {
-        HIP_TRY(ctx, hipStreamSynchronize(stream));     // the regions' initial records (queued above) before the other streams read them
+        rc_sync = ctx_sync(ctx, stream, "the regions' initial records");     // (queued above) before the other streams read them
+        if (rc_sync) return rc_sync;
+    }
+    {
+        std::vector<std::vector<Part *>> mine(n_threads);
+        for (uint32_t k = 0; k < n_parts; ++k) mine[k % n_threads].push_back(&parts[k]);
         std::vector<std::thread> others;
-        for (uint32_t k = 1; k < n_parts; ++k) others.emplace_back([&, k]() { parts[k].rc = run_range(parts[k]); });
-        parts[0].rc = run_range(parts[0]);
+        for (uint32_t j = 1; j < n_threads; ++j) others.emplace_back([&, j]() { drive(mine[j].data(), (int) mine[j].size()); });
+        drive(mine[0].data(), (int) mine[0].size());
         for (auto &t : others) t.join();
-    } else {
-        parts[0].rc = run_range(parts[0]);
     }
     for (auto &hf : parts) if (hf.lost) ctx->lost = true;                                 // the watchdog gave up on a part: the context is done
     for (auto &hf : parts) if (hf.rc) return fail(ctx, hf.rc, "%s", hf.err.c_str());     // first failing part, after the join
     if (stats) {
-        for (const Half &hf : parts) {
+        for (const Part &hf : parts) {
             stats->samples += hf.st.samples; stats->segments += hf.st.segments; stats->shadow_rays += hf.st.shadow_rays;
             stats->invalid_samples += hf.st.invalid_samples;
             stats->iterations += hf.st.iterations;
@@ -1071,7 +1162,8 @@ static int render_serial(msk_scene *sc, const msk_render_params *prm, float *d_f
     HIP_TRY(ctx, hipGetLastError());
     unsigned long long h[4] = {0, 0, 0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(h, counters.p, 32, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    // (one kernel for the whole job: the wall limit is 30 x MSK_WATCHDOG_S, an hour at the default)
+    if (int rcw = ctx_sync(ctx, stream, "the MSK_RNG_PCG_BLOCK render (k_path_serial + Film::put)", 30.0)) { counters.leak(); ovf.leak(); return rcw; }
     if (stats) {
         stats->samples = h[0]; stats->segments = h[1]; stats->shadow_rays = h[2]; stats->invalid_samples = h[3]; stats->passes = 1;
         if (t_begin && t_end) (void) hipEventElapsedTime(&stats->ms_total, t_begin, t_end);
@@ -1257,7 +1349,7 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
 #undef MSK_RESOLVE
         if (b) (void) hipEventRecord(b, stream);
         ev_resolve.push_back({a, b});
-        HIP_TRY(ctx, hipStreamSynchronize(stream));   // d_pix / records are reused by the next pass
+        if ((rc = ctx_sync(ctx, stream, "the film replay of a pass"))) return rc;   // d_pix / records are reused by the next pass
         if (stats) stats->passes++;
     }
     {
@@ -1277,7 +1369,7 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     }
     if (t_end) (void) hipEventRecord(t_end, stream);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    if ((rc = ctx_sync(ctx, stream, "Film::put"))) return rc;
     if (stats) {
         if (t_begin && t_end) (void) hipEventElapsedTime(&stats->ms_total, t_begin, t_end);
         sum_events(ev_resolve, &stats->ms_resolve);      // trace / shade were summed group by group in run_wavefront
@@ -1316,7 +1408,7 @@ extern "C" int msk_gpu_render(msk_scene *scene, const msk_render_params *params,
     }
     if (ws.host_film) {
         HIP_TRY(ctx, hipMemcpyAsync(ws.host_film, film.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = ctx_sync(ctx, ctx->stream, "the film's copy-back"))) return rc;
         std::memcpy(film_xyzaw, ws.host_film, bytes);
     } else {
         HIP_TRY(ctx, hipMemcpy(film_xyzaw, film.p, bytes, hipMemcpyDeviceToHost));
@@ -1426,12 +1518,14 @@ extern "C" int msk_gpu_sample_pixels(msk_scene *scene, const msk_render_params *
     HIP_TRY(ctx, ox.alloc(n_rec * 12)); HIP_TRY(ctx, op.alloc(n_rec * 8));
     EventPool ev{ctx, 0};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> e1, e2;
+    // a lost context (the watchdog gave up): the local buffers are dropped without hipFree, which would wait for the device
+    auto sb_leak = [&]() { if (ctx->lost) { sb.leak(); for (DevBuf *b : {&d_pix, &d_inv, &ra, &rb, &ox, &op}) b->leak(); } };
     rc = run_wavefront(scene, ctx->stream, &p, p.spp, d_pix.as<uint4>(), d_inv.as<uint32_t>(), n_pixels, ra.as<float4>(), rb.as<float>(), sb,
                        region_size, n_regions, nullptr, ev, e1, e2);
-    if (rc) return rc;
+    if (rc) { sb_leak(); return rc; }
     hipLaunchKernelGGL(k_export_records, dim3((uint32_t) ((n_rec + 255) / 256)), dim3(256), 0, ctx->stream, ra.as<float4>(),
                        rb.as<float>(), n_pixels, p.spp, ox.as<float>(), op.as<float>());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = ctx_sync(ctx, ctx->stream, "k_export_records"))) { sb_leak(); return rc; }
     std::vector<float> hx((size_t) n_rec * 3), hp(out_pos ? (size_t) n_rec * 2 : 0);
     HIP_TRY(ctx, hipMemcpy(hx.data(), ox.p, n_rec * 12, hipMemcpyDeviceToHost));
     if (out_pos) HIP_TRY(ctx, hipMemcpy(hp.data(), op.p, n_rec * 8, hipMemcpyDeviceToHost));
@@ -1478,7 +1572,7 @@ static int trace_batch(msk_scene *scene, uint64_t n, const float *rays, float *o
         hipLaunchKernelGGL(k_trace_batch<3>, dim3(grid), dim3(MSK_BLOCK), scene->trace_lds_bytes, ctx->stream, scene->dev,
                            d_rays.as<float4>(), n, oh, oa, d_ovf.as<uint32_t>());
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rcw = ctx_sync(ctx, ctx->stream, "k_trace_batch")) { d_rays.leak(); d_out.leak(); d_ovf.leak(); return rcw; }
     HIP_TRY(ctx, hipMemcpy(out_any ? (void *) out_any : (void *) out_hit, d_out.p, out_any ? n : n * 16, hipMemcpyDeviceToHost));
     return MSK_OK;
 }

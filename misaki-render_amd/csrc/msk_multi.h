@@ -44,22 +44,44 @@ static int group_init(const int *ids, int n, msk_ctx **out) {
     g->prop = g->group->ctxs[0]->prop;
     g->group->peer.assign(n, 1);
     (void) hipSetDevice(ids[0]);
+    // MSK_GROUP_FORCE_STAGED=1: every member's film but the first reaches the first device through hipMemcpyPeerAsync into a
+    // staging buffer, as it does for a member whose memory cannot be mapped — the branch a node with full peer access (and a
+    // one-GPU rehearsal, where every member is "the same device") never takes otherwise.  MSK_GROUP_LOG=1 says per member
+    // which of the two it got (on stderr, once per msk_gpu_init).
+    const bool force_staged = env_u32("MSK_GROUP_FORCE_STAGED", 0) != 0, log = env_u32("MSK_GROUP_LOG", 0) != 0;
     for (int k = 1; k < n; ++k) {
-        if (ids[k] == ids[0]) continue;
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, ids[0], ids[k]) != hipSuccess) can = 0;
-        if (can) {
-            const hipError_t e = hipDeviceEnablePeerAccess(ids[k], 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+        int can = ids[k] == ids[0] ? 1 : 0;
+        const char *why = ids[k] == ids[0] ? "same device as member 0" : "peer access enabled";
+        if (ids[k] != ids[0]) {
+            if (hipDeviceCanAccessPeer(&can, ids[0], ids[k]) != hipSuccess) can = 0;
+            if (!can) why = "hipDeviceCanAccessPeer says no";
+            else {
+                const hipError_t e = hipDeviceEnablePeerAccess(ids[k], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { can = 0; why = "hipDeviceEnablePeerAccess failed"; }
+            }
+            (void) hipGetLastError();
         }
-        (void) hipGetLastError();
+        if (force_staged) { can = 0; why = "MSK_GROUP_FORCE_STAGED"; }
         g->group->peer[k] = (char) can;
+        if (log) std::fprintf(stderr, "[msk_gpu] group member %d (device %d): film summed %s (%s)\n", k, ids[k],
+                              can ? "in place over peer access" : "from a staged hipMemcpyPeerAsync copy on device 0", why);
     }
     *out = g;
     return MSK_OK;
 }
 
+// A member the watchdog gave up on takes its DEVICE out of the group's teardown: every member context on that ordinal is marked
+// lost as well (their hipFree / hipStreamDestroy would wait for the same hung device), and so is the group.
+static void group_spread_lost(msk_ctx *g) {
+    for (msk_ctx *c : g->group->ctxs)
+        if (c->lost) {
+            g->lost = true;
+            for (msk_ctx *o : g->group->ctxs) if (o->device == c->device) o->lost = true;
+        }
+}
+
 static void group_shutdown(msk_ctx *g) {
+    group_spread_lost(g);
     for (msk_ctx *c : g->group->ctxs) msk_gpu_shutdown(c);
     delete g->group;
     g->group = nullptr;
@@ -67,7 +89,9 @@ static void group_shutdown(msk_ctx *g) {
 }
 
 static int group_fail(msk_ctx *g, size_t k, int rc) {
-    if (g->group->ctxs[k]->lost) g->lost = true;          // the watchdog gave up on a member: the group is done as well
+    // the watchdog gave up on a member — the one whose error is reported or any other (the callers stop at the FIRST failing
+    // member; a later one may be the lost one): the group is done as well, and its teardown frees nothing on a device
+    group_spread_lost(g);
     return fail(g, rc, "device %d (member %zu of %zu): %s", g->group->ctxs[k]->device, k, g->group->ctxs.size(),
                 g->group->ctxs[k]->last_error.c_str());
 }
@@ -96,6 +120,7 @@ static int group_scene_create(msk_ctx *g, const msk_scene_desc *d, msk_scene **o
 }
 
 static void group_scene_destroy(msk_scene *s) {
+    group_spread_lost(s->ctx);
     for (msk_scene *p : s->parts) if (p) msk_gpu_scene_destroy(p);
     if (s->ctx->lost) return;                             // (as for a single context: device memory is not freed under a hung kernel)
     (void) hipSetDevice(s->ctx->device);

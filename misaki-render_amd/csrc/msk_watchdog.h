@@ -71,20 +71,96 @@ inline unsigned poll_sleep_us(double waited_s) { return waited_s < 0.020 ? 0u : 
 // the waiting side needs the HIP runtime: msk_gpu.hip defines MSK_WATCHDOG_SYNC before it includes this file, the CPU test does not
 #ifdef MSK_WATCHDOG_SYNC
 #include <hip/hip_runtime.h>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
 #include <thread>
 namespace mskwd {
-// hipStreamSynchronize with a wall limit: hipSuccess, the stream's error, or hipErrorNotReady when `p` says the wait ran out
-inline hipError_t sync(hipStream_t stream, const Progress &p) {
-    if (p.limits().wall_s <= 0.0) return hipStreamSynchronize(stream);
+
+// HOW a host thread waits for the end of a sync group (MSK_WAIT; round 6, DESIGN.md section 7 "host-side waits"): eight ranks of
+// one node share its CPU quota (16 CPUs on the bench boxes), and a wait that spins takes a CPU for the whole render.
+//   callback  hipLaunchHostFunc behind the group's last command signals a condition variable the waiting thread sleeps on
+//             (timed: the wall limit holds) — no CPU while the device works
+//   sleep     hipStreamQuery every 50 us from the start (no yield phase): a few per cent of one CPU per waiting thread
+//   poll      rounds 4-5: hipStreamQuery + yield for the first 20 ms of a wait (spins through every ordinary group), then sleeps
+//   event     a hipEventBlockingSync event + hipEventSynchronize: blocks in the driver; NO wall limit (the stall check stays)
+//   sync      hipStreamSynchronize: the runtime's own wait; NO wall limit
+enum WaitMode { WAIT_POLL = 0, WAIT_SLEEP = 1, WAIT_CALLBACK = 2, WAIT_EVENT = 3, WAIT_SYNC = 4 };
+#ifndef MSK_WAIT_DEFAULT
+#define MSK_WAIT_DEFAULT WAIT_CALLBACK
+#endif
+inline const char *wait_mode_name(WaitMode m) { static const char *n[] = {"poll", "sleep", "callback", "event", "sync"}; return n[(int) m]; }
+inline WaitMode wait_mode_from_env() {
+    const char *s = std::getenv("MSK_WAIT");
+    if (s) for (int m = 0; m <= (int) WAIT_SYNC; ++m) if (!std::strcmp(s, wait_mode_name((WaitMode) m))) return (WaitMode) m;
+    return (WaitMode) MSK_WAIT_DEFAULT;
+}
+
+#define MSK_WAIT_SLOTS 8
+// What the host functions of WAIT_CALLBACK signal.  Allocated on its own and LEAKED with a lost context: a host function that
+// was queued behind a kernel which never finished may still fire after the context is gone.
+struct Hub {
+    std::mutex m;
+    std::condition_variable cv;
+    uint64_t fired[MSK_WAIT_SLOTS] = {};
+    uint64_t armed[MSK_WAIT_SLOTS] = {};                // (written by the arming thread only)
+    struct Slot { Hub *hub; int k; } slots[MSK_WAIT_SLOTS];
+    Hub() { for (int k = 0; k < MSK_WAIT_SLOTS; ++k) slots[k] = Slot{this, k}; }
+    static void fire(void *arg) {
+        Slot *s = (Slot *) arg;
+        { std::lock_guard<std::mutex> lk(s->hub->m); ++s->hub->fired[s->k]; }
+        s->hub->cv.notify_all();
+    }
+};
+
+// one thing a thread waits for: everything queued on `stream` up to arm()
+struct Ticket {
+    hipStream_t stream = nullptr;
+    int slot = 0;                   // of the hub (one per part of the pool; waits outside the loop use slot 0)
+    hipEvent_t event = nullptr;     // WAIT_EVENT: a hipEventBlockingSync event owned by the context
+    uint64_t seq = 0;
+};
+
+struct Waiter {
+    WaitMode mode = (WaitMode) MSK_WAIT_DEFAULT;
+    Hub *hub = nullptr;
+};
+
+// after the last command of what is to be waited for has been queued
+inline hipError_t arm(const Waiter &w, Ticket &t) {
+    if (w.mode == WAIT_CALLBACK) { t.seq = ++w.hub->armed[t.slot]; return hipLaunchHostFunc(t.stream, Hub::fire, &w.hub->slots[t.slot]); }
+    if (w.mode == WAIT_EVENT) return hipEventRecord(t.event, t.stream);
+    return hipSuccess;
+}
+
+// Waits until ONE of the n armed tickets is complete: its index, with *err = what its stream reported; or -1 when the wall limit
+// of `p` ran out first (poll / sleep / callback).  event / sync wait for tickets[0] — the caller lists the oldest first.
+inline int wait_any(const Waiter &w, Ticket *const *tickets, int n, const Progress &p, hipError_t *err) {
+    *err = hipSuccess;
+    const double limit = p.limits().wall_s;
+    if (w.mode == WAIT_SYNC || (w.mode == WAIT_EVENT && !tickets[0]->event)) { *err = hipStreamSynchronize(tickets[0]->stream); return 0; }
+    if (w.mode == WAIT_EVENT) { *err = hipEventSynchronize(tickets[0]->event); return 0; }
+    if (w.mode == WAIT_CALLBACK) {
+        std::unique_lock<std::mutex> lk(w.hub->m);
+        int hit = -1;
+        auto ready = [&]() { for (int i = 0; i < n; ++i) if (w.hub->fired[tickets[i]->slot] >= tickets[i]->seq) { hit = i; return true; } return false; };
+        if (limit > 0.0) { if (!w.hub->cv.wait_for(lk, std::chrono::duration<double>(limit), ready)) return -1; }
+        else w.hub->cv.wait(lk, ready);
+        return hit;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
-        const hipError_t e = hipStreamQuery(stream);
-        if (e != hipErrorNotReady) return e;
+        for (int i = 0; i < n; ++i) {
+            const hipError_t e = hipStreamQuery(tickets[i]->stream);
+            if (e != hipErrorNotReady) { *err = e; return i; }
+        }
+        (void) hipGetLastError();
         const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (p.waited(waited) == TIMED_OUT) { (void) hipGetLastError(); return hipErrorNotReady; }
-        const unsigned us = poll_sleep_us(waited);
+        if (p.waited(waited) == TIMED_OUT) return -1;
+        const unsigned us = w.mode == WAIT_SLEEP ? (waited < 1.0 ? 50u : 5000u) : poll_sleep_us(waited);
         if (us) std::this_thread::sleep_for(std::chrono::microseconds(us)); else std::this_thread::yield();
     }
 }
+
 }  // namespace mskwd
 #endif

@@ -545,20 +545,20 @@ def cbox_scene(width, height, coeff_lookup=None, extra_meshes=(), crop=None):
 
 # BASELINE configs 3 and 5 name assets/bunny and assets/teapot-full, whose meshes the reference does not ship
 # (SURVEY F3): the stand-ins are closed bumpy meshes of the same triangle class inside the Cornell room.
-def bunny_class_scene(size, res=187):
+def bunny_class_scene(size, res=187, crop=None):
     """Config-3 class: ~70 k-triangle rough-conductor mesh (two-sided), room + luminaire, no boxes."""
     blob = blob_mesh("bunny_class", (278, 200, 280), 160, res, res, WHITE, seed=7, bump=0.25)
     blob.bsdf = {"type": "roughconductor", "alpha": 0.15, "eta": (0.2, 0.92, 1.1), "k": (3.9, 2.45, 2.14), "twosided": True}
-    return flatten(cbox_meshes()[:6] + [blob], size, size)
+    return flatten(cbox_meshes()[:6] + [blob], size, size, crop=crop)
 
 
-def teapot_class_scene(size, res=270, diffuse=False):
+def teapot_class_scene(size, res=270, diffuse=False, crop=None):
     """Config-5 class: ~146 k-triangle rough-dielectric mesh, room + luminaire, no boxes (diffuse=True: the same geometry,
     white diffuse — measurements of the shading variants on one scene)."""
     blob = blob_mesh("teapot_class", (278, 200, 280), 160, res, res, WHITE, seed=7, bump=0.25)
     if not diffuse:
         blob.bsdf = {"type": "roughdielectric", "alpha": 0.1, "int_ior": 1.5, "ext_ior": 1.0}
-    return flatten(cbox_meshes()[:6] + [blob], size, size)
+    return flatten(cbox_meshes()[:6] + [blob], size, size, crop=crop)
 
 
 # ----------------------------------------------------------------------------- develop

@@ -415,6 +415,33 @@ def test_two_members_behind_one_context(abi, hostmirror, oracle, golden_lookup):
         abi.Context([0] * 9)
 
 
+def test_group_film_sum_staged_branch_equals_peer_branch(abi, hostmirror, golden_lookup, monkeypatch, capfd):
+    """The two ways a member's film reaches the first device (msk_multi.h): read in place by k_film_sum (peer access — what
+    ids = {0, 0, 0} always gets) or copied into a staging buffer by hipMemcpyPeerAsync first (a member whose memory cannot be
+    mapped).  MSK_GROUP_FORCE_STAGED=1 takes the second branch on a one-GPU box: same members, same order of the sum —
+    the films must be equal bit for bit; MSK_GROUP_LOG=1 says per member which branch it got (HDRFilm::put's mutexed
+    accumulation, films/hdrfilm.cpp:43-46, is what both replace)."""
+    flat = cbox(hostmirror, golden_lookup, 80, 48)
+    prm = abi.render_params(spp=7, seed=3)
+    films = {}
+    for forced in ("0", "1"):
+        monkeypatch.setenv("MSK_GROUP_FORCE_STAGED", forced)
+        monkeypatch.setenv("MSK_GROUP_LOG", "1")
+        with abi.Context((0, 0, 0)) as grp:
+            sc = abi.Scene(grp, flat)
+            films[forced], st = sc.render(prm)
+            again, _ = sc.render(prm)
+            sc.close()
+        assert st.samples == 80 * 48 * 7 and np.array_equal(again, films[forced])
+        err = capfd.readouterr().err
+        lines = [l for l in err.splitlines() if l.startswith("[msk_gpu] group member")]
+        assert len(lines) == 2, err
+        assert all(("staged hipMemcpyPeerAsync" in l and "MSK_GROUP_FORCE_STAGED" in l) if forced == "1" else ("in place over peer access" in l and "same device" in l)
+                   for l in lines), lines
+    assert np.array_equal(films["0"].view(np.uint32), films["1"].view(np.uint32))
+    assert np.isfinite(films["0"]).all() and films["0"][..., :3].max() > 0
+
+
 def test_scene_lifecycle_releases_device_memory(gpu_ctx, abi, hostmirror, golden_lookup):
     """create / render / destroy in a loop: every DevBuf and the cached workspace go back to the allocator, a second
     context on the same device works side by side, and results do not depend on what ran before."""
