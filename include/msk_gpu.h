@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MSK_ABI_VERSION 6
+#define MSK_ABI_VERSION 7
 
 /* ---- status codes ------------------------------------------------------- */
 #define MSK_OK                 0
@@ -92,12 +92,32 @@ typedef struct msk_mesh_desc {
     uint32_t has_texcoords;  /* Mesh::has_vertex_texcoords() (mesh.h:67)        */
 } msk_mesh_desc;
 
-/* A spectrum the device can evaluate: value(l) = scale * S(coeff, l) with the sigmoid polynomial
- * S of render/srgb.h:8-19.  RGB triples above 1 use the normalisation of srgb_d65.cpp:18-22
- * (scale = 2 * max(rgb), coeff = fetch(rgb / scale)) without the D65 factor. */
+/*
+ * A tabulated spectrum on a regular wavelength grid = the reference's `regular` texture plugin
+ * (spectra/regular.cpp:27-91,148 — what <spectrum value="l0:v0, l1:v1, ..."/> with equidistant
+ * wavelengths becomes, xml.cpp:300-341; the loader has already multiplied the values of a spectrum inside an
+ * <emitter> by MSK_CIE_Y_NORMALIZATION, xml.cpp:306-314).  value(l) = lerp of values[first_value + i], i = 0 .. size-1,
+ * at x = (l - lambda_min) * inv_interval with inv_interval = float(1 / ((double) lambda_max - lambda_min) / (size - 1)))
+ * and the segment index clamped to [0, size - 2] (RegularSpectrum::eval -> eval_pdf, regular.cpp:73-91: outside the
+ * table the end segments are continued linearly).  ABI v7.  2 <= size <= MSK_REGULAR_MAX (the D65 and CIE tables'
+ * 95; regular.cpp:30-31 needs two entries), lambda_min < lambda_max, values finite and non-negative (regular.cpp:59-60).
+ * An `irregular` spectrum (unequal steps) is not part of this ABI: the host loader refuses it with its own message.
+ */
+#define MSK_REGULAR_MAX 95
+typedef struct msk_regular_spectrum_desc {
+    float    lambda_min, lambda_max;
+    uint32_t size;
+    uint32_t first_value;    /* offset into msk_scene_desc.regular_values       */
+} msk_regular_spectrum_desc;
+
+/* A spectrum the device can evaluate.  regular == 0: value(l) = scale * S(coeff, l) with the sigmoid polynomial
+ * S of render/srgb.h:8-19; RGB triples above 1 use the normalisation of srgb_d65.cpp:18-22
+ * (scale = 2 * max(rgb), coeff = fetch(rgb / scale)) without the D65 factor; scale >= 0.
+ * regular == k > 0 (ABI v7): the tabulated spectrum regular_spectra[k - 1] of the scene; coeff / scale are ignored. */
 typedef struct msk_spectrum_desc {
     float coeff[3];
     float scale;
+    uint32_t regular;
 } msk_spectrum_desc;
 
 /*
@@ -127,6 +147,8 @@ typedef struct msk_bsdf_desc {
     float   reflectance_scale;   /* diffuse reflectance = S(reflectance, l) * reflectance_scale: 1 for an `srgb` spectrum; a
                                     `uniform` spectrum of value c (spectra/uniform.cpp:16-27, what <spectrum value="c"/> makes
                                     outside an emitter, xml.cpp:285-292) is {0, 0, +inf} with scale c */
+    uint32_t reflectance_regular; /* ABI v7: k > 0 = the diffuse reflectance is the tabulated spectrum regular_spectra[k - 1]
+                                    (reflectance / reflectance_scale / reflectance_texture are then unused); 0 = not tabulated */
 } msk_bsdf_desc;
 
 /*
@@ -159,6 +181,9 @@ typedef struct msk_emitter_desc {
     int32_t mesh_id;         /* the shape this emitter is attached to          */
     float   radiance[3];     /* sigmoid-polynomial coefficients                */
     float   d65_scale;
+    uint32_t radiance_regular; /* ABI v7: k > 0 = radiance(l) is the tabulated spectrum regular_spectra[k - 1] as it stands
+                                  (AreaLight / ConstantBackgroundEmitter with a `regular` radiance: no D65 factor, no
+                                  sigmoid; radiance / d65_scale unused); 0 = the srgb_d65 form above */
 } msk_emitter_desc;
 
 /* PerspectiveCamera (sensors/perspective.cpp:8-42); matrices are row-major 4x4. */
@@ -201,6 +226,10 @@ typedef struct msk_scene_desc {
     const float *d65;           /* MSK_CIE_SAMPLES                             */
     uint32_t n_textures;        /* may be 0 (textures then unused)             */
     const msk_texture_desc *textures;
+    /* ABI v7: tabulated spectra (may be 0 / NULL) */
+    uint32_t n_regular_spectra, n_regular_values;
+    const msk_regular_spectrum_desc *regular_spectra;
+    const float *regular_values;
 } msk_scene_desc;
 
 /*
@@ -254,6 +283,12 @@ typedef struct msk_stats {
        reference switches the test off for blocks with AOV channels, integrator.cpp:59-60 — below -1e-5.  Such a sample is
        splatted all the same, as the reference does; the plugin logs the count at Warn level. */
     uint64_t invalid_samples;
+    /* ABI v7: the bytes of SoA path state the call's launches of the shading / traversal kernels were ASKED to move — counted
+       by the library from its own layout (what a live slot makes its kernels read and write), not measured:
+       shading 176 B per segment (+ 16 in the general variant) - 64 B per sample + 48 B per shadow ray + 20 B per sample record;
+       traversal 48 B per segment + 32 B (16 B for trees in HBM) per shadow ray.  bytes / launches_* = the algorithmic bytes per
+       launch a roofline needs; HBM traffic is a separate, measured figure (rocprofv3 PMC).  0 for MSK_RNG_PCG_BLOCK renders. */
+    uint64_t bytes_shade, bytes_trace;
 } msk_stats;
 
 typedef struct msk_ctx   msk_ctx;

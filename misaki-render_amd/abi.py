@@ -11,7 +11,8 @@ import os
 
 import numpy as np
 
-MSK_ABI_VERSION = 6
+MSK_ABI_VERSION = 7
+MSK_REGULAR_MAX = 95
 MSK_OK = 0
 MSK_ERR_INVALID_ARG, MSK_ERR_NO_DEVICE, MSK_ERR_HIP, MSK_ERR_OOM, MSK_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 MSK_BSDF_DIFFUSE, MSK_BSDF_ROUGHCONDUCTOR, MSK_BSDF_ROUGHDIELECTRIC = 0, 1, 2
@@ -30,8 +31,12 @@ class MeshDesc(C.Structure):
                 ("has_normals", C.c_uint32), ("has_texcoords", C.c_uint32)]
 
 
+class RegularSpectrumDesc(C.Structure):
+    _fields_ = [("lambda_min", C.c_float), ("lambda_max", C.c_float), ("size", C.c_uint32), ("first_value", C.c_uint32)]
+
+
 class SpectrumDesc(C.Structure):
-    _fields_ = [("coeff", C.c_float * 3), ("scale", C.c_float)]
+    _fields_ = [("coeff", C.c_float * 3), ("scale", C.c_float), ("regular", C.c_uint32)]
 
 
 class BsdfDesc(C.Structure):
@@ -39,7 +44,7 @@ class BsdfDesc(C.Structure):
                 ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("sample_visible", C.c_int32),
                 ("eta", SpectrumDesc), ("k", SpectrumDesc), ("specular_reflectance", SpectrumDesc),
                 ("specular_transmittance", SpectrumDesc), ("ior_eta", C.c_float), ("ior_inv_eta", C.c_float),
-                ("reflectance_texture", C.c_uint32), ("reflectance_scale", C.c_float)]
+                ("reflectance_texture", C.c_uint32), ("reflectance_scale", C.c_float), ("reflectance_regular", C.c_uint32)]
 
 
 class TextureDesc(C.Structure):
@@ -49,7 +54,7 @@ class TextureDesc(C.Structure):
 
 class EmitterDesc(C.Structure):
     _fields_ = [("type", C.c_int32), ("mesh_id", C.c_int32), ("radiance", C.c_float * 3),
-                ("d65_scale", C.c_float)]
+                ("d65_scale", C.c_float), ("radiance_regular", C.c_uint32)]
 
 
 class CameraDesc(C.Structure):
@@ -72,7 +77,9 @@ class SceneDesc(C.Structure):
                 ("n_vertices", C.c_uint32), ("n_faces", C.c_uint32),
                 ("camera", CameraDesc), ("film", FilmDesc),
                 ("cie1931_xyz", C.POINTER(C.c_float)), ("d65", C.POINTER(C.c_float)),
-                ("n_textures", C.c_uint32), ("textures", C.POINTER(TextureDesc))]
+                ("n_textures", C.c_uint32), ("textures", C.POINTER(TextureDesc)),
+                ("n_regular_spectra", C.c_uint32), ("n_regular_values", C.c_uint32),
+                ("regular_spectra", C.POINTER(RegularSpectrumDesc)), ("regular_values", C.POINTER(C.c_float))]
 
 
 class RenderParams(C.Structure):
@@ -88,7 +95,8 @@ class Stats(C.Structure):
                 ("ms_generate", C.c_float), ("ms_trace", C.c_float), ("ms_shade", C.c_float),
                 ("ms_resolve", C.c_float), ("n_trace_launches", C.c_uint32),
                 ("n_shade_launches", C.c_uint32), ("launches_trace", C.c_uint32), ("launches_shade", C.c_uint32),
-                ("launches_wavefront", C.c_uint32), ("invalid_samples", C.c_uint64)]
+                ("launches_wavefront", C.c_uint32), ("invalid_samples", C.c_uint64),
+                ("bytes_shade", C.c_uint64), ("bytes_trace", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -389,6 +389,23 @@ MSK_DEV spec regular_eval(const float *tbl, spec wl) {
     }
     return r;
 }
+// spectra/regular.cpp:73-91 on a table with its own grid (a `regular` spectrum of the scene, ABI v7): x = (l - lambda_min) *
+// inv_interval, the segment index clamped to [0, last] with last = size - 2.  Below the table the conversion saturates at 0
+// (the reference converts a negative float to uint32_t there — undefined in C++; the oracle takes 0 as well), above it the last
+// segment is continued, as the reference does.
+MSK_DEV spec regular_eval_grid(const float *tbl, float lam_min, float inv_interval, uint32_t last, spec wl) {
+    spec r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float x = (wl.v[i] - lam_min) * inv_interval;
+        uint32_t idx = (uint32_t) x;                 // v_cvt_u32_f32: saturating, a negative x gives 0
+        idx = idx < last ? idx : last;
+        float y0 = tbl[idx], y1 = tbl[idx + 1];
+        float w1 = x - (float) idx, w0 = 1.f - w1;
+        r.v[i] = w0 * y0 + w1 * y1;
+    }
+    return r;
+}
 // core/spectrum.h:82-115; cie = x[95] y[95] z[95]
 MSK_DEV void spectrum_to_xyz(const float *cie, spec value, spec wl, float *X, float *Y, float *Z) {
     spec cx, cy, cz;

@@ -107,8 +107,9 @@ struct msk_scene {
     DevBuf part_films[MSK_MAX_GROUP], staged[MSK_MAX_GROUP], group_film;
     Workspace *ws = nullptr;           // render buffers, kept between calls (hipMalloc/hipFree of GBs costs milliseconds)
     DeviceScene dev;
-    DevBuf nodes, nodes4, nodes4q, nodes8, tris, tris3, tri_bounds, tri_verts, tri_frames, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, cdf, cie;
+    DevBuf nodes, nodes4, nodes4q, nodes8, tris, tris3, tri_bounds, tri_verts, tri_frames, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, emitter_grid, spectra, cdf, cie;
     bool lds_scene = false, lds_tables = false, all_diffuse = true;
+    bool has_regular = false;          // the scene holds tabulated spectra (ABI v7): the shading instantiations that evaluate them run
     int trace_mode = 0;                // 0 binary tree in LDS, 1 binary tree in HBM/L2, 2 4-wide tree in HBM/L2, 4 8-wide quantised tree in HBM/L2,
                                        // 5 4-wide tree with quantised boxes in HBM/L2 (64-byte nodes; the default for trees in HBM)
     size_t trace_lds_bytes = 0, shade_lds_bytes = 0;
@@ -258,6 +259,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     }
     if (any_normals) tn.assign((size_t) d->n_faces * 12, 0.f);
     if (any_uvs) tuv.assign((size_t) d->n_faces * 8, 0.f);
+    int rc_spec = MSK_OK;
     std::vector<uint8_t> covered(d->n_faces, 0);
     std::vector<float> mesh_area(d->n_meshes, 0.f);
     std::vector<std::vector<float>> mesh_cdf(d->n_meshes);
@@ -304,7 +306,44 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     for (uint32_t g = 0; g < d->n_faces; ++g)
         if (!covered[g]) return fail(ctx, MSK_ERR_INVALID_ARG, "face %u belongs to no mesh", g);
 
-    static_assert(sizeof(msk_bsdf_desc) == 16 * MSK_BSDF_F4, "msk_bsdf_desc is uploaded verbatim as MSK_BSDF_F4 float4");
+    // ---- tabulated (`regular`) spectra, ABI v7 (spectra/regular.cpp:27-70): validated here, before any kernel indexes with them
+    if ((d->n_regular_spectra && !d->regular_spectra) || (d->n_regular_values && !d->regular_values))
+        return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: regular spectrum arrays missing");
+    if (d->n_regular_values >= (1u << 24))
+        return fail(ctx, MSK_ERR_UNSUPPORTED, "msk_gpu_scene_create: %u tabulated spectrum values, a spectrum record addresses fewer than 2^24", d->n_regular_values);
+    for (uint32_t k = 0; k < d->n_regular_spectra; ++k) {
+        const msk_regular_spectrum_desc &r = d->regular_spectra[k];
+        if (r.size < 2) return fail(ctx, MSK_ERR_INVALID_ARG, "regular spectrum %u: ContinuousDistribution: needs at least two entries!", k);     // regular.cpp:30-31
+        if (r.size > MSK_REGULAR_MAX) return fail(ctx, MSK_ERR_UNSUPPORTED, "regular spectrum %u: %u values, this back end takes at most %d", k, r.size, MSK_REGULAR_MAX);
+        if (!(r.lambda_min < r.lambda_max) || !std::isfinite(r.lambda_min) || !std::isfinite(r.lambda_max))
+            return fail(ctx, MSK_ERR_INVALID_ARG, "regular spectrum %u: ContinuousDistribution: invalid range!", k);                                // regular.cpp:33-34
+        if ((uint64_t) r.first_value + r.size > d->n_regular_values)
+            return fail(ctx, MSK_ERR_INVALID_ARG, "regular spectrum %u: values [%u, %u) exceed the %u in regular_values", k, r.first_value, r.first_value + r.size, d->n_regular_values);
+        bool mass = false;
+        for (uint32_t i = 0; i < r.size; ++i) {
+            const float v = d->regular_values[r.first_value + i];
+            if (!(v >= 0.f) || !std::isfinite(v)) return fail(ctx, MSK_ERR_INVALID_ARG, "regular spectrum %u: ContinuousDistribution: entries must be non-negative!", k);   // regular.cpp:59-60
+            mass |= v > 0.f;
+        }
+        if (!mass) return fail(ctx, MSK_ERR_INVALID_ARG, "regular spectrum %u: ContinuousDistribution: no probability mass found!", k);            // regular.cpp:73-74
+    }
+    // 1 / interval as RegularSpectrum keeps it: the interval in double, its reciprocal rounded to float (regular.cpp:42-43,66-70)
+    auto inv_interval = [&](const msk_regular_spectrum_desc &r) { return (float) (1.0 / (((double) r.lambda_max - (double) r.lambda_min) / (double) (r.size - 1))); };
+    bool any_regular = false;
+    // device form of an msk_spectrum_desc: {c0, c1, c2, scale} or {lambda_min, inv_interval, first | last << 24, -1} (msk_kernels.h: spectrum_eval)
+    auto spectrum_record = [&](const msk_spectrum_desc &sp, float *o, const char *what, uint32_t b) -> int {
+        if (sp.regular) {
+            if (sp.regular > d->n_regular_spectra) return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: %s names regular spectrum %u of %u", b, what, sp.regular, d->n_regular_spectra);
+            const msk_regular_spectrum_desc &r = d->regular_spectra[sp.regular - 1];
+            const uint32_t w = r.first_value | ((r.size - 2u) << 24);
+            o[0] = r.lambda_min; o[1] = inv_interval(r); std::memcpy(&o[2], &w, 4); o[3] = -1.f;
+            any_regular = true;
+            return MSK_OK;
+        }
+        if (!(sp.scale >= 0.f)) return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: the scale of %s must not be negative", b, what);
+        o[0] = sp.coeff[0]; o[1] = sp.coeff[1]; o[2] = sp.coeff[2]; o[3] = sp.scale;
+        return MSK_OK;
+    };
     if (d->n_textures && !d->textures) return fail(ctx, MSK_ERR_INVALID_ARG, "msk_gpu_scene_create: texture array missing");
     const uint32_t n_bsdf_f4 = std::max(1u, d->n_bsdfs) * MSK_BSDF_F4 + d->n_textures * 3;
     std::vector<float> bsdfs((size_t) n_bsdf_f4 * 4, 0.f);
@@ -331,16 +370,34 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
             return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: the relative index of refraction must be positive", b);
         if (bd.reflectance_texture > d->n_textures)
             return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: reflectance_texture %u out of range", b, bd.reflectance_texture);
-        if (bd.type == MSK_BSDF_DIFFUSE && !(bd.reflectance_scale >= 0.f && bd.reflectance_scale < INFINITY))
+        if (bd.type == MSK_BSDF_DIFFUSE && !bd.reflectance_regular && !(bd.reflectance_scale >= 0.f && bd.reflectance_scale < INFINITY))
             return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: reflectance_scale must be finite and non-negative (1 for an srgb reflectance)", b);
         if (bd.reflectance_texture && bd.type != MSK_BSDF_DIFFUSE)
             return fail(ctx, MSK_ERR_UNSUPPORTED, "bsdf %u: only the diffuse reflectance can be textured", b);
-        if (bd.type != MSK_BSDF_DIFFUSE || bd.back_bsdf >= 0 || bd.reflectance_texture) all_diffuse = false;
-        msk_bsdf_desc rec = bd;                                    // device form: the texture's float4 offset in the table
-        if (bd.reflectance_texture) rec.reflectance_texture = std::max(1u, d->n_bsdfs) * MSK_BSDF_F4 + (bd.reflectance_texture - 1) * 3;
-        std::memcpy(&bsdfs[(size_t) b * 4 * MSK_BSDF_F4], &rec, sizeof rec);
+        if (bd.reflectance_regular && (bd.type != MSK_BSDF_DIFFUSE || bd.reflectance_texture))
+            return fail(ctx, MSK_ERR_INVALID_ARG, "bsdf %u: reflectance_regular names the reflectance of an untextured diffuse BSDF", b);
+        if (bd.type != MSK_BSDF_DIFFUSE || bd.back_bsdf >= 0 || bd.reflectance_texture || bd.reflectance_regular) all_diffuse = false;
+        // the device record, MSK_BSDF_F4 float4 (msk_kernels.h: BsdfRec): {type, back, r0, r1} {r2, au, av, sample_visible} eta k
+        // spec trans {ior_eta, ior_inv_eta, float4 offset of the texture record, reflectance_scale}
+        float *o = &bsdfs[(size_t) b * 4 * MSK_BSDF_F4];
+        std::memcpy(&o[0], &bd.type, 4); std::memcpy(&o[1], &bd.back_bsdf, 4);
+        msk_spectrum_desc refl;
+        refl.coeff[0] = bd.reflectance[0]; refl.coeff[1] = bd.reflectance[1]; refl.coeff[2] = bd.reflectance[2];
+        refl.scale = bd.type == MSK_BSDF_DIFFUSE ? bd.reflectance_scale : 0.f; refl.regular = bd.reflectance_regular;
+        float r4[4];
+        if ((rc_spec = spectrum_record(refl, r4, "reflectance", b))) return rc_spec;
+        o[2] = r4[0]; o[3] = r4[1]; o[4] = r4[2];
+        o[5] = bd.alpha_u; o[6] = bd.alpha_v; std::memcpy(&o[7], &bd.sample_visible, 4);
+        if ((rc_spec = spectrum_record(bd.eta, &o[8], "eta", b)) || (rc_spec = spectrum_record(bd.k, &o[12], "k", b)) ||
+            (rc_spec = spectrum_record(bd.specular_reflectance, &o[16], "specular_reflectance", b)) ||
+            (rc_spec = spectrum_record(bd.specular_transmittance, &o[20], "specular_transmittance", b))) return rc_spec;
+        o[24] = bd.ior_eta; o[25] = bd.ior_inv_eta;
+        const uint32_t tex_off = bd.reflectance_texture ? std::max(1u, d->n_bsdfs) * MSK_BSDF_F4 + (bd.reflectance_texture - 1) * 3 : 0u;
+        std::memcpy(&o[26], &tex_off, 4);
+        o[27] = r4[3];                                             // reflectance_scale, or -1 for a tabulated reflectance
     }
     std::vector<float> emitters((size_t) std::max(1u, d->n_emitters) * 8, 0.f), d65((size_t) std::max(1u, d->n_emitters) * 95, 0.f), cdf_all;
+    std::vector<float> emitter_grid((size_t) std::max(1u, d->n_emitters) * 4, 0.f);
     int env_emitter = -1;
     for (uint32_t e = 0; e < d->n_emitters; ++e) {
         const msk_emitter_desc &ed = d->emitters[e];
@@ -365,8 +422,24 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         } else {
             return fail(ctx, MSK_ERR_UNSUPPORTED, "emitter %u: type %d is not supported (area, constant)", e, ed.type);
         }
-        for (int i = 0; i < 95; ++i) d65[e * 95 + i] = d->d65[i] * ed.d65_scale;   // d65.cpp:41-42
+        float *gr = &emitter_grid[(size_t) e * 4];
+        if (ed.radiance_regular) {          // a `regular` radiance: its own table on its own grid, no sigmoid factor (area.cpp:51-54, regular.cpp:148)
+            if (ed.radiance_regular > d->n_regular_spectra) return fail(ctx, MSK_ERR_INVALID_ARG, "emitter %u: radiance names regular spectrum %u of %u", e, ed.radiance_regular, d->n_regular_spectra);
+            const msk_regular_spectrum_desc &r = d->regular_spectra[ed.radiance_regular - 1];
+            for (uint32_t i = 0; i < r.size; ++i) d65[e * 95 + i] = d->regular_values[r.first_value + i];
+            const uint32_t last = r.size - 2u;
+            gr[0] = r.lambda_min; gr[1] = inv_interval(r); std::memcpy(&gr[2], &last, 4); gr[3] = 1.f;
+            o[0] = o[1] = 0.f; o[2] = INFINITY;
+            any_regular = true;
+        } else {
+            for (int i = 0; i < 95; ++i) d65[e * 95 + i] = d->d65[i] * ed.d65_scale;   // d65.cpp:41-42
+            const uint32_t last = 93u;
+            gr[0] = 360.f; gr[1] = (float) (1.0 / ((830.0 - 360.0) / 94.0)); std::memcpy(&gr[2], &last, 4); gr[3] = 0.f;
+        }
     }
+    if (any_regular) all_diffuse = false;              // tabulated spectra are evaluated by the general shading variant only
+    std::vector<float> spectra_pool(d->regular_values, d->regular_values + d->n_regular_values);
+    if (spectra_pool.empty()) spectra_pool.push_back(0.f);
     if (cdf_all.empty()) cdf_all.push_back(0.f);
 
     // oracle D10: the triangle-bounds predicate's padding, computed exactly as the oracle does (0.5e-5 of the scene's scale =
@@ -416,13 +489,14 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         }
 
     msk_scene *s = new msk_scene();
-    s->ctx = ctx; s->n_tris = d->n_faces; s->bvh_depth = bvh.max_depth; s->all_diffuse = all_diffuse;
+    s->ctx = ctx; s->n_tris = d->n_faces; s->bvh_depth = bvh.max_depth; s->all_diffuse = all_diffuse; s->has_regular = any_regular;
     std::vector<float> cie(d->cie1931_xyz, d->cie1931_xyz + 3 * MSK_CIE_SAMPLES);
     hipError_t e = hipSuccess;
     auto up = [&](DevBuf &b, const std::vector<float> &v) { if (e == hipSuccess) e = b.upload(v); };
     if (!gpu_build) { up(s->nodes, bvh.nodes); up(s->tris, bvh.tris); up(s->tri_bounds, bvh.bounds); }
     up(s->tri_verts, tv); up(s->tri_normals, tn); up(s->tri_uvs, tuv);
     up(s->bsdfs, bsdfs); up(s->emitters, emitters); up(s->emitter_d65, d65); up(s->cdf, cdf_all); up(s->cie, cie);
+    up(s->emitter_grid, emitter_grid); up(s->spectra, spectra_pool);
     if (e == hipSuccess) e = s->mesh_info.upload(mesh_info);
     if (e == hipSuccess && gpu_build) {
         const size_t nf = d->n_faces;
@@ -459,6 +533,7 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
     ds.tri_uvs = any_uvs ? s->tri_uvs.as<float4>() : nullptr;
     ds.mesh_info = s->mesh_info.as<int4>(); ds.bsdfs = s->bsdfs.as<float4>(); ds.emitters = s->emitters.as<float4>();
     ds.emitter_d65 = s->emitter_d65.as<float>(); ds.cdf = s->cdf.as<float>(); ds.cie = s->cie.as<float>();
+    ds.emitter_grid = s->emitter_grid.as<float4>(); ds.spectra = s->spectra.as<float>(); ds.n_spectra = d->n_regular_values;
     ds.n_nodes = (uint32_t) (bvh.nodes.size() / 16); ds.n_tris = d->n_faces; ds.n_emitters = d->n_emitters;
     ds.n_meshes = d->n_meshes; ds.n_bsdfs = d->n_bsdfs; ds.n_bsdf_f4 = n_bsdf_f4; ds.cdf_len = (uint32_t) cdf_all.size();
     ds.root_ref = bvh.root_ref;
@@ -561,12 +636,12 @@ extern "C" int msk_gpu_scene_create(msk_ctx *ctx, const msk_scene_desc *d, msk_s
         s->trace_lds_bytes = (size_t) ds.stack_entries * MSK_BLOCK * 4 + (size_t) MSK_BLOCK * 16;       // + four words per lane (node4_step)
     }
     // LDS plan of k_shade_gen: the small lookup tables (tri_verts, mesh/bsdf/emitter records, cdf, d65, cie)
-    const size_t table_bytes = ((size_t) ds.n_tris * 6 + ds.n_meshes + ds.n_bsdf_f4 + ds.n_emitters * 2 +
-                                (ds.n_emitters * 95 + 3) / 4 + (ds.cdf_len + 3) / 4 + 72) * 16;
+    const size_t table_bytes = ((size_t) ds.n_tris * 6 + ds.n_meshes + ds.n_bsdf_f4 + ds.n_emitters * 3 +
+                                (ds.n_emitters * 95 + 3) / 4 + (ds.cdf_len + 3) / 4 + 72 + (ds.n_spectra + 3) / 4) * 16;
     s->lds_tables = table_bytes <= 40 * 1024;
     // + the waves' done-queues (k_shade_gen: MSK_DONE_Q_F4 float4 per wave)
     // (a scene whose per-triangle tables stay in HBM still stages the small ones: msk_kernels.h, small_tables_float4s — the same formula)
-    const size_t small_bytes = ((size_t) ds.n_meshes + ds.n_bsdf_f4 + ds.n_emitters * 2 + (ds.n_emitters * 95 + 3) / 4 + (ds.cdf_len + 3) / 4 + 72) * 16;
+    const size_t small_bytes = ((size_t) ds.n_meshes + ds.n_bsdf_f4 + ds.n_emitters * 3 + (ds.n_emitters * 95 + 3) / 4 + (ds.cdf_len + 3) / 4 + 72 + (ds.n_spectra + 3) / 4) * 16;
     const size_t small_staged = small_bytes <= (size_t) MSK_SMALL_TABLES_KB * 1024 ? small_bytes : 0;
     s->shade_lds_bytes = (s->lds_tables ? table_bytes : small_staged) + (size_t) (MSK_BLOCK / MSK_WAVE) * MSK_DONE_Q_F4 * 16;
     if (s->trace_lds_bytes > ctx->prop.sharedMemPerBlock) {
@@ -877,6 +952,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
             // (not timed: msk_stats::ms_shade / ms_trace stay the sums of k_shade_gen / k_trace launches)
             hipEvent_t a = nullptr, b = nullptr;
             if (diffuse_only) hipExtLaunchKernelGGL((k_wavefront<true>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
+            else if (sc->has_regular) hipExtLaunchKernelGGL((k_wavefront<false, true>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
             else hipExtLaunchKernelGGL((k_wavefront<false>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
             p.it += fused_iters; p.last_iters = fused_iters;
             p.st.launches_wavefront += 1;
@@ -885,9 +961,9 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
                 hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
                 if (timed) { a = p.ev.get(); b = p.ev.get(); c = p.ev.get(); d = p.ev.get(); }
                 const bool have_ev = a && b && c && d;
-#define MSK_SHADE(L, D) hipExtLaunchKernelGGL((k_shade_gen<L, D>), dim3(grid), dim3(MSK_BLOCK), shade_lds + shade_pad_lds, stream_h, a, b, 0, sc->dev, sb.st, pp)
-                if (sc->lds_tables) { if (diffuse_only) MSK_SHADE(true, true); else MSK_SHADE(true, false); }
-                else { if (diffuse_only) MSK_SHADE(false, true); else MSK_SHADE(false, false); }
+#define MSK_SHADE(...) hipExtLaunchKernelGGL((k_shade_gen<__VA_ARGS__>), dim3(grid), dim3(MSK_BLOCK), shade_lds + shade_pad_lds, stream_h, a, b, 0, sc->dev, sb.st, pp)
+                if (sc->lds_tables) { if (diffuse_only) MSK_SHADE(true, true); else if (sc->has_regular) MSK_SHADE(true, false, true); else MSK_SHADE(true, false); }
+                else { if (diffuse_only) MSK_SHADE(false, true); else if (sc->has_regular) MSK_SHADE(false, false, true); else MSK_SHADE(false, false); }
 #undef MSK_SHADE
                 launch_trace(sc, stream_h, sb.st, pp, c, d);
                 p.st.launches_shade += 1; p.st.launches_trace += 1;
@@ -1036,6 +1112,17 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
             stats->ms_trace += hf.st.ms_trace; stats->ms_shade += hf.st.ms_shade;
             stats->n_trace_launches += hf.st.n_trace_launches; stats->n_shade_launches += hf.st.n_shade_launches;
             stats->launches_trace += hf.st.launches_trace; stats->launches_shade += hf.st.launches_shade; stats->launches_wavefront += hf.st.launches_wavefront;
+            // ABI v7: the bytes of SoA path state this pass's launches were asked to move (counted from what the kernels
+            // read and write per live slot, not measured): a segment = a slot that is live after a shading sweep.
+            //   shading  176 B/segment (id 8, wl, thr, res, ray_d, hit in; id 8, wl, thr, res, ray_o, ray_d out; + aux 8 in / 8 out in the
+            //            general variant) - 64 B/sample (a new sample's thr = 1 and res = 0 are neither written nor read)
+            //            + 48 B/shadow ray (contrib in; sh, contrib out) + 20 B/sample (its record)
+            //   traversal 48 B/segment (ray_o, ray_d in; hit out) + per shadow ray: sh in, and ray_o again where the shadow rays are a
+            //            second queue of the launch (k_trace_q / k_trace: 32 B; k_trace_r walks both rays of a slot together: 16 B)
+            const unsigned long long seg = hf.st.segments, smp = hf.st.samples, shd = hf.st.shadow_rays;
+            const bool lane_refill = sc->trace_mode != 0 && sc->trace_mode != 3 && (getenv("MSK_TRACE_REFILL") ? atoi(getenv("MSK_TRACE_REFILL")) != 0 : true);
+            stats->bytes_shade += seg * (176ull + (diffuse_only ? 0ull : 16ull)) + shd * 48ull + smp * 20ull - std::min(smp * 64ull, seg * 176ull);
+            stats->bytes_trace += seg * 48ull + shd * (lane_refill ? 16ull : 32ull);
         }
     }
     (void) ev_trace; (void) ev_shade;

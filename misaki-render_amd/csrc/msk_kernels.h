@@ -22,12 +22,13 @@
 // (imageblock.cpp:55-114, 133-173), so the film is bit-identical to the scalar CPU order.
 #pragma once
 #include "msk_device.h"
+#include <type_traits>
 #include "../../include/msk_gpu.h"
 
 namespace msk {
 
 #define MSK_WAVE 64
-#define MSK_BSDF_F4 7   /* sizeof(msk_bsdf_desc) / 16 */
+#define MSK_BSDF_F4 7   /* float4 per BSDF record (built from msk_bsdf_desc by msk_gpu_scene_create) */
 #define MSK_BLOCK 256
 #define MSK_LEAF_BIT 0x80000000u  /* child ref: leaf = BIT | first_tri << 5 | count ; inner = node index */
 #define MSK_NO_PRIM 0xffffffffu
@@ -63,12 +64,18 @@ struct DeviceScene {
     const float4 *tri_normals;  // 3 x float4 per triangle (n0 n1 n2) or nullptr
     const float4 *tri_uvs;      // 2 x float4 per triangle (uv0 uv1 | uv2 -) or nullptr
     const int4 *mesh_info;      // {bsdf_id, emitter_id, flags(1=normals,2=texcoords), first_face}
-    const float4 *bsdfs;        // MSK_BSDF_F4 x float4 per bsdf = msk_bsdf_desc verbatim (reflectance_texture rewritten as the
+    const float4 *bsdfs;        // MSK_BSDF_F4 x float4 per bsdf (BsdfRec; spectra as spectrum records, reflectance_texture as the
                                 // float4 offset of the texture record), then 3 x float4 per texture: {color0, m02} {color1, m12}
                                 // {m00 m01 m10 m11}
     uint32_t n_bsdf_f4;         // float4 count of `bsdfs` (records + textures)
     const float4 *emitters;     // 2 x float4 per emitter: {c0,c1,c2,inv_area} {mesh,first_face,face_count,cdf_off (uint bits)}
-    const float *emitter_d65;   // 95 floats per emitter (d65 * d65_scale)
+    const float *emitter_d65;   // 95 floats per emitter: d65 * d65_scale, or the values of a `regular` radiance (ABI v7)
+    const float4 *emitter_grid; // per emitter {lambda_min, inv_interval, last segment (uint bits), 1 = the table IS the radiance (no
+                                // sigmoid factor)} of that table: {360, 0.2, 93, 0} for the D65 form.  Read by the general shading
+                                // variant only: a scene with a tabulated emitter never runs the diffuse-only one
+    const float *spectra;       // values of the scene's other `regular` spectra (BSDF parameters), n_spectra floats; a spectrum
+                                // record {lambda_min, inv_interval, first | last << 24 (uint bits), -1} names its part
+    uint32_t n_spectra;
     const float *cdf;           // concatenated area CDFs (face_count+1 each)
     const float *cie;           // 285 floats
     uint32_t n_nodes, n_tris, n_emitters, n_meshes, n_bsdfs, cdf_len;
@@ -1320,9 +1327,17 @@ struct SceneTables {
     const int4 *mesh_info;
     const float4 *bsdfs, *emitters;
     const float *emitter_d65, *cdf, *cie;
+    const float4 *emitter_grid;
+    const float *spectra;
 };
+// The same tables for a scene that holds tabulated (`regular`) spectra: the TYPE selects the code that can evaluate them (spectrum
+// records of the table form, emitters' tables on their own grids).  Scenes without any — every BASELINE config — run the
+// instantiations that do not carry those branches (measured: 3.2 % of the config-3-class render, 1.4 % of the config-5-class one).
+struct SceneTablesR : SceneTables {};
+template <class TB> struct tb_traits { static constexpr bool regular = false; };
+template <> struct tb_traits<SceneTablesR> { static constexpr bool regular = true; };
 MSK_DEV uint32_t tables_lds_float4s(const DeviceScene &sc) {
-    return sc.n_tris * 6 + sc.n_meshes + sc.n_bsdf_f4 + sc.n_emitters * 2 + (sc.n_emitters * 95 + 3) / 4 + (sc.cdf_len + 3) / 4 + 72;
+    return sc.n_tris * 6 + sc.n_meshes + sc.n_bsdf_f4 + sc.n_emitters * 3 + (sc.n_emitters * 95 + 3) / 4 + (sc.cdf_len + 3) / 4 + 72 + (sc.n_spectra + 3) / 4;
 }
 // A scene whose per-triangle tables do not fit LDS can still keep the SMALL ones there (mesh / BSDF / texture / emitter records, the
 // emitters' D65 tables and area CDFs, the CIE table: every bounce and every finished sample looks several of them up through
@@ -1331,7 +1346,7 @@ MSK_DEV uint32_t tables_lds_float4s(const DeviceScene &sc) {
 #define MSK_SMALL_TABLES_KB 16
 #endif
 MSK_DEV uint32_t small_tables_float4s(const DeviceScene &sc) {
-    const uint32_t n = sc.n_meshes + sc.n_bsdf_f4 + sc.n_emitters * 2 + (sc.n_emitters * 95 + 3) / 4 + (sc.cdf_len + 3) / 4 + 72;
+    const uint32_t n = sc.n_meshes + sc.n_bsdf_f4 + sc.n_emitters * 3 + (sc.n_emitters * 95 + 3) / 4 + (sc.cdf_len + 3) / 4 + 72 + (sc.n_spectra + 3) / 4;
     return n * 16u <= MSK_SMALL_TABLES_KB * 1024u ? n : 0u;
 }
 template <bool LDS_TABLES>
@@ -1346,6 +1361,7 @@ MSK_DEV SceneTables stage_tables(const DeviceScene &sc, float4 *lds) {
         if (lds == nullptr || small_tables_float4s(sc) == 0u) {
             t.mesh_info = sc.mesh_info; t.bsdfs = sc.bsdfs; t.emitters = sc.emitters;
             t.emitter_d65 = sc.emitter_d65; t.cdf = sc.cdf; t.cie = sc.cie;
+            t.emitter_grid = sc.emitter_grid; t.spectra = sc.spectra;
             return t;
         }
     } else {
@@ -1358,6 +1374,8 @@ MSK_DEV SceneTables stage_tables(const DeviceScene &sc, float4 *lds) {
     t.emitter_d65 = copy1(sc.emitter_d65, sc.n_emitters * 95);
     t.cdf = copy1(sc.cdf, sc.cdf_len);
     t.cie = copy1(sc.cie, 285);
+    t.emitter_grid = copy4(sc.emitter_grid, sc.n_emitters);          // (after the older tables: their LDS offsets are those of ABI v6)
+    t.spectra = copy1(sc.spectra, sc.n_spectra);
     // (Round 5, measured and taken out: the area emitters' triangles — what every NEE sample reads — staged beside them: +-0;
     // tri_verts and tri_frames of a scene whose tables stay in HBM interleaved into ONE 128-byte line per triangle, so that a hit
     // touches one line instead of pieces of two to four: config-5 / config-3 class renders 116.2 / 138.9 ms against 115.9 / 138.2,
@@ -1430,9 +1448,17 @@ MSK_DEV Interaction make_interaction(const SceneTables &sc, float4 hit, f3 ray_d
     return si;
 }
 
-// spectra/srgb_d65.cpp:34-36
-MSK_DEV spec emitter_radiance(const SceneTables &sc, int e, spec wl) {
+// spectra/srgb_d65.cpp:34-36.  With SceneTablesR: the emitter's table on its own grid — the D65 grid again for the srgb_d65 form
+// (same constants, same bits), or a `regular` radiance as it stands (area.cpp:51-54 with RegularSpectrum::eval, regular.cpp:148).
+template <class TB>
+MSK_DEV spec emitter_radiance(const TB &sc, int e, spec wl) {
     const float4 c = sc.emitters[2 * e];
+    if (tb_traits<TB>::regular) {
+        const float4 g = sc.emitter_grid[e];
+        const spec t = regular_eval_grid(sc.emitter_d65 + 95 * e, g.x, g.y, __float_as_uint(g.z), wl);
+        if (g.w != 0.f) return t;
+        return t * srgb_model_eval(c.x, c.y, c.z, wl);
+    }
     return regular_eval(sc.emitter_d65 + 95 * e, wl) * srgb_model_eval(c.x, c.y, c.z, wl);
 }
 
@@ -1465,11 +1491,21 @@ MSK_DEV f3 checkerboard_coeffs(const SceneTables &tb, uint32_t rec, float4 hit) 
     const bool first = (fu > .5f) == (fv > .5f);
     return first ? mk3(t0.x, t0.y, t0.z) : mk3(t1.x, t1.y, t1.z);
 }
-MSK_DEV spec spectrum_eval(float4 s, spec wl) { return srgb_model_eval(s.x, s.y, s.z, wl) * s.w; }
+// a spectrum record: {c0, c1, c2, scale >= 0} = scale * S(c, l), or {lambda_min, inv_interval, first | last << 24, -1} = the
+// `regular` spectrum whose values start at tb.spectra[first] (msk_spectrum_desc::regular; RegularSpectrum::eval, regular.cpp:148)
+template <class TB>
+MSK_DEV spec spectrum_eval(const TB &tb, float4 s, spec wl) {
+    if (tb_traits<TB>::regular && s.w < 0.f) {
+        const uint32_t w = __float_as_uint(s.z);
+        return regular_eval_grid(tb.spectra + (w & 0xffffffu), s.x, s.y, w >> 24, wl);
+    }
+    return srgb_model_eval(s.x, s.y, s.z, wl) * s.w;
+}
 MSK_DEV float clamp_alpha(float a) { return fmax_std(a, 1e-4f); }
 
 // bsdfs/roughdielectric.cpp:118-190 eval + pdf (both lobes, TransportMode::Radiance)
-MSK_DEV void roughdielectric_eval_pdf(const BsdfRec &b, f3 wi, f3 wo, spec wl, spec *val, float *pdf) {
+template <class TB>
+MSK_DEV void roughdielectric_eval_pdf(const TB &tb, const BsdfRec &b, f3 wi, f3 wo, spec wl, spec *val, float *pdf) {
     const float cos_i = wi.z, cos_o = wo.z;
     if (cos_i == 0.f) return;
     const float au = clamp_alpha(b.b.y), av = clamp_alpha(b.b.z);
@@ -1482,11 +1518,11 @@ MSK_DEV void roughdielectric_eval_pdf(const BsdfRec &b, f3 wi, f3 wo, spec wl, s
     fresnel_dielectric(dot(wi, m), b.ior.x, &F, &ct, &e_it, &e_ti);
     const float G = smith_g1(wi, m, au, av) * smith_g1(wo, m, au, av);
     if (reflect) {
-        *val = spectrum_eval(b.spec, wl) * (F * D * G) / (4.f * fabsf(cos_i));
+        *val = spectrum_eval(tb, b.spec, wl) * (F * D * G) / (4.f * fabsf(cos_i));
     } else {
         const float scale = inv_eta * inv_eta;
         const float denom = dot(wi, m) + eta * dot(wo, m);
-        *val = spectrum_eval(b.trans, wl) *
+        *val = spectrum_eval(tb, b.trans, wl) *
                fabsf((scale * (1.f - F) * D * G * eta * eta * dot(wi, m) * dot(wo, m)) / (cos_i * (denom * denom)));
     }
     if (dot(wi, m) * wi.z <= 0.f || dot(wo, m) * wo.z <= 0.f) return;
@@ -1499,7 +1535,8 @@ MSK_DEV void roughdielectric_eval_pdf(const BsdfRec &b, f3 wi, f3 wo, spec wl, s
     *pdf = prob * fabsf(dwh_dwo);
 }
 // bsdfs/roughdielectric.cpp:57-116 sample; *eta_out = bs.eta
-MSK_DEV spec roughdielectric_sample(const BsdfRec &b, f3 wi, float sample1, f2 sample, spec wl, f3 *wo, float *pdf,
+template <class TB>
+MSK_DEV spec roughdielectric_sample(const TB &tb, const BsdfRec &b, f3 wi, float sample1, f2 sample, spec wl, f3 *wo, float *pdf,
                                     float *eta_out, bool *ok) {
     const float cos_i = wi.z;
     const float au = clamp_alpha(b.b.y), av = clamp_alpha(b.b.z);
@@ -1517,7 +1554,7 @@ MSK_DEV spec roughdielectric_sample(const BsdfRec &b, f3 wi, float sample1, f2 s
     float dwh_dwo;
     if (selected_r) {
         *wo = m * 2.f * dot(wi, m) - wi;
-        weight = weight * spectrum_eval(b.spec, wl);
+        weight = weight * spectrum_eval(tb, b.spec, wl);
         dwh_dwo = 1.f / (4.f * dot(*wo, m));
     } else {
         *wo = m * (dot(wi, m) * eta_ti + cos_t) - wi * eta_ti;
@@ -1534,8 +1571,8 @@ MSK_DEV spec roughdielectric_sample(const BsdfRec &b, f3 wi, float sample1, f2 s
 
 // eval + pdf with wi on the front side (roughconductor.cpp:82-117 / diffuse.cpp:35-57)
 // `refl` = the diffuse reflectance spectrum at wl, evaluated once per bounce by the caller (used by eval and by sample)
-template <bool DIFFUSE_ONLY>
-MSK_DEV void bsdf_eval_pdf(const BsdfRec &b, f3 wi, f3 wo, spec wl, spec refl, spec *val, float *pdf) {
+template <bool DIFFUSE_ONLY, class TB>
+MSK_DEV void bsdf_eval_pdf(const TB &tb, const BsdfRec &b, f3 wi, f3 wo, spec wl, spec refl, spec *val, float *pdf) {
     *val = splat(0.f); *pdf = 0.f;
     const float cos_i = wi.z, cos_o = wo.z;
     if (DIFFUSE_ONLY || __float_as_int(b.a.x) == 0) {
@@ -1545,7 +1582,7 @@ MSK_DEV void bsdf_eval_pdf(const BsdfRec &b, f3 wi, f3 wo, spec wl, spec refl, s
         }
         return;
     }
-    if (__float_as_int(b.a.x) == MSK_BSDF_ROUGHDIELECTRIC) { roughdielectric_eval_pdf(b, wi, wo, wl, val, pdf); return; }
+    if (__float_as_int(b.a.x) == MSK_BSDF_ROUGHDIELECTRIC) { roughdielectric_eval_pdf(tb, b, wi, wo, wl, val, pdf); return; }
     const float au = clamp_alpha(b.b.y), av = clamp_alpha(b.b.z);
     if (cos_i > 0.f && cos_o > 0.f) {
         const f3 H = normalized(wo + wi);
@@ -1553,12 +1590,12 @@ MSK_DEV void bsdf_eval_pdf(const BsdfRec &b, f3 wi, f3 wo, spec wl, spec refl, s
         if (D != 0) {
             const float G = smith_g1(wi, H, au, av) * smith_g1(wo, H, au, av);
             const float result = D * G / (4.f * wi.z);
-            const spec eta = spectrum_eval(b.eta, wl), kk = spectrum_eval(b.k, wl);
+            const spec eta = spectrum_eval(tb, b.eta, wl), kk = spectrum_eval(tb, b.k, wl);
             const float c = dot(wi, H);
             spec F;
 #pragma unroll
             for (int i = 0; i < 4; ++i) F.v[i] = fresnel_conductor(c, eta.v[i], kk.v[i]);
-            *val = F * spectrum_eval(b.spec, wl) * result;
+            *val = F * spectrum_eval(tb, b.spec, wl) * result;
         }
     }
     const f3 m = normalized(wo + wi);
@@ -1568,12 +1605,12 @@ MSK_DEV void bsdf_eval_pdf(const BsdfRec &b, f3 wi, f3 wo, spec wl, spec refl, s
     }
 }
 // sample with wi on the front side; returns the weight, fills wo / pdf / ok (= a direction was produced)
-template <bool DIFFUSE_ONLY>
-MSK_DEV spec bsdf_sample(const BsdfRec &b, f3 wi, float sample1, f2 sample, spec wl, spec refl, f3 *wo, float *pdf, float *eta_out,
+template <bool DIFFUSE_ONLY, class TB>
+MSK_DEV spec bsdf_sample(const TB &tb, const BsdfRec &b, f3 wi, float sample1, f2 sample, spec wl, spec refl, f3 *wo, float *pdf, float *eta_out,
                          bool *ok) {
     *wo = mk3(0.f, 0.f, 0.f); *pdf = 0.f; *ok = false; *eta_out = 1.f;
     if (!DIFFUSE_ONLY && __float_as_int(b.a.x) == MSK_BSDF_ROUGHDIELECTRIC)
-        return roughdielectric_sample(b, wi, sample1, sample, wl, wo, pdf, eta_out, ok);
+        return roughdielectric_sample(tb, b, wi, sample1, sample, wl, wo, pdf, eta_out, ok);
     const float cos_i = wi.z;
     if (cos_i <= 0.f) return splat(0.f);
     *ok = true;
@@ -1590,7 +1627,7 @@ MSK_DEV spec bsdf_sample(const BsdfRec &b, f3 wi, float sample1, f2 sample, spec
     if (__float_as_int(b.b.w)) weight = smith_g1(*wo, m, au, av);
     else weight = smith_g1(wi, m, au, av) * smith_g1(*wo, m, au, av) * dot(wi, m) / (cos_i * m.z);
     *pdf /= 4.f * dot(*wo, m);
-    const spec eta = spectrum_eval(b.eta, wl), kk = spectrum_eval(b.k, wl);
+    const spec eta = spectrum_eval(tb, b.eta, wl), kk = spectrum_eval(tb, b.k, wl);
     const float c = dot(wi, m);
     spec F;
 #pragma unroll
@@ -1789,8 +1826,8 @@ MSK_DEV bool sort_by_class(const PathState &st, const RegionView &in, const Sort
 // region's plain-diffuse range and its misses by the diffuse code at four waves per SIMD, the classes in between + the sweep's
 // tail by the general variant.  Bit-identical, and slower: config-5 / config-3 class renders +4.5 % / +3.7 % — every region is
 // visited, sorted and its counters read and written twice, and two thin launches drain twice.)
-template <bool DIFFUSE_ONLY>
-MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, const DoneQueue &dq, const SortScratch &ss, const PathState &st,
+template <bool DIFFUSE_ONLY, class TB>
+MSK_DEV RegionView shade_region(const DeviceScene &sc, const TB &tb, const DoneQueue &dq, const SortScratch &ss, const PathState &st,
                                 const PassParams &pp, uint32_t wave, uint32_t lane) {
     uint32_t n_queued = 0;
     RegionCtl rc = pp.regions[wave];
@@ -1927,7 +1964,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
                     float scale = bs.ior.w;
                     const uint32_t tex = __float_as_uint(bs.ior.z);
                     if (tex) { c = checkerboard_coeffs(tb, tex, hit); scale = 1.f; }
-                    refl = srgb_model_eval(c.x, c.y, c.z, wl) * scale;
+                    refl = spectrum_eval(tb, make_float4(c.x, c.y, c.z, scale), wl);      // (scale -1: a `regular` reflectance)
                 }
                 // ---- next-event estimation (path.cpp:56-67, scene.cpp:68-103)
                 if (n_em > 0) {
@@ -1994,7 +2031,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
                         f3 wo = si.sh.to_local(d);
                         if (flipped) wo.z = -wo.z;
                         spec bsdf_val; float bsdf_pdf;
-                        bsdf_eval_pdf<DIFFUSE_ONLY>(bs, wi_s, wo, wl, refl, &bsdf_val, &bsdf_pdf);
+                        bsdf_eval_pdf<DIFFUSE_ONLY>(tb, bs, wi_s, wo, wl, refl, &bsdf_val, &bsdf_pdf);
                         const float w = mis_weight(pdf, bsdf_pdf);
                         contrib = thr * emitter_val * bsdf_val * w;
                         if (any_nonzero(contrib)) {
@@ -2008,7 +2045,7 @@ MSK_DEV RegionView shade_region(const DeviceScene &sc, const SceneTables &tb, co
                     const f2 u2 = counter_pair(key, pb + 2);
                     f3 wo_l; bool ok; float bs_eta;
                     const float sample1 = DIFFUSE_ONLY ? 0.f : counter_pair(key, pb + 1).x;
-                    const spec bsdf_val = bsdf_sample<DIFFUSE_ONLY>(bs, wi_s, sample1, u2, wl, refl, &wo_l, &bs_pdf, &bs_eta, &ok);
+                    const spec bsdf_val = bsdf_sample<DIFFUSE_ONLY>(tb, bs, wi_s, sample1, u2, wl, refl, &wo_l, &bs_pdf, &bs_eta, &ok);
                     if (!ok) {
                         // failed sample: zero direction, the reference's ray misses and the loop ends (path.cpp:89-97) — but the
                         // NEE term of this bounce was added before the sample (path.cpp:60-66).  diffuse / roughconductor fail
@@ -2165,10 +2202,11 @@ MSK_DEV DoneQueue done_queue(float4 *base) {
     return dq;
 }
 
-template <bool LDS_TABLES, bool DIFFUSE_ONLY>
+template <bool LDS_TABLES, bool DIFFUSE_ONLY, bool REGULAR = false>
 MSK_DEV void shade_gen_body(const DeviceScene &sc, const PathState &st, const PassParams &pp) {
     extern __shared__ float4 lds_dyn[];
-    const SceneTables tb = stage_tables<LDS_TABLES>(sc, lds_dyn);
+    typename std::conditional<REGULAR, SceneTablesR, SceneTables>::type tb;
+    static_cast<SceneTables &>(tb) = stage_tables<LDS_TABLES>(sc, lds_dyn);
     const uint32_t lwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
     const uint32_t queue_f4 = LDS_TABLES ? tables_lds_float4s(sc) : small_tables_float4s(sc);   // after the staged tables
     const DoneQueue dq = done_queue(lds_dyn + queue_f4);
@@ -2180,9 +2218,9 @@ MSK_DEV void shade_gen_body(const DeviceScene &sc, const PathState &st, const Pa
     if (lwave >= pp.region_count) return;
     shade_region<DIFFUSE_ONLY>(sc, tb, dq, ss, st, pp, pp.region_first + lwave, threadIdx.x & (MSK_WAVE - 1));
 }
-template <bool LDS_TABLES, bool DIFFUSE_ONLY>
+template <bool LDS_TABLES, bool DIFFUSE_ONLY, bool REGULAR = false>
 __global__ void __launch_bounds__(MSK_BLOCK)
-k_shade_gen(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<LDS_TABLES, DIFFUSE_ONLY>(sc, st, pp); }
+k_shade_gen(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<LDS_TABLES, DIFFUSE_ONLY, REGULAR>(sc, st, pp); }
 // The general variants sit a few registers above the 168 that three waves per SIMD allow (two cost 20 % of the shading time
 // on the mesh scenes): the allocator is told to stay at three.
 #ifndef MSK_SHADE_GEN_WAVES
@@ -2194,6 +2232,13 @@ k_shade_gen<false, false>(DeviceScene sc, PathState st, PassParams pp) { shade_g
 template <>
 __global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_SHADE_GEN_WAVES)))
 k_shade_gen<true, false>(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<true, false>(sc, st, pp); }
+// ... and the same two for scenes with tabulated spectra
+template <>
+__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_SHADE_GEN_WAVES)))
+k_shade_gen<false, false, true>(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<false, false, true>(sc, st, pp); }
+template <>
+__global__ void __launch_bounds__(MSK_BLOCK) __attribute__((amdgpu_waves_per_eu(MSK_SHADE_GEN_WAVES)))
+k_shade_gen<true, false, true>(DeviceScene sc, PathState st, PassParams pp) { shade_gen_body<true, false, true>(sc, st, pp); }
 // The diffuse-only variants fit four waves per SIMD (128 VGPRs, no scratch); left alone, the allocator spends 24 more registers
 // on the explicit fp64 fma chains of det_sincos and lands at three.
 #ifndef MSK_NO_SHADE4
@@ -2212,12 +2257,13 @@ k_shade_gen<true, true>(DeviceScene sc, PathState st, PassParams pp) { shade_gen
 // left (or `max_iters` sweeps have run: a bounded launch, the host relaunches while work remains).  Tables, tree and
 // triangles are staged once per block instead of once per launch.  Same arithmetic as k_shade_gen / k_trace<0>: same records.
 // ------------------------------------------------------------------------------------------
-template <bool DIFFUSE_ONLY>
+template <bool DIFFUSE_ONLY, bool REGULAR = false>
 __global__ void __launch_bounds__(MSK_BLOCK)
 k_wavefront(DeviceScene sc, PathState st, PassParams pp, uint32_t max_iters, uint32_t queue_f4, uint32_t trace_f4) {
     extern __shared__ float4 lds_dyn[];
     // LDS: [tables][done queues][traversal stacks][tree + triangles]; offsets in float4 from the host's plan
-    const SceneTables tb = stage_tables<true>(sc, lds_dyn);
+    typename std::conditional<REGULAR, SceneTablesR, SceneTables>::type tb;
+    static_cast<SceneTables &>(tb) = stage_tables<true>(sc, lds_dyn);
     const DoneQueue dq = done_queue(lds_dyn + queue_f4);
     uint32_t *stack_base = (uint32_t *) (lds_dyn + trace_f4);
     float4 *scene_lds = lds_dyn + trace_f4 + (sc.stack_entries * MSK_BLOCK) / 4;

@@ -153,6 +153,7 @@ static void group_merge_stats(msk_stats *out, const std::vector<msk_stats> &st, 
         out->ms_trace += s.ms_trace; out->ms_shade += s.ms_shade; out->ms_resolve = std::max(out->ms_resolve, s.ms_resolve);
         out->n_trace_launches += s.n_trace_launches; out->n_shade_launches += s.n_shade_launches;
         out->launches_trace += s.launches_trace; out->launches_shade += s.launches_shade; out->launches_wavefront += s.launches_wavefront;
+        out->bytes_shade += s.bytes_shade; out->bytes_trace += s.bytes_trace;
     }
     out->ms_total = ms_wall;                 // host wall time of the whole call: the members' renders side by side + the film sum
 }

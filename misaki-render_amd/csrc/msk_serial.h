@@ -74,7 +74,8 @@ k_path_serial(DeviceScene sc, SerialParams prm) {
     if (prm.per_wave && (threadIdx.x & (MSK_WAVE - 1u))) return;
     const uint32_t bi = prm.per_wave ? tid / MSK_WAVE : tid;
     if (bi >= prm.n_blocks) return;
-    const SceneTables tb = stage_tables<false>(sc, nullptr);
+    SceneTablesR tb;                        // (the fidelity mode carries the table forms of tabulated spectra always: one instantiation)
+    static_cast<SceneTables &>(tb) = stage_tables<false>(sc, nullptr);
     const BlockInfo b = prm.blocks[bi];
     const int border = sc.filter_border;
     const int sx = b.size_x + 2 * border, sy = b.size_y + 2 * border;
@@ -144,7 +145,7 @@ k_path_serial(DeviceScene sc, SerialParams prm) {
                         float scale = bs.ior.w;
                         const uint32_t tex = __float_as_uint(bs.ior.z);
                         if (tex) { c = checkerboard_coeffs(tb, tex, hit); scale = 1.f; }
-                        refl = srgb_model_eval(c.x, c.y, c.z, wl) * scale;
+                        refl = spectrum_eval(tb, make_float4(c.x, c.y, c.z, scale), wl);
                     }
                     const float tmin = (1.f + max_abs(si.p)) * MSK_RAY_EPS_F;          // interaction.h:40-44
                     // ---- next-event estimation (path.cpp:56-67, scene.cpp:68-103); the draw is made whatever the scene holds
@@ -206,7 +207,7 @@ k_path_serial(DeviceScene sc, SerialParams prm) {
                                 f3 wo = si.sh.to_local(d);
                                 if (flipped) wo.z = -wo.z;
                                 spec bsdf_val; float bsdf_pdf;
-                                bsdf_eval_pdf<false>(bs, wi_s, wo, wl, refl, &bsdf_val, &bsdf_pdf);
+                                bsdf_eval_pdf<false>(tb, bs, wi_s, wo, wl, refl, &bsdf_val, &bsdf_pdf);
                                 const float w = mis_weight(pdf, bsdf_pdf);
                                 const spec contrib = thr * emitter_val * bsdf_val * w;
                                 if (any_nonzero(contrib)) {                            // scene.cpp:91-95: an occluded sample adds nothing
@@ -223,7 +224,7 @@ k_path_serial(DeviceScene sc, SerialParams prm) {
                     const float sample1 = rng.next_float();
                     f2 u2; u2.x = rng.next_float(); u2.y = rng.next_float();
                     f3 wo_l; bool ok; float bs_pdf, bs_eta;
-                    const spec bsdf_val = bsdf_sample<false>(bs, wi_s, sample1, u2, wl, refl, &wo_l, &bs_pdf, &bs_eta, &ok);
+                    const spec bsdf_val = bsdf_sample<false>(tb, bs, wi_s, sample1, u2, wl, refl, &wo_l, &bs_pdf, &bs_eta, &ok);
                     f3 wo = mk3(0.f, 0.f, 0.f);
                     if (ok) { if (flipped) wo_l.z = -wo_l.z; wo = si.sh.to_world(wo_l); ++n_segments; }
                     // the sampled ray (a failed sample's zero direction finds nothing: path.cpp:89-97)

@@ -3,6 +3,7 @@
 // not happen here: the "path" integrator flattens these objects into msk_scene_desc and calls the
 // C ABI (include/msk_gpu.h).
 #pragma once
+#include <cstring>
 #include "core.h"
 #include "msk_gpu.h"
 
@@ -11,12 +12,18 @@ namespace misaki {
 class Scene; class Shape; class Mesh; class BSDF; class Emitter; class Sensor; class Film; class Sampler;
 class ReconstructionFilter; class ImageBlock; class Integrator;
 
+// include/misaki/core/mathutils.h:17 / core/spectrum.h:75
+namespace math { constexpr float Epsilon = 5.9604644775390625e-08f; }       // std::numeric_limits<float>::epsilon() / 2
+#define MSK_CIE_Y_NORMALIZATION float(1.0 / 106.7502593994140625)
+
 // include/misaki/render/texture.h — spectra as the back end sees them
 class Texture : public Object {
 public:
     // plugins that the GPU back end can evaluate describe themselves as a sigmoid-polynomial
     // (render/srgb.h:8-19) optionally multiplied by a scaled D65 table (spectra/srgb_d65.cpp:34-36)
-    struct Flat { float coeff[3] = {0, 0, 0}; float scale = 1.f; float d65_scale = 0.f; bool uses_d65 = false; };
+    // ... or as a table on a regular wavelength grid (spectra/regular.cpp): `regular` with lambda_min / lambda_max / values
+    struct Flat { float coeff[3] = {0, 0, 0}; float scale = 1.f; float d65_scale = 0.f; bool uses_d65 = false;
+                  bool regular = false; float lambda_min = 0.f, lambda_max = 0.f; std::vector<float> values; };
     virtual bool flatten(Flat &out) const { (void) out; return false; }
     // plugins whose value varies with si.uv describe themselves as an msk_texture_desc instead
     virtual bool flatten_texture(msk_texture_desc &out) const { (void) out; return false; }
@@ -26,6 +33,26 @@ public:
 protected:
     Texture(const Properties &props) : m_id(props.id()) {}
     std::string m_id;
+};
+
+// the scene-level tables a BSDF / emitter adds to while it flattens itself: textures that vary over the surface and
+// tabulated spectra (msk_scene_desc::textures / regular_spectra / regular_values)
+struct FlatTables {
+    std::vector<msk_texture_desc> &textures;
+    std::vector<msk_regular_spectrum_desc> &regular;
+    std::vector<float> &regular_values;
+    uint32_t add_regular(const Texture::Flat &f) {          // -> the 1-based index msk_spectrum_desc::regular holds
+        regular.push_back(msk_regular_spectrum_desc{f.lambda_min, f.lambda_max, (uint32_t) f.values.size(), (uint32_t) regular_values.size()});
+        regular_values.insert(regular_values.end(), f.values.begin(), f.values.end());
+        return (uint32_t) regular.size();
+    }
+    // a spectrum the device evaluates as scale * S(coeff, l) or as a table; false for the illuminant forms
+    bool put(msk_spectrum_desc &d, const Texture::Flat &f) {
+        if (f.uses_d65) return false;
+        std::memcpy(d.coeff, f.coeff, sizeof f.coeff); d.scale = f.scale; d.regular = f.regular ? add_regular(f) : 0u;
+        if (f.regular) { d.coeff[0] = d.coeff[1] = d.coeff[2] = 0.f; d.scale = 1.f; }
+        return true;
+    }
 };
 
 // include/misaki/render/rfilter.h
@@ -100,7 +127,7 @@ protected:
 class BSDF : public Object {
 public:
     // `textures`: the scene's table of surface-varying textures; a BSDF that uses one appends it (msk_bsdf_desc::reflectance_texture)
-    virtual bool flatten(msk_bsdf_desc &out, std::vector<msk_texture_desc> &textures) const { (void) out; (void) textures; return false; }
+    virtual bool flatten(msk_bsdf_desc &out, FlatTables &tables) const { (void) out; (void) tables; return false; }
     virtual const BSDF *nested(int side) const { (void) side; return nullptr; }   // twosided: the BSDF of side 0 / 1
     std::string id() const override { return m_id; }
     MSK_DECLARE_CLASS()
@@ -112,7 +139,7 @@ protected:
 // include/misaki/render/emitter.h
 class Emitter : public Object {
 public:
-    virtual bool flatten(msk_emitter_desc &out) const { (void) out; return false; }
+    virtual bool flatten(msk_emitter_desc &out, FlatTables &tables) const { (void) out; (void) tables; return false; }
     virtual bool is_environment() const { return false; }
     virtual bool is_surface() const { return false; }
     void set_shape(Shape *shape);
@@ -237,6 +264,8 @@ struct FlatScene {
     std::vector<msk_bsdf_desc> bsdfs;
     std::vector<msk_emitter_desc> emitters;
     std::vector<msk_texture_desc> textures;
+    std::vector<msk_regular_spectrum_desc> regular;      // tabulated spectra (ABI v7) and their values
+    std::vector<float> regular_values;
     std::vector<float> vertices;
     std::vector<uint32_t> faces;
     msk_render_params params;

@@ -201,6 +201,43 @@ private:
 MSK_IMPLEMENT_CLASS(UniformSpectrum, Texture)
 MSK_REGISTER_INSTANCE(UniformSpectrum, "uniform")
 
+// spectra/regular.cpp:27-91,148: a spectrum tabulated on a regular wavelength grid (what <spectrum value="l0:v0, l1:v1, ..."/>
+// with equidistant wavelengths makes, xml.cpp:300-341).  Same properties: size, lambda_min, lambda_max, values (a pointer to
+// `size` floats, read here); same checks and messages as SpectrumContinuousDistribution::update (regular.cpp:27-70).
+class RegularSpectrum final : public Texture {
+public:
+    RegularSpectrum(const Properties &props) : Texture(props) {
+        m_lambda_min = props.float_("lambda_min"); m_lambda_max = props.float_("lambda_max");
+        const int size = props.int_("size");
+        const float *values = (const float *) props.pointer("values");
+        if (size < 2) Throw("ContinuousDistribution: needs at least two entries!");
+        if (!(m_lambda_min < m_lambda_max)) Throw("ContinuousDistribution: invalid range!");
+        m_values.assign(values, values + size);
+        const double interval_size = ((double) m_lambda_max - (double) m_lambda_min) / (size - 1);
+        double integral = 0.;
+        bool mass = false;
+        for (int i = 0; i + 1 < size; ++i) {
+            const double y0 = m_values[i], y1 = m_values[i + 1], value = 0.5 * interval_size * (y0 + y1);
+            integral += value;
+            if (y0 < 0. || y1 < 0.) Throw("ContinuousDistribution: entries must be non-negative!");
+            mass |= value > 0.;
+        }
+        if (!mass) Throw("ContinuousDistribution: no probability mass found!");
+        m_integral = (float) integral;
+    }
+    bool flatten(Flat &out) const override {
+        out.regular = true; out.uses_d65 = false; out.lambda_min = m_lambda_min; out.lambda_max = m_lambda_max; out.values = m_values;
+        return true;
+    }
+    float mean() const override { return m_integral; }              // regular.cpp:150 returns the integral
+    MSK_DECLARE_CLASS()
+private:
+    float m_lambda_min, m_lambda_max, m_integral = 0.f;
+    std::vector<float> m_values;
+};
+MSK_IMPLEMENT_CLASS(RegularSpectrum, Texture)
+MSK_REGISTER_INSTANCE(RegularSpectrum, "regular")
+
 // srgb with the normalisation of spectra/srgb_d65.cpp:18-22 but no illuminant: value = scale * S(fetch(rgb / scale))
 // for colours above 1 (conductor eta / k given as <rgb>), plain srgb otherwise
 class SRGBUnboundedSpectrum final : public Texture {
@@ -270,7 +307,7 @@ public:
     }
     bool flatten_texture(msk_texture_desc &out) const override {
         Flat c0, c1;
-        if (!m_color0->flatten(c0) || !m_color1->flatten(c1) || c0.uses_d65 || c1.uses_d65 || c0.scale != 1.f || c1.scale != 1.f) return false;
+        if (!m_color0->flatten(c0) || !m_color1->flatten(c1) || c0.uses_d65 || c1.uses_d65 || c0.regular || c1.regular || c0.scale != 1.f || c1.scale != 1.f) return false;
         std::memset(&out, 0, sizeof out);
         out.type = MSK_TEXTURE_CHECKERBOARD;
         std::memcpy(out.color0, c0.coeff, sizeof c0.coeff);
@@ -402,17 +439,19 @@ static void init_bsdf_desc(msk_bsdf_desc &out) {
 class SmoothDiffuse final : public BSDF {
 public:
     SmoothDiffuse(const Properties &props) : BSDF(props) { m_reflectance = props.texture("reflectance", 0.5f); }
-    bool flatten(msk_bsdf_desc &out, std::vector<msk_texture_desc> &textures) const override {
+    bool flatten(msk_bsdf_desc &out, FlatTables &tables) const override {
         Texture::Flat f;
         msk_texture_desc td;
         init_bsdf_desc(out);
         out.type = MSK_BSDF_DIFFUSE;
-        if (m_reflectance->flatten(f) && !f.uses_d65) {
+        if (m_reflectance->flatten(f) && f.regular) {                // a tabulated reflectance (spectra/regular.cpp)
+            out.reflectance_regular = tables.add_regular(f);
+        } else if (m_reflectance->flatten(f) && !f.uses_d65) {
             std::memcpy(out.reflectance, f.coeff, sizeof f.coeff);
             out.reflectance_scale = f.scale;
         } else if (m_reflectance->flatten_texture(td)) {            // a reflectance that varies over the surface
-            textures.push_back(td);
-            out.reflectance_texture = (uint32_t) textures.size();
+            tables.textures.push_back(td);
+            out.reflectance_texture = (uint32_t) tables.textures.size();
         } else {
             return false;
         }
@@ -459,16 +498,13 @@ public:
         else { const float v = props.float_(name); p.set_color("color", Color3{v, v, v}); }
         return InstanceManager::get()->create_instance<Texture>(p);
     }
-    bool flatten(msk_bsdf_desc &out, std::vector<msk_texture_desc> &textures) const override {
-        (void) textures;
+    bool flatten(msk_bsdf_desc &out, FlatTables &tables) const override {
         Texture::Flat e, k, s;
         if (!m_eta->flatten(e) || !m_k->flatten(k) || !m_specular_reflectance->flatten(s) || e.uses_d65 || k.uses_d65 || s.uses_d65) return false;
         init_bsdf_desc(out);
         out.type = MSK_BSDF_ROUGHCONDUCTOR;
         out.alpha_u = m_alpha_u; out.alpha_v = m_alpha_v; out.sample_visible = m_sample_visible ? 1 : 0;
-        auto put = [](msk_spectrum_desc &d, const Texture::Flat &f) { std::memcpy(d.coeff, f.coeff, sizeof f.coeff); d.scale = f.scale; };
-        put(out.eta, e); put(out.k, k); put(out.specular_reflectance, s);
-        return true;
+        return tables.put(out.eta, e) && tables.put(out.k, k) && tables.put(out.specular_reflectance, s);
     }
     MSK_DECLARE_CLASS()
 private:
@@ -504,17 +540,14 @@ public:
             m_alpha_u = m_alpha_v = props.float_("alpha", 0.1f);
         }
     }
-    bool flatten(msk_bsdf_desc &out, std::vector<msk_texture_desc> &textures) const override {
-        (void) textures;
+    bool flatten(msk_bsdf_desc &out, FlatTables &tables) const override {
         Texture::Flat r, t;
         if (!m_specular_reflectance->flatten(r) || !m_specular_transmittance->flatten(t) || r.uses_d65 || t.uses_d65) return false;
         init_bsdf_desc(out);
         out.type = MSK_BSDF_ROUGHDIELECTRIC;
         out.alpha_u = m_alpha_u; out.alpha_v = m_alpha_v; out.sample_visible = m_sample_visible ? 1 : 0;
         out.ior_eta = m_eta; out.ior_inv_eta = m_inv_eta;
-        auto put = [](msk_spectrum_desc &d, const Texture::Flat &f) { std::memcpy(d.coeff, f.coeff, sizeof f.coeff); d.scale = f.scale; };
-        put(out.specular_reflectance, r); put(out.specular_transmittance, t);
-        return true;
+        return tables.put(out.specular_reflectance, r) && tables.put(out.specular_transmittance, t);
     }
     MSK_DECLARE_CLASS()
 private:
@@ -538,7 +571,7 @@ public:
         if (!m_brdf[1]) m_brdf[1] = m_brdf[0];
     }
     const BSDF *nested(int i) const override { return m_brdf[i].get(); }
-    bool flatten(msk_bsdf_desc &out, std::vector<msk_texture_desc> &textures) const override { return m_brdf[0]->flatten(out, textures); }   // front side; flatten_scene adds the back
+    bool flatten(msk_bsdf_desc &out, FlatTables &tables) const override { return m_brdf[0]->flatten(out, tables); }   // front side; flatten_scene adds the back
     MSK_DECLARE_CLASS()
 private:
     ref<BSDF> m_brdf[2];
@@ -551,11 +584,12 @@ class AreaLight final : public Emitter {
 public:
     AreaLight(const Properties &props) : Emitter(props) { m_radiance = props.texture("radiance", Texture::D65(1.f)); }
     bool is_surface() const override { return true; }
-    bool flatten(msk_emitter_desc &out) const override {
+    bool flatten(msk_emitter_desc &out, FlatTables &tables) const override {
         Texture::Flat f;
-        if (!m_radiance->flatten(f) || !f.uses_d65) return false;
+        if (!m_radiance->flatten(f) || !(f.uses_d65 || f.regular)) return false;
         std::memset(&out, 0, sizeof out);
         out.type = MSK_EMITTER_AREA;
+        if (f.regular) { out.radiance_regular = tables.add_regular(f); return true; }      // a `regular` radiance as it stands
         std::memcpy(out.radiance, f.coeff, sizeof f.coeff);
         out.d65_scale = f.d65_scale;
         return true;
@@ -572,12 +606,13 @@ class ConstantBackgroundEmitter final : public Emitter {
 public:
     ConstantBackgroundEmitter(const Properties &props) : Emitter(props) { m_radiance = props.texture("radiance", Texture::D65(1.f)); }
     bool is_environment() const override { return true; }
-    bool flatten(msk_emitter_desc &out) const override {
+    bool flatten(msk_emitter_desc &out, FlatTables &tables) const override {
         Texture::Flat f;
-        if (!m_radiance->flatten(f) || !f.uses_d65) return false;
+        if (!m_radiance->flatten(f) || !(f.uses_d65 || f.regular)) return false;
         std::memset(&out, 0, sizeof out);
         out.type = MSK_EMITTER_CONSTANT;
         out.mesh_id = -1;
+        if (f.regular) { out.radiance_regular = tables.add_regular(f); return true; }      // a `regular` radiance as it stands
         std::memcpy(out.radiance, f.coeff, sizeof f.coeff);
         out.d65_scale = f.d65_scale;
         return true;
@@ -754,11 +789,13 @@ MSK_REGISTER_INSTANCE(OBJMesh, "obj")
 // =========================================================================== flatten
 void flatten_scene(const Scene *scene, const Sensor *sensor, FlatScene &out) {
     out.meshes.clear(); out.bsdfs.clear(); out.emitters.clear(); out.textures.clear(); out.vertices.clear(); out.faces.clear();
+    out.regular.clear(); out.regular_values.clear();
+    FlatTables tables{out.textures, out.regular, out.regular_values};
     // Scene::m_emitters order (scene.cpp:27-41) decides which emitter sample_emitter_direct picks (scene.cpp:80-84)
     std::map<const Emitter *, int> emitter_index;
     for (auto &e : scene->emitters()) {
         msk_emitter_desc ed;
-        if (!e->flatten(ed))
+        if (!e->flatten(ed, tables))
             Throw("Emitter \"{}\" cannot be evaluated by the GPU path integrator", e->clazz()->name());
         if (!e->is_surface() && !e->is_environment())
             Throw("Emitter \"{}\" is not attached to a shape: not supported by the GPU path integrator", e->clazz()->name());
@@ -771,14 +808,14 @@ void flatten_scene(const Scene *scene, const Sensor *sensor, FlatScene &out) {
         if (!shape->is_mesh()) Throw("Shape {} (\"{}\") is not a triangle mesh: not supported by the GPU path integrator", i, shape->id());
         const Mesh *mesh = static_cast<const Mesh *>(shape);
         msk_bsdf_desc bd;
-        if (!shape->bsdf()->flatten(bd, out.textures))
+        if (!shape->bsdf()->flatten(bd, tables))
             Throw("BSDF \"{}\" of shape {} cannot be evaluated by the GPU path integrator", shape->bsdf()->clazz()->name(), i);
         if (const BSDF *back = shape->bsdf()->nested(1)) {          // twosided adapter (twosided.cpp:38-101)
             if (back == shape->bsdf()->nested(0)) {
                 bd.back_bsdf = (int32_t) out.bsdfs.size();
             } else {
                 msk_bsdf_desc bb;
-                if (!back->flatten(bb, out.textures)) Throw("BSDF \"{}\" of shape {} cannot be evaluated by the GPU path integrator", back->clazz()->name(), i);
+                if (!back->flatten(bb, tables)) Throw("BSDF \"{}\" of shape {} cannot be evaluated by the GPU path integrator", back->clazz()->name(), i);
                 out.bsdfs.push_back(bb);
                 bd.back_bsdf = (int32_t) out.bsdfs.size() - 1;
             }
@@ -812,6 +849,8 @@ void flatten_scene(const Scene *scene, const Sensor *sensor, FlatScene &out) {
     std::memcpy(d.film.filter_lut, film->filter()->values().data(), sizeof d.film.filter_lut);
     d.cie1931_xyz = cie1931_xyz_table(); d.d65 = d65_table();
     d.n_textures = (uint32_t) out.textures.size(); d.textures = out.textures.data();
+    d.n_regular_spectra = (uint32_t) out.regular.size(); d.n_regular_values = (uint32_t) out.regular_values.size();
+    d.regular_spectra = out.regular.data(); d.regular_values = out.regular_values.data();
 }
 
 // "0,1,2" -> {0,1,2}; empty -> {single}

@@ -7,6 +7,7 @@
 #include <misaki/core.h>
 #include <misaki/render.h>
 
+#include <cmath>
 #include <cstring>
 #include <fstream>
 #include <set>
@@ -277,15 +278,48 @@ std::pair<std::string, std::string> parse(Context &ctx, Node &n, Tag parent_tag,
             }
             case Tag::Spectrum: {
                 check_attributes(rd, n, {"name", "value", "filename"}, false);
+                // xml.cpp:565-627: exactly one of value / filename; one token = a constant, else wavelength:value pairs
+                if ((n.attr("value") != nullptr) == (n.attr("filename") != nullptr)) rd.fail(n.offset, "'spectrum' tag requires one of \"value\" or \"filename\" attributes");
+                if (n.attr("filename")) rd.fail(n.offset, "<spectrum filename=...> is not implemented (nor is it by the reference loader, xml.cpp:620-622)");
                 auto t = string::tokenize(n.value("value"));
-                if (n.attr("filename") || t.size() != 1) rd.fail(n.offset, "only constant <spectrum value=\"c\"/> is supported by this loader");
-                float c = parse_float(rd, n, t[0]);
-                // xml.cpp:279-300: uniform c (reflectance) or D65 * c (inside an emitter)
-                Properties p(within_emitter ? "d65" : "uniform");
-                if (within_emitter) p.set_float("scale", c); else p.set_float("value", c);
-                ref<Object> o = InstanceManager::get()->create_instance(p, Class::for_name("Texture"));
-                auto ex = o->expand();
-                props.set_object(n.value("name"), ex.empty() ? o : ex[0]);
+                if (t.size() == 1) {
+                    float c = parse_float(rd, n, t[0]);
+                    // xml.cpp:279-300: uniform c (reflectance) or D65 * c (inside an emitter)
+                    Properties p(within_emitter ? "d65" : "uniform");
+                    if (within_emitter) p.set_float("scale", c); else p.set_float("value", c);
+                    ref<Object> o = InstanceManager::get()->create_instance(p, Class::for_name("Texture"));
+                    auto ex = o->expand();
+                    props.set_object(n.value("name"), ex.empty() ? o : ex[0]);
+                    break;
+                }
+                // xml.cpp:594-619 + create_texture_from_spectrum (:300-341): the pairs, the unit conversion inside an emitter
+                // (values are scaled so that D65 integrates to a luminance of 1), regular or irregular by the steps
+                std::vector<float> wavelengths, values;
+                for (auto &tok : t) {
+                    auto pair = string::tokenize(tok, ":");
+                    if (pair.size() != 2) rd.fail(n.offset, "invalid spectrum (expected wavelength:value pairs)");
+                    wavelengths.push_back(parse_float(rd, n, pair[0])); values.push_back(parse_float(rd, n, pair[1]));
+                }
+                const float unit_conversion = within_emitter ? MSK_CIE_Y_NORMALIZATION : 1.f;
+                bool is_regular = true;
+                float interval = 0.f;
+                for (size_t k = 0; k < wavelengths.size(); ++k) {
+                    values[k] *= unit_conversion;
+                    if (k == 0) continue;
+                    const float distance = wavelengths[k] - wavelengths[k - 1];
+                    if (distance < 0.f) rd.fail(n.offset, "Wavelengths must be specified in increasing order!");
+                    if (k == 1) interval = distance;
+                    else if (std::abs(distance - interval) > math::Epsilon) is_regular = false;
+                }
+                if (!is_regular)
+                    rd.fail(n.offset, "spectrum \"" + n.value("name") + "\": unequal wavelength steps make an `irregular` spectrum (spectra/irregular.cpp), which "
+                            "the GPU path integrator cannot evaluate; resample it on a regular grid (the `regular` plugin)");
+                Properties p("regular");
+                p.set_int("size", (int) wavelengths.size());
+                p.set_float("lambda_min", wavelengths.front());
+                p.set_float("lambda_max", wavelengths.back());
+                p.set_pointer("values", values.data());              // read by the plugin's constructor, below
+                props.set_object(n.value("name"), InstanceManager::get()->create_instance(p, Class::for_name("Texture")));
                 break;
             }
             case Tag::Transform:

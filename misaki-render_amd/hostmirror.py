@@ -226,7 +226,8 @@ def write_obj(mesh, path):
 def _bsdf_xml(m, v3):
     """The <bsdf> element of one shape (reference plugin parameter names)."""
     spec = m.bsdf
-    refl_xml = '<spectrum name="reflectance" value="%.9g"/>' % float(m.reflectance) if np.isscalar(m.reflectance) else \
+    refl_xml = '<spectrum name="reflectance" value="%s"/>' % m.reflectance.text if isinstance(m.reflectance, Regular) else \
+               '<spectrum name="reflectance" value="%.9g"/>' % float(m.reflectance) if np.isscalar(m.reflectance) else \
                '<rgb name="reflectance" value="%s"/>' % v3(m.reflectance)
     if spec is None:
         return ['        <bsdf type="diffuse">', '            ' + refl_xml, '        </bsdf>']
@@ -257,7 +258,8 @@ def _bsdf_xml(m, v3):
             "roughdielectric": ("specular_reflectance", "specular_transmittance")}[spec["type"]]
     for k in keys:
         if k in spec:
-            body.append('<rgb name="%s" value="%s"/>' % (k, v3(spec[k])))
+            body.append('<spectrum name="%s" value="%s"/>' % (k, spec[k].text) if isinstance(spec[k], Regular) else
+                        '<rgb name="%s" value="%s"/>' % (k, v3(spec[k])))
     for k in ("int_ior", "ext_ior"):
         if k in spec:
             body.append('<float name="%s" value="%r"/>' % (k, float(spec[k])))
@@ -290,7 +292,8 @@ def write_scene_xml(meshes, directory, width, height, spp, camera=None, integrat
 
     def env_xml():
         rad = env.get("radiance")
-        body = ['        <rgb name="radiance" value="%s"/>' % v3(rad)] if rad is not None else \
+        body = ['        <spectrum name="radiance" value="%s"/>' % rad.text] if isinstance(rad, Regular) else \
+               ['        <rgb name="radiance" value="%s"/>' % v3(rad)] if rad is not None else \
                (['        <spectrum name="radiance" value="%r"/>' % float(env["scale"])] if "scale" in env else [])   # D65 * scale
         return ['    <emitter type="constant">'] + body + ['    </emitter>']
     if env is not None and env.get("first"):
@@ -303,7 +306,8 @@ def write_scene_xml(meshes, directory, width, height, spp, camera=None, integrat
                     '        </transform>']
         out += _bsdf_xml(m, v3)
         if m.radiance is not None:
-            out += ['        <emitter type="area">', '            <rgb name="radiance" value="%s"/>' % v3(m.radiance), '        </emitter>']
+            out += ['        <emitter type="area">', '            <spectrum name="radiance" value="%s"/>' % m.radiance.text if isinstance(m.radiance, Regular)
+                    else '            <rgb name="radiance" value="%s"/>' % v3(m.radiance), '        </emitter>']
         out.append('    </shape>')
     if env is not None and not env.get("first"):
         out += env_xml()
@@ -382,9 +386,58 @@ def blob_mesh(name, center, radius, n_theta, n_phi, reflectance, seed=1, bump=0.
     return MeshSpec(name, faces, reflectance)
 
 
-def spectrum_desc(rgb, fetch):
+MSK_CIE_Y_NORMALIZATION = np.float32(1.0 / 106.7502593994140625)       # include/misaki/core/spectrum.h:75
+
+
+class Regular:
+    """A tabulated spectrum on a regular grid = the reference's `regular` texture (spectra/regular.cpp:27-91): what
+    <spectrum value="l0:v0, l1:v1, ..."/> with equidistant wavelengths makes (xml.cpp:300-341).  Accepted wherever the mirror takes
+    an rgb: MeshSpec.reflectance, MeshSpec.radiance, a BSDF's eta / k / specular_*, the environment's radiance."""
+
+    def __init__(self, lambda_min, lambda_max, values, text=None):
+        self.lambda_min, self.lambda_max = float(np.float32(lambda_min)), float(np.float32(lambda_max))
+        self.values = np.asarray(values, np.float32).copy()
+        self.text = text          # the "l:v, l:v, ..." it was parsed from (write_scene_xml writes it back)
+
+    @staticmethod
+    def from_pairs(text, within_emitter=False):
+        """create_texture_from_spectrum (xml.cpp:279-341) for "l:v, l:v, ...": values x MSK_CIE_Y_NORMALIZATION inside an
+        <emitter>; the steps must agree within math::Epsilon (else the reference makes an `irregular` spectrum, which the back
+        end does not take)."""
+        pairs = [t.split(":") for t in text.replace(",", " ").split()]
+        wl = np.array([np.float32(a) for a, _ in pairs], np.float32)
+        v = np.array([np.float32(b) for _, b in pairs], np.float32)
+        if within_emitter:
+            v = v * MSK_CIE_Y_NORMALIZATION
+        step = np.diff(wl)
+        if (step < 0).any():
+            raise ValueError("Wavelengths must be specified in increasing order!")
+        if len(wl) > 2 and (np.abs(step[1:] - step[0]) > np.float32(2.0 ** -24)).any():
+            raise ValueError("irregular spectrum (unequal wavelength steps): not supported by the GPU path integrator")
+        return Regular(wl[0], wl[-1], v, text=text)
+
+
+class _RegularPool:
+    """The scene's regular_spectra / regular_values arrays while a scene is flattened."""
+
+    def __init__(self):
+        self.descs, self.values = [], []
+
+    def add(self, r):
+        n = len(r.values)
+        if not (2 <= n <= abi.MSK_REGULAR_MAX):
+            raise ValueError("a regular spectrum needs 2..%d values (got %d)" % (abi.MSK_REGULAR_MAX, n))
+        self.descs.append(abi.RegularSpectrumDesc(r.lambda_min, r.lambda_max, n, len(self.values)))
+        self.values += [float(x) for x in r.values]
+        return len(self.descs)
+
+
+def spectrum_desc(rgb, fetch, pool=None):
     """rgb -> msk_spectrum_desc.  In-gamut colours: S(fetch(rgb)); values above 1 (conductor eta/k) use the
-    normalisation of spectra/srgb_d65.cpp:18-22 without the D65 factor: scale = 2 max, fetch(rgb / scale)."""
+    normalisation of spectra/srgb_d65.cpp:18-22 without the D65 factor: scale = 2 max, fetch(rgb / scale).
+    A Regular: the tabulated form (its index in the scene's pool)."""
+    if isinstance(rgb, Regular):
+        return abi.SpectrumDesc((C.c_float * 3)(0.0, 0.0, 0.0), 1.0, pool.add(rgb))
     rgb = np.asarray(rgb, np.float32)
     if rgb.max() <= 1.0:
         return abi.SpectrumDesc((C.c_float * 3)(*fetch(tuple(float(x) for x in rgb))), 1.0)
@@ -408,7 +461,7 @@ def _texture_desc(tex, fetch):
     return t
 
 
-def _bsdf_desc(m, fetch, index, textures=None):
+def _bsdf_desc(m, fetch, index, textures=None, pool=None):
     b = abi.BsdfDesc()
     b.back_bsdf = -1
     one = abi.SpectrumDesc((C.c_float * 3)(0.0, 0.0, float("inf")), 1.0)
@@ -418,7 +471,9 @@ def _bsdf_desc(m, fetch, index, textures=None):
     spec = m.bsdf or {"type": "diffuse"}
     if spec["type"] == "diffuse":
         b.type = abi.MSK_BSDF_DIFFUSE
-        if np.isscalar(m.reflectance):        # <spectrum name="reflectance" value="c"/>: the `uniform` plugin (spectra/uniform.cpp)
+        if isinstance(m.reflectance, Regular):
+            b.reflectance_regular = pool.add(m.reflectance)
+        elif np.isscalar(m.reflectance):        # <spectrum name="reflectance" value="c"/>: the `uniform` plugin (spectra/uniform.cpp)
             b.reflectance[:] = (0.0, 0.0, float("inf"))
             b.reflectance_scale = float(m.reflectance)
         else:
@@ -432,8 +487,8 @@ def _bsdf_desc(m, fetch, index, textures=None):
         a = spec.get("alpha", 0.1)
         b.alpha_u, b.alpha_v = (a, a) if np.isscalar(a) else a
         b.sample_visible = int(bool(spec.get("sample_visible", False)))
-        b.eta, b.k = spectrum_desc(spec["eta"], fetch), spectrum_desc(spec["k"], fetch)
-        b.specular_reflectance = spectrum_desc(spec.get("specular_reflectance", (1.0, 1.0, 1.0)), fetch)
+        b.eta, b.k = spectrum_desc(spec["eta"], fetch, pool), spectrum_desc(spec["k"], fetch, pool)
+        b.specular_reflectance = spectrum_desc(spec.get("specular_reflectance", (1.0, 1.0, 1.0)), fetch, pool)
     elif spec["type"] == "roughdielectric":
         # bsdfs/roughdielectric.cpp:14-24: m_eta = int_ior / ext_ior in fp32
         b.type = abi.MSK_BSDF_ROUGHDIELECTRIC
@@ -442,8 +497,8 @@ def _bsdf_desc(m, fetch, index, textures=None):
         b.sample_visible = int(bool(spec.get("sample_visible", False)))
         int_ior, ext_ior = np.float32(spec.get("int_ior", 1.5046)), np.float32(spec.get("ext_ior", 1.00028))
         b.ior_eta, b.ior_inv_eta = float(int_ior / ext_ior), float(ext_ior / int_ior)
-        b.specular_reflectance = spectrum_desc(spec.get("specular_reflectance", (1.0, 1.0, 1.0)), fetch)
-        b.specular_transmittance = spectrum_desc(spec.get("specular_transmittance", (1.0, 1.0, 1.0)), fetch)
+        b.specular_reflectance = spectrum_desc(spec.get("specular_reflectance", (1.0, 1.0, 1.0)), fetch, pool)
+        b.specular_transmittance = spectrum_desc(spec.get("specular_transmittance", (1.0, 1.0, 1.0)), fetch, pool)
     else:
         raise ValueError(spec["type"])
     if spec.get("twosided"):
@@ -484,20 +539,25 @@ def flatten(meshes, width, height, camera=None, filter_stddev=0.5, coeff_lookup=
     camera = camera or CBOX_CAMERA
     fs = FlatScene()
     all_v, all_f, md, bd, ed, td = [], [], [], [], [], []
+    pool = _RegularPool()
     nv = nf = 0
 
+    def emitter_desc(kind, mesh_id, radiance, scale_in=1.0):
+        if isinstance(radiance, Regular):        # a `regular` radiance as it stands (no D65 factor, no sigmoid)
+            return abi.EmitterDesc(kind, mesh_id, (C.c_float * 3)(0.0, 0.0, 0.0), 0.0, pool.add(radiance))
+        ce, sc = _radiance_desc(radiance, fetch, scale_in)
+        return abi.EmitterDesc(kind, mesh_id, (C.c_float * 3)(*ce), float(sc), 0)
+
     def env_desc():
-        ce, sc = _radiance_desc(env.get("radiance"), fetch, env.get("scale", 1.0))
-        return abi.EmitterDesc(abi.MSK_EMITTER_CONSTANT, -1, (C.c_float * 3)(*ce), sc)
+        return emitter_desc(abi.MSK_EMITTER_CONSTANT, -1, env.get("radiance"), env.get("scale", 1.0))
     if env is not None and env.get("first"):
         ed.append(env_desc())
     for i, m in enumerate(meshes):
         v, f = triangulate(m)
-        bd.append(_bsdf_desc(m, fetch, len(bd), td))
+        bd.append(_bsdf_desc(m, fetch, len(bd), td, pool))
         eid = -1
         if m.radiance is not None:
-            ce, d65_scale = _radiance_desc(m.radiance, fetch)
-            ed.append(abi.EmitterDesc(abi.MSK_EMITTER_AREA, i, (C.c_float * 3)(*ce), float(d65_scale)))
+            ed.append(emitter_desc(abi.MSK_EMITTER_AREA, i, m.radiance))
             eid = len(ed) - 1
         md.append(abi.MeshDesc(nv, len(v), nf, len(f), i, eid, 0, 1 if m.texcoords is not None else 0))
         all_v.append(v)
@@ -513,12 +573,17 @@ def flatten(meshes, width, height, camera=None, filter_stddev=0.5, coeff_lookup=
     bsdfs_a = (abi.BsdfDesc * max(1, len(bd)))(*bd)
     emit_a = (abi.EmitterDesc * max(1, len(ed)))(*ed)
     tex_a = (abi.TextureDesc * max(1, len(td)))(*td)
-    fs.keep += [verts, faces, cie, d65, meshes_a, bsdfs_a, emit_a, tex_a]
+    reg_a = (abi.RegularSpectrumDesc * max(1, len(pool.descs)))(*pool.descs)
+    reg_v = np.ascontiguousarray(np.array(pool.values + ([] if pool.values else [0.0]), np.float32))
+    fs.keep += [verts, faces, cie, d65, meshes_a, bsdfs_a, emit_a, tex_a, reg_a, reg_v]
     d = fs.desc
     d.abi_version = abi.MSK_ABI_VERSION
     d.n_meshes, d.n_bsdfs, d.n_emitters = len(md), len(bd), len(ed)
     d.meshes, d.bsdfs, d.emitters = meshes_a, bsdfs_a, emit_a
     d.n_textures, d.textures = len(td), tex_a
+    d.n_regular_spectra, d.n_regular_values = len(pool.descs), len(pool.values)
+    d.regular_spectra = reg_a
+    d.regular_values = reg_v.ctypes.data_as(C.POINTER(C.c_float))
     d.vertices = verts.ctypes.data_as(C.POINTER(C.c_float))
     d.faces = faces.ctypes.data_as(C.POINTER(C.c_uint32))
     d.n_vertices, d.n_faces = nv, nf

@@ -115,6 +115,11 @@ struct Scene {
     std::vector<float> mesh_area;          // Mesh::m_surface_area
     std::vector<std::vector<float>> mesh_cdf;  // Distribution1D::m_cdf per mesh
     std::vector<std::vector<float>> emitter_d65;  // RegularSpectrum::m_pdf per emitter
+    // spectra/regular.cpp:27-70: RegularSpectrum::m_distr of every tabulated spectrum of the scene (ABI v7), and which grid the
+    // emitter's radiance table lives on (the D65 grid, or its own when the radiance is a `regular` spectrum)
+    struct RegularTable { float range_x, inv_interval; std::vector<float> pdf; };
+    std::vector<RegularTable> regular;
+    std::vector<RegularTable> emitter_table;
     float tri_pad = 0.f;                   // D10: half the BVH padding, see intersect_triangle
     int env = -1;                          // Scene::m_environment as an index into emitters
     float env_radius = 0.f;                // ConstantBackgroundEmitter::m_bsphere.radius after set_scene
@@ -237,12 +242,26 @@ static Scene *scene_from_desc(const msk_scene_desc *d) {
         }
         area_distr_build(*sc, m);
     }
+    // spectra/regular.cpp:27-70: SpectrumContinuousDistribution(range, values, size); update() computes the interval in double
+    // and keeps 1 / interval as a float (:66-70)
+    for (uint32_t k = 0; k < d->n_regular_spectra; ++k) {
+        const msk_regular_spectrum_desc &r = d->regular_spectra[k];
+        Scene::RegularTable t;
+        t.range_x = r.lambda_min;
+        const double interval_size = ((double) r.lambda_max - (double) r.lambda_min) / (double) (r.size - 1);
+        t.inv_interval = (float) (1.0 / interval_size);
+        t.pdf.assign(d->regular_values + r.first_value, d->regular_values + r.first_value + r.size);
+        sc->regular.push_back(t);
+    }
     // spectra/srgb_d65.cpp:24-31 -> d65.cpp:37-45: values = d65_data[i] * m_scale
     sc->emitter_d65.resize(d->n_emitters);
+    sc->emitter_table.resize(d->n_emitters);
     for (uint32_t e = 0; e < d->n_emitters; ++e) {
         sc->emitter_d65[e].resize(MSK_CIE_SAMPLES);
         for (int i = 0; i < MSK_CIE_SAMPLES; ++i)
             sc->emitter_d65[e][i] = sc->d65[i] * sc->emitters[e].d65_scale;
+        if (sc->emitters[e].radiance_regular) sc->emitter_table[e] = sc->regular[sc->emitters[e].radiance_regular - 1];
+        else sc->emitter_table[e] = Scene::RegularTable{360.f, (float) (1.0 / ((830.0 - 360.0) / 94.0)), sc->emitter_d65[e]};
     }
     // scene.cpp:35-41 m_environment; constant.cpp:21-28 set_scene: sphere around Scene::bbox() (bbox.h:105-112)
     for (uint32_t e = 0; e < d->n_emitters; ++e)
@@ -472,23 +491,27 @@ static Interaction compute_interaction(const Scene &sc, const Ray &ray, const Hi
 // ===========================================================================
 // a12  spectra
 // ===========================================================================
-// spectra/regular.cpp:73-91 eval_pdf over [360,830], 95 samples, interval 5
-static S4 regular_eval(const std::vector<float> &tbl, S4 wl) {
-    const float range_x = 360.f;
-    const float inv_interval = (float) (1.0 / ((830.0 - 360.0) / 94.0));   // regular.cpp:70
+// spectra/regular.cpp:73-91 eval_pdf on the table's own grid (D65: [360,830], 95 samples, interval 5).
+// The segment index: `x.cast<uint32_t>().cwiseMin(size - 2).cwiseMax(0)` in the reference.  Above the table that is size - 2 (the
+// last segment continued linearly).  BELOW it the reference converts a negative float to uint32_t — undefined in C++; the
+// restatement takes index 0 there (the first segment continued linearly: what the cwiseMax(0) is written for, and what the
+// device's saturating conversion gives).  Wavelengths are sampled in [360, 830]: D65 and CIE never see either case.
+static S4 regular_eval(const Scene::RegularTable &t, S4 wl) {
+    const uint32_t last = (uint32_t) t.pdf.size() - 2u;
     S4 r;
     for (int i = 0; i < 4; ++i) {
-        float x = (wl.v[i] - range_x) * inv_interval;
-        uint32_t idx = std::max(std::min((uint32_t) x, (uint32_t) (MSK_CIE_SAMPLES - 2)), 0u);
-        float y0 = tbl[idx], y1 = tbl[idx + 1];
+        float x = (wl.v[i] - t.range_x) * t.inv_interval;
+        uint32_t idx = x > 0.f ? std::min((uint32_t) std::min(x, 4.0e9f), last) : 0u;
+        float y0 = t.pdf[idx], y1 = t.pdf[idx + 1];
         float w1 = x - (float) idx, w0 = 1.f - w1;
         r.v[i] = w0 * y0 + w1 * y1;
     }
     return r;
 }
-// spectra/srgb_d65.cpp:34-36
+// spectra/srgb_d65.cpp:34-36; a `regular` radiance (AreaLight::m_radiance->eval, area.cpp:51-54): the table as it stands
 static S4 emitter_radiance(const Scene &sc, int e, S4 wl) {
-    return regular_eval(sc.emitter_d65[e], wl) * srgb_model_eval(sc.emitters[e].radiance, wl);
+    if (sc.emitters[e].radiance_regular) return regular_eval(sc.emitter_table[e], wl);
+    return regular_eval(sc.emitter_table[e], wl) * srgb_model_eval(sc.emitters[e].radiance, wl);
 }
 // core/spectrum.h:82-115 cie1931_xyz + spectrum_to_xyz
 static void spectrum_to_xyz(const Scene &sc, S4 value, S4 wl, float xyz[3]) {
@@ -678,7 +701,10 @@ static float mis_weight(float pdf_a, float pdf_b) {
 struct BSDFSampleRec { V3 wo; float pdf, eta; uint32_t sampled_type; };   // render/bsdf.h:60-80
 enum : uint32_t { kDiffuseReflection = 1u, kGlossyReflection = 2u, kGlossyTransmission = 4u };
 
-static S4 spectrum_eval(const msk_spectrum_desc &sp, S4 wl) { return srgb_model_eval(sp.coeff, wl) * sp.scale; }
+static S4 spectrum_eval(const Scene &sc, const msk_spectrum_desc &sp, S4 wl) {
+    if (sp.regular) return regular_eval(sc.regular[sp.regular - 1], wl);          // RegularSpectrum::eval (regular.cpp:148)
+    return srgb_model_eval(sp.coeff, wl) * sp.scale;
+}
 
 // render/microfacet.h:11-18
 static float eval_ggx(V3 m, float au, float av) {
@@ -747,7 +773,7 @@ static void fresnel_dielectric(float cos_theta_i, float eta, float *F, float *co
     *F = r;
 }
 // bsdfs/roughdielectric.cpp:118-190 eval + pdf (both lobes enabled, TransportMode::Radiance)
-static void roughdielectric_eval_pdf(const msk_bsdf_desc &b, V3 wi, V3 wo, S4 wl, S4 *val, float *pdf) {
+static void roughdielectric_eval_pdf(const Scene &sc, const msk_bsdf_desc &b, V3 wi, V3 wo, S4 wl, S4 *val, float *pdf) {
     *val = s4(0.f); *pdf = 0.f;
     const float cos_i = wi.z, cos_o = wo.z;
     if (cos_i == 0.f) return;
@@ -762,11 +788,11 @@ static void roughdielectric_eval_pdf(const msk_bsdf_desc &b, V3 wi, V3 wo, S4 wl
         fresnel_dielectric(dot(wi, m), b.ior_eta, &F, &ct, &e_it, &e_ti);
         float G = smith_g1(wi, m, au, av) * smith_g1(wo, m, au, av);
         if (reflect) {
-            *val = spectrum_eval(b.specular_reflectance, wl) * (F * D * G) / (4.f * std::fabs(cos_i));
+            *val = spectrum_eval(sc, b.specular_reflectance, wl) * (F * D * G) / (4.f * std::fabs(cos_i));
         } else {
             float scale = inv_eta * inv_eta;
             float denom = dot(wi, m) + eta * dot(wo, m);
-            *val = spectrum_eval(b.specular_transmittance, wl) *
+            *val = spectrum_eval(sc, b.specular_transmittance, wl) *
                    std::fabs((scale * (1.f - F) * D * G * eta * eta * dot(wi, m) * dot(wo, m)) / (cos_i * (denom * denom)));
         }
     }
@@ -781,7 +807,7 @@ static void roughdielectric_eval_pdf(const msk_bsdf_desc &b, V3 wi, V3 wo, S4 wl
     *pdf = prob * std::fabs(dwh_dwo);
 }
 // bsdfs/roughdielectric.cpp:57-116 sample (both lobes enabled)
-static S4 roughdielectric_sample(const msk_bsdf_desc &b, V3 wi, float sample1, V2 sample, S4 wl, BSDFSampleRec *bs) {
+static S4 roughdielectric_sample(const Scene &sc, const msk_bsdf_desc &b, V3 wi, float sample1, V2 sample, S4 wl, BSDFSampleRec *bs) {
     const float cos_i = wi.z;
     const float au = clamp_alpha(b.alpha_u), av = clamp_alpha(b.alpha_v);
     float sau = au, sav = av;
@@ -798,7 +824,7 @@ static S4 roughdielectric_sample(const msk_bsdf_desc &b, V3 wi, float sample1, V
     float dwh_dwo;
     if (selected_r) {
         bs->wo = m * 2.f * dot(wi, m) - wi;                               // fresnel.h:17-21
-        weight = weight * spectrum_eval(b.specular_reflectance, wl);
+        weight = weight * spectrum_eval(sc, b.specular_reflectance, wl);
         dwh_dwo = 1.f / (4.f * dot(bs->wo, m));
     } else {
         bs->wo = m * (dot(wi, m) * eta_ti + cos_t) - wi * eta_ti;          // fresnel.h:30-35 refract(wi, m, cos_t, eta_ti)
@@ -823,25 +849,29 @@ static const float *checkerboard_lookup(const msk_texture_desc &t, V2 uv) {
 }
 // SmoothDiffuse::m_reflectance->eval(si) (diffuse.cpp:31,44): the coefficients of the spectrum the reflectance
 // texture shows at the hit
-struct Reflectance { const float *coeff; float scale; };
+struct Reflectance { const float *coeff; float scale; uint32_t regular; };
 static Reflectance reflectance_at(const Scene &sc, const msk_bsdf_desc &b, V2 uv) {
-    if (b.reflectance_texture == 0) return {b.reflectance, b.reflectance_scale};
-    return {checkerboard_lookup(sc.textures[b.reflectance_texture - 1], uv), 1.f};
+    if (b.reflectance_regular) return {b.reflectance, 1.f, b.reflectance_regular};
+    if (b.reflectance_texture == 0) return {b.reflectance, b.reflectance_scale, 0u};
+    return {checkerboard_lookup(sc.textures[b.reflectance_texture - 1], uv), 1.f, 0u};
 }
-static S4 reflectance_eval(Reflectance r, S4 wl) { return srgb_model_eval(r.coeff, wl) * r.scale; }
+static S4 reflectance_eval(const Scene &sc, Reflectance r, S4 wl) {
+    if (r.regular) return regular_eval(sc.regular[r.regular - 1], wl);
+    return srgb_model_eval(r.coeff, wl) * r.scale;
+}
 
 // one-sided evaluation (wi already on the front side for twosided); refl = reflectance_at() of the hit
-static void bsdf_eval_pdf(const msk_bsdf_desc &b, Reflectance refl, V3 wi, V3 wo, S4 wl, S4 *val, float *pdf) {
+static void bsdf_eval_pdf(const Scene &sc, const msk_bsdf_desc &b, Reflectance refl, V3 wi, V3 wo, S4 wl, S4 *val, float *pdf) {
     *val = s4(0.f); *pdf = 0.f;
     float cos_i = wi.z, cos_o = wo.z;
     if (b.type == MSK_BSDF_DIFFUSE) {                                  // diffuse.cpp:35-57
         if (cos_i > 0.f && cos_o > 0.f) {
-            *val = reflectance_eval(refl, wl) * kInvPi * cos_o;
+            *val = reflectance_eval(sc, refl, wl) * kInvPi * cos_o;
             *pdf = square_to_cosine_hemisphere_pdf(wo);
         }
         return;
     }
-    if (b.type == MSK_BSDF_ROUGHDIELECTRIC) { roughdielectric_eval_pdf(b, wi, wo, wl, val, pdf); return; }
+    if (b.type == MSK_BSDF_ROUGHDIELECTRIC) { roughdielectric_eval_pdf(sc, b, wi, wo, wl, val, pdf); return; }
     const float au = clamp_alpha(b.alpha_u), av = clamp_alpha(b.alpha_v);
     // roughconductor.cpp:82-98 eval
     if (cos_i > 0.f && cos_o > 0.f) {
@@ -850,8 +880,8 @@ static void bsdf_eval_pdf(const msk_bsdf_desc &b, Reflectance refl, V3 wi, V3 wo
         if (D != 0) {
             float G = smith_g1(wi, H, au, av) * smith_g1(wo, H, au, av);
             float result = D * G / (4.f * wi.z);
-            S4 F = fresnel_conductor4(dot(wi, H), spectrum_eval(b.eta, wl), spectrum_eval(b.k, wl));
-            *val = F * spectrum_eval(b.specular_reflectance, wl) * result;
+            S4 F = fresnel_conductor4(dot(wi, H), spectrum_eval(sc, b.eta, wl), spectrum_eval(sc, b.k, wl));
+            *val = F * spectrum_eval(sc, b.specular_reflectance, wl) * result;
         }
     }
     // roughconductor.cpp:100-117 pdf
@@ -861,16 +891,16 @@ static void bsdf_eval_pdf(const msk_bsdf_desc &b, Reflectance refl, V3 wi, V3 wo
         else *pdf = (distr_eval(m, au, av) * m.z) / (4.f * dot(wo, m));
     }
 }
-static S4 bsdf_sample(const msk_bsdf_desc &b, Reflectance refl, V3 wi, float sample1, V2 sample, S4 wl, BSDFSampleRec *bs) {
+static S4 bsdf_sample(const Scene &sc, const msk_bsdf_desc &b, Reflectance refl, V3 wi, float sample1, V2 sample, S4 wl, BSDFSampleRec *bs) {
     bs->wo = mk3(0, 0, 0); bs->pdf = 0.f; bs->eta = 1.f; bs->sampled_type = 0;       // render/bsdf.h:75-77
-    if (b.type == MSK_BSDF_ROUGHDIELECTRIC) return roughdielectric_sample(b, wi, sample1, sample, wl, bs);
+    if (b.type == MSK_BSDF_ROUGHDIELECTRIC) return roughdielectric_sample(sc, b, wi, sample1, sample, wl, bs);
     float cos_i = wi.z;
     if (cos_i <= 0.f) return s4(0.f);
     if (b.type == MSK_BSDF_DIFFUSE) {                                  // diffuse.cpp:18-33
         bs->wo = square_to_cosine_hemisphere(sample);
         bs->pdf = square_to_cosine_hemisphere_pdf(bs->wo);
         bs->sampled_type = kDiffuseReflection;
-        return bs->pdf > 0.f ? reflectance_eval(refl, wl) : s4(0.f);
+        return bs->pdf > 0.f ? reflectance_eval(sc, refl, wl) : s4(0.f);
     }
     // roughconductor.cpp:52-80
     const float au = clamp_alpha(b.alpha_u), av = clamp_alpha(b.alpha_v);
@@ -882,7 +912,7 @@ static S4 bsdf_sample(const msk_bsdf_desc &b, Reflectance refl, V3 wi, float sam
     if (b.sample_visible) weight = smith_g1(bs->wo, m, au, av);
     else weight = smith_g1(wi, m, au, av) * smith_g1(bs->wo, m, au, av) * dot(wi, m) / (cos_i * m.z);
     bs->pdf /= 4.f * dot(bs->wo, m);
-    S4 F = fresnel_conductor4(dot(wi, m), spectrum_eval(b.eta, wl), spectrum_eval(b.k, wl));
+    S4 F = fresnel_conductor4(dot(wi, m), spectrum_eval(sc, b.eta, wl), spectrum_eval(sc, b.k, wl));
     return F * weight;
 }
 // twosided.cpp:38-101: pick the nested BSDF by the side wi is on, flip z of wi and wo on the back
@@ -931,7 +961,7 @@ static S4 path_sample(const Scene &sc, Sampler &sampler, Ray ray, S4 wl, const m
                 const msk_bsdf_desc *bb = bsdf_side(sc, bsdf, &wi_s, &flipped);
                 if (flipped) wo.z *= -1.f;
                 S4 bsdf_val; float bsdf_pdf;
-                bsdf_eval_pdf(*bb, reflectance_at(sc, *bb, si.uv), wi_s, wo, wl, &bsdf_val, &bsdf_pdf);
+                bsdf_eval_pdf(sc, *bb, reflectance_at(sc, *bb, si.uv), wi_s, wo, wl, &bsdf_val, &bsdf_pdf);
                 float weight = mis_weight(ds.pdf, bsdf_pdf);
                 if (g_trace_path)
                     std::printf("  d%d NEE: ds.pdf %.9g bsdf_pdf %.9g w %.9g emitter_val %.9g bsdf_val %.9g %.9g %.9g %.9g thr %.9g wo_local %.9g %.9g %.9g wi %.9g %.9g %.9g\n", depth, ds.pdf,
@@ -947,7 +977,7 @@ static S4 path_sample(const Scene &sc, Sampler &sampler, Ray ray, S4 wl, const m
         {
             V3 wi_s = si.wi; bool flipped;
             const msk_bsdf_desc *bb = bsdf_side(sc, bsdf, &wi_s, &flipped);
-            bsdf_val = bsdf_sample(*bb, reflectance_at(sc, *bb, si.uv), wi_s, sample1, u2, wl, &bs);
+            bsdf_val = bsdf_sample(sc, *bb, reflectance_at(sc, *bb, si.uv), wi_s, sample1, u2, wl, &bs);
             if (flipped) bs.wo.z *= -1.f;
         }
         const V3 bs_wo = bs.wo; const float bs_pdf = bs.pdf, bs_eta = bs.eta;
@@ -1312,6 +1342,17 @@ void msk_oracle_sample_wavelength(float u, float *wl4, float *w4) {
     S4 a, b; sample_wavelength(u, &a, &b);
     for (int i = 0; i < 4; ++i) { wl4[i] = a.v[i]; w4[i] = b.v[i]; }
 }
+static const Scene kNoScene{};    // the BSDF KAT entry points below take bare descs: none of them names a tabulated spectrum
+// KAT hook: RegularSpectrum::eval (regular.cpp:73-91,148) of a table at four wavelengths
+void msk_oracle_regular_eval(float lambda_min, float lambda_max, const float *values, uint32_t size, const float *wl4, float *out4) {
+    Scene::RegularTable t;
+    t.range_x = lambda_min;
+    t.inv_interval = (float) (1.0 / (((double) lambda_max - (double) lambda_min) / (double) (size - 1)));
+    t.pdf.assign(values, values + size);
+    S4 w; for (int i = 0; i < 4; ++i) w.v[i] = wl4[i];
+    S4 r = regular_eval(t, w);
+    for (int i = 0; i < 4; ++i) out4[i] = r.v[i];
+}
 // KAT hook: 0 / 1 = the checkerboard shows color0 / color1 at uv
 int msk_oracle_checkerboard(const msk_texture_desc *t, float u, float v) { return checkerboard_lookup(*t, V2{u, v}) == t->color0 ? 0 : 1; }
 void msk_oracle_srgb_model_eval(const float *coeff3, const float *wl4, float *out4) {
@@ -1341,7 +1382,7 @@ void msk_oracle_bsdf_eval(const msk_bsdf_desc *bsdfs, int n, int id, const float
     S4 wl; for (int i = 0; i < 4; ++i) wl.v[i] = wl4[i];
     bool flipped; const msk_bsdf_desc *b = bsdf_side(sc, sc.bsdfs[id], &wi, &flipped);
     if (flipped) wo.z *= -1.f;
-    S4 v; bsdf_eval_pdf(*b, Reflectance{b->reflectance, b->reflectance_scale}, wi, wo, wl, &v, pdf);
+    S4 v; bsdf_eval_pdf(kNoScene, *b, Reflectance{b->reflectance, b->reflectance_scale, 0u}, wi, wo, wl, &v, pdf);
     for (int i = 0; i < 4; ++i) val4[i] = v.v[i];
 }
 void msk_oracle_bsdf_sample(const msk_bsdf_desc *bsdfs, int n, int id, const float *wi3, const float *u2, const float *wl4,
@@ -1350,7 +1391,7 @@ void msk_oracle_bsdf_sample(const msk_bsdf_desc *bsdfs, int n, int id, const flo
     V3 wi = mk3(wi3[0], wi3[1], wi3[2]);
     S4 wl; for (int i = 0; i < 4; ++i) wl.v[i] = wl4[i];
     bool flipped; const msk_bsdf_desc *b = bsdf_side(sc, sc.bsdfs[id], &wi, &flipped);
-    BSDFSampleRec bs; S4 w = bsdf_sample(*b, Reflectance{b->reflectance, b->reflectance_scale}, wi, 0.f, V2{u2[0], u2[1]}, wl, &bs);
+    BSDFSampleRec bs; S4 w = bsdf_sample(kNoScene, *b, Reflectance{b->reflectance, b->reflectance_scale, 0u}, wi, 0.f, V2{u2[0], u2[1]}, wl, &bs);
     if (flipped) bs.wo.z *= -1.f;
     wo3[0] = bs.wo.x; wo3[1] = bs.wo.y; wo3[2] = bs.wo.z; *pdf = bs.pdf;
     for (int i = 0; i < 4; ++i) weight4[i] = w.v[i];
@@ -1362,7 +1403,7 @@ void msk_oracle_bsdf_sample2(const msk_bsdf_desc *bsdfs, int n, int id, const fl
     V3 wi = mk3(wi3[0], wi3[1], wi3[2]);
     S4 wl; for (int i = 0; i < 4; ++i) wl.v[i] = wl4[i];
     bool flipped; const msk_bsdf_desc *b = bsdf_side(sc, sc.bsdfs[id], &wi, &flipped);
-    BSDFSampleRec bs; S4 w = bsdf_sample(*b, Reflectance{b->reflectance, b->reflectance_scale}, wi, sample1, V2{u2[0], u2[1]}, wl, &bs);
+    BSDFSampleRec bs; S4 w = bsdf_sample(kNoScene, *b, Reflectance{b->reflectance, b->reflectance_scale, 0u}, wi, sample1, V2{u2[0], u2[1]}, wl, &bs);
     if (flipped) bs.wo.z *= -1.f;
     wo3[0] = bs.wo.x; wo3[1] = bs.wo.y; wo3[2] = bs.wo.z; *pdf = bs.pdf; *eta = bs.eta; *sampled_type = bs.sampled_type;
     for (int i = 0; i < 4; ++i) weight4[i] = w.v[i];

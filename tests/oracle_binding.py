@@ -78,6 +78,12 @@ class Oracle:
         self.lib.msk_oracle_srgb_model_eval(_p(c), _p(w), _p(o))
         return o
 
+    def regular_eval(self, lambda_min, lambda_max, values, wl):
+        """RegularSpectrum::eval (spectra/regular.cpp:73-91,148) of a table at four wavelengths"""
+        v, w, o = np.ascontiguousarray(values, np.float32), np.asarray(wl, np.float32), np.zeros(4, np.float32)
+        self.lib.msk_oracle_regular_eval(C.c_float(lambda_min), C.c_float(lambda_max), _p(v), C.c_uint32(len(v)), _p(w), _p(o))
+        return o
+
     def coordinate_system(self, n):
         n = np.asarray(n, np.float32)
         s, t = np.zeros(3, np.float32), np.zeros(3, np.float32)

@@ -27,18 +27,24 @@ def test_library_exports_every_declared_symbol(abi):
 
 def test_struct_layouts_match_the_header(abi, tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "msk_gpu.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "msk_gpu.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(msk_mesh_desc),sizeof(msk_bsdf_desc),sizeof(msk_emitter_desc),sizeof(msk_camera_desc),'
                    'sizeof(msk_film_desc),sizeof(msk_scene_desc),sizeof(msk_render_params),sizeof(msk_stats),'
                    'offsetof(msk_scene_desc,camera),offsetof(msk_render_params,rng_mode),sizeof(msk_texture_desc),'
-                   'offsetof(msk_bsdf_desc,reflectance_texture),offsetof(msk_bsdf_desc,reflectance_scale),offsetof(msk_scene_desc,textures));return 0;}\n')
+                   'offsetof(msk_bsdf_desc,reflectance_texture),offsetof(msk_bsdf_desc,reflectance_scale),offsetof(msk_scene_desc,textures),'
+                   'sizeof(msk_spectrum_desc),sizeof(msk_regular_spectrum_desc),offsetof(msk_bsdf_desc,reflectance_regular),'
+                   'offsetof(msk_emitter_desc,radiance_regular),offsetof(msk_scene_desc,regular_spectra),offsetof(msk_scene_desc,regular_values),'
+                   'offsetof(msk_stats,bytes_shade));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(abi.MeshDesc), C.sizeof(abi.BsdfDesc), C.sizeof(abi.EmitterDesc), C.sizeof(abi.CameraDesc),
             C.sizeof(abi.FilmDesc), C.sizeof(abi.SceneDesc), C.sizeof(abi.RenderParams), C.sizeof(abi.Stats),
             abi.SceneDesc.camera.offset, abi.RenderParams.rng_mode.offset, C.sizeof(abi.TextureDesc),
-            abi.BsdfDesc.reflectance_texture.offset, abi.BsdfDesc.reflectance_scale.offset, abi.SceneDesc.textures.offset]
+            abi.BsdfDesc.reflectance_texture.offset, abi.BsdfDesc.reflectance_scale.offset, abi.SceneDesc.textures.offset,
+            C.sizeof(abi.SpectrumDesc), C.sizeof(abi.RegularSpectrumDesc), abi.BsdfDesc.reflectance_regular.offset,
+            abi.EmitterDesc.radiance_regular.offset, abi.SceneDesc.regular_spectra.offset, abi.SceneDesc.regular_values.offset,
+            abi.Stats.bytes_shade.offset]
     assert got == want
 
 

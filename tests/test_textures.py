@@ -48,7 +48,7 @@ def test_checkerboard_known_answers(oracle, abi):
 
 def test_descriptor_layout(hostmirror, abi):
     import ctypes
-    assert ctypes.sizeof(abi.TextureDesc) == 64 and ctypes.sizeof(abi.BsdfDesc) == 112
+    assert ctypes.sizeof(abi.TextureDesc) == 64 and ctypes.sizeof(abi.BsdfDesc) == 132
     flat = checker_floor_scene(hostmirror, 16, 16, {"type": "checkerboard", "color0": C0, "color1": C1, "scale": (10, 10)})
     d = flat.desc
     assert d.n_textures == 1 and d.textures[0].type == abi.MSK_TEXTURE_CHECKERBOARD
