@@ -240,7 +240,7 @@ def mesh_profile(tag):
         return None
 
 
-def other_configs(abi, hm, ctx):
+def other_configs(abi, hm, ctx, skip_cpu=False):
     """BASELINE configs 3, 4 and 5 as one GPU sees them (N = 1 only, after the timed region): config 4 whole on this GPU,
     configs 3 / 5 on the bunny- / teapot-class stand-ins (the reference ships no meshes), config 5 at the 128-spp share
     one GPU of eight renders.  Three renders each: the first allocates the workspace, the faster of the other two is reported.
@@ -275,14 +275,33 @@ def other_configs(abi, hm, ctx):
                     dt, st = dt_k, st_k
             general = tag is not None                         # non-diffuse BSDFs: the general shading variant (aux in the state)
             seg, smp, shd = int(st.segments), int(st.samples), int(st.shadow_rays)
-            b_shade = seg * (176 + (16 if general else 0)) - smp * 64 + shd * 48 + smp * 20
-            b_trace = seg * 48 + shd * (16 if general else 32)        # k_trace_r reads ray_o once per slot; k_trace_q once per queue
+            # algorithmic bytes of the two kernels: counted by the library for THIS render (msk_stats::bytes_*, ABI v7)
+            b_shade, b_trace = int(st.bytes_shade), int(st.bytes_trace)
             ms_wave = max(st.ms_total - st.ms_resolve, 1e-6)
             gbs = (b_shade + b_trace) / (ms_wave * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_shade_gen || k_trace", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_sample": round((b_shade + b_trace) / max(smp, 1), 1),
                     "note": "state bytes of both wavefront kernels over the wavefront phase's device time; the traversal of a tree in "
                             "HBM/L2 is bound by VALU issue and load latency, not by these bytes (DESIGN.md §9)"}
+            l2 = None
+            if tag and not skip_cpu:
+                # film-level parity at the config's full size (north star: per-pixel L2 vs the CPU path < 1e-4): 16 spp = 16.8 M
+                # samples = 8192 regions (the four-part loop), the oracle on every host thread, same counter RNG and seed
+                try:
+                    p16 = abi.render_params(spp=16, seed=0)
+                    f16 = np.zeros_like(film)
+                    sc.render(p16, out=f16)
+                    osc = _oracle().scene(flat)
+                    t0 = time.perf_counter()
+                    ref, rst = osc.render(p16, len(os.sched_getaffinity(0)))
+                    t_cpu = time.perf_counter() - t0
+                    osc.close()
+                    a, b = hm.develop(f16)[..., :3].astype(np.float64), hm.develop(ref)[..., :3].astype(np.float64)
+                    per_px = np.sqrt(((a - b) ** 2).sum(-1))
+                    l2 = {"max": float(per_px.max()), "pixels_gt_1e-4": int((per_px > 1e-4).sum()), "film_bit_identical": bool(np.array_equal(f16, ref)),
+                          "spp": 16, "samples": int(rst.samples), "cpu_s": round(t_cpu, 1), "cpu_msamples_per_s": round(rst.samples / t_cpu / 1e6, 3)}
+                except Exception as e:
+                    l2 = {"error": str(e)[:200]}
             prof = mesh_profile(tag) if tag else None
             if prof:
                 k = prof.get("kernels", {})
@@ -308,7 +327,7 @@ def other_configs(abi, hm, ctx):
                         "ms_device": round(st.ms_total, 1), "segments_per_sample": round(st.segments / max(st.samples, 1), 3),
                         "iterations": int(st.iterations), "passes": int(st.passes), "ms_resolve": round(st.ms_resolve, 1),
                         "scene_create_s": round(t_scene, 2), "finite": bool(np.isfinite(film).all()),
-                        "timing": "wall time of msk_gpu_render incl. the film copy-back (PCIe)", "roofline": roof})
+                        "timing": "wall time of msk_gpu_render incl. the film copy-back (PCIe)", "roofline": roof, "l2_vs_cpu": l2})
             sc.close()
         except Exception as e:                                       # reported, never fatal for the headline line
             out.append({"workload": name, "tag": tag or "c4_1gpu", "error": str(e)[:300]})
@@ -458,9 +477,14 @@ def stream_yardstick(roof):
             return {"error": (p.stdout + p.stderr)[-200:]}
         y = {"unit": "GB/s", "read": rates.get("read"), "write": rates.get("write"), "copy": rates.get("copy"), "soa7": rates["soa7"],
              "what": "streaming kernels without arithmetic on this box, measured in this run; soa7 = the shading sweep's access shape"}
+        # the ratio mixes a committed profile (another run, maybe another build) with this run's soa7: only when the profile is this build's
         shade = ((roof.get("per_kernel_single_stream_profile") or {}).get("k_shade_gen") or {}).get("achieved")
-        if shade:
+        if shade and not roof.get("profile_stale"):
             y["shade_vs_soa7"] = round(shade / rates["soa7"], 3)
+            y["shade_vs_soa7_source"] = "k_shade_gen's single-stream HBM rate of the committed profile (build %s = this build) / this run's soa7" % roof.get("profile_build_id")
+        elif shade:
+            y["shade_vs_soa7"] = None
+            y["shade_vs_soa7_source"] = "omitted: the committed profile was taken on build %s, this is %s" % (roof.get("profile_build_id"), roof.get("build_id"))
         return y
     except Exception as e:                      # never let the yardstick cost the bench line
         return {"error": str(e)[:200]}
@@ -484,8 +508,11 @@ def roofline(stats, args):
     l_trace = sum(s.launches_trace for s in stats)                   # launches actually made
     l_shade = sum(s.launches_shade for s in stats)
     l_wave = sum(s.launches_wavefront for s in stats)
-    bytes_trace = seg * 48 + shd * 32
-    bytes_shade = seg * 176 - smp * 64 + shd * 48 + smp * 20
+    # counted by the library for these very renders (msk_stats::bytes_shade / bytes_trace, ABI v7: what its kernels' launches were
+    # asked to move, from its own layout) — the formulas of the docstring, evaluated where the layout lives
+    bytes_trace = sum(s.bytes_trace for s in stats)
+    bytes_shade = sum(s.bytes_shade for s in stats)
+    bytes_agree = bytes_trace == seg * 48 + shd * 32 and bytes_shade == seg * 176 - smp * 64 + shd * 48 + smp * 20       # DESIGN.md §5, restated here
     # the two kernels take nearly the same time on this workload and which one is ahead depends on the box; the shading
     # kernel (five times the bytes) is reported unless the traversal kernel is clearly the longer one
     if ms_trace > 1.03 * ms_shade:
@@ -550,6 +577,16 @@ def roofline(stats, args):
             "ms_resolve": round(sum(s.ms_resolve for s in stats), 2),
             "ms_total_device": round(sum(s.ms_total for s in stats), 2),
             "segments_per_sample": round(seg / max(smp, 1), 3),
+            # the two per-sample figures side by side: this layout's (msk_stats::bytes_*, + 40 B/sample of film replay input) and
+            # SURVEY 8(d)'s canonical 150 + 428 L for L segments per sample.  The canonical layout carries a 76-byte path state and
+            # a 32-byte ray in AND out of every shade, a 20-byte hit record and a 48-byte shadow item per segment; this one
+            # keeps id in 8 bytes, no rng counter / eta / pdf fields (recomputed or folded into the ray), writes no thr / res for a
+            # fresh sample and moves shadow data only for slots that carry a shadow ray — about half the bytes for the same path.
+            "bytes_per_sample": {"this_layout": round((bytes_shade + bytes_trace) / max(smp, 1) + 40.0, 1),
+                                 "survey_canonical_150_plus_428L": round(150.0 + 428.0 * seg / max(smp, 1), 1),
+                                 "source": "msk_stats::bytes_shade + bytes_trace of this run (+ 40 B/sample the film replay reads)",
+                                 "library_count_equals_design_formula": bool(bytes_agree)},
+            "frac_if_canonical_bytes": round((150.0 + 428.0 * seg / max(smp, 1)) * smp / max(ms_wavefront * 1e-3, 1e-9) / 1e9 / HBM_PEAK_GBS, 4),
             "valu": valu, "per_kernel_single_stream_profile": profile_single_stream(pm)}
 
 
@@ -766,10 +803,12 @@ def main():
         else:
             out["cpu_baseline"] = None
         if n_gpus == 1 and not args.no_other_configs:
-            out["other_configs"] = other_configs(abi, hm, ctx)
+            out["other_configs"] = other_configs(abi, hm, ctx, skip_cpu=args.no_cpu_baseline)
             for e in out["other_configs"]:
                 if "value" in e:
                     compact[e["tag"] + "_msamples_per_s"] = e["value"]
+                if (e.get("l2_vs_cpu") or {}).get("max") is not None:
+                    compact[e["tag"] + "_l2_max"] = e["l2_vs_cpu"]["max"]
         out["config"].update(compact)       # c3 / c5 / c4_1gpu _msamples_per_s, l2_max, cpu_config1_msamples_per_s
         out["config"].update(sharded)       # N > 1: c4_* / c5_* of the sharded config 4 / 5 runs
         if "cpu_baseline_all_threads" in out:

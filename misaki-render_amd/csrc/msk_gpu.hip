@@ -878,12 +878,15 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     pp0.region_first = 0; pp0.region_count = n_regions;
     pp0.trace_split = sc->trace_mode == 0 ? std::max(1u, env_u32("MSK_TRACE_SPLIT", 2)) : 1u;
     pp0.aov_rgb = aov_rgb;
+    pp0.aov_groups = aov ? aov->n_groups : 0u;
+    for (uint32_t g = 0; g < MSK_MAX_AOV_GROUPS; ++g) pp0.aov_rec[g] = aov && g < aov->n_groups ? aov->rec[g] : nullptr;
     pp0.packed = packed ? 1u : 0u;
     pp0.stack_ovf = nullptr;
     // (MSK_FORCE_GENERAL_SHADE=1, measurements only: an all-diffuse scene through the general variant — what a per-class diffuse
     // instantiation could save a mixed scene's diffuse chunks)
     const bool force_general = env_u32("MSK_FORCE_GENERAL_SHADE", 0) != 0;
-    const bool diffuse_only = sc->all_diffuse && !aov_rgb && !force_general;      // the AOV RGB record lives in the general shading variant
+    // (the AOV RGB record and the validity test over an "aov" render's record groups live in the general shading variant)
+    const bool diffuse_only = sc->all_diffuse && !aov_rgb && !(aov && aov->n_groups) && !force_general;
     // material-sorted shading (general variant): LDS for the permutation, 3 bytes per slot of a region and wave (MSK_SORT=0: off)
     const size_t sort_lds = (size_t) (MSK_BLOCK / MSK_WAVE) * 3 * region_size;
     const bool sort_on = !diffuse_only && (!sc->all_diffuse || force_general) && region_size <= 4096 && env_u32("MSK_SORT", 1) &&

@@ -163,6 +163,10 @@ struct PassParams {
     RegionCtl *regions;
     uint32_t *stack_ovf;          // traversal-stack overflow (LaneStack), (stack_total - stack_entries) x lanes words, or nullptr
     float4 *aov_rgb;              // nullptr, or per sample {R,G,B,pos.x} of the nested path integrator (aov.cpp:124-141)
+    // an "aov" render's primary-hit record groups (AovParams::rec, written by k_aov_primary while the sample's path is at depth 1):
+    // the record of a finished sample reads them back for ImageBlock::put's validity test, which covers EVERY channel of the block
+    uint32_t aov_groups;
+    const float4 *aov_rec[8 /* MSK_MAX_AOV_GROUPS */];
 };
 
 // AOV channels read off the primary hit (integrators/aov.cpp:95-122), three per record group
@@ -1716,18 +1720,19 @@ MSK_DEV bool invalid_value(float a, float b, float c, bool warn_negative) {
 template <bool DIFFUSE_ONLY>
 MSK_DEV uint32_t emit_record(const DeviceScene &sc, const SceneTables &tb, const PassParams &pp, spec wl, spec res, uint32_t pix, uint32_t si) {
     // what only this function needs of the kernel's arguments (MSK_COLD_KARGS above)
-    struct Cold { const uint32_t *pix_to_j; const uint4 *pix_table; float4 *rec_a; float *rec_b; float4 *aov_rgb; uint32_t spp_owned, packed;
+    struct Cold { const uint32_t *pix_to_j; const uint4 *pix_table; float4 *rec_a; float *rec_b; float4 *aov_rgb; uint32_t spp_owned, packed, aov_groups;
                   float filter_radius, filter_scale; int filter_border; } k;
     if (MSK_COLD_KARGS) {
         const karg_ptr ka = karg_base();
         k.pix_to_j = MSK_KARG_PP(ka, const uint32_t *, pix_to_j); k.pix_table = MSK_KARG_PP(ka, const uint4 *, pix_table);
         k.rec_a = MSK_KARG_PP(ka, float4 *, rec_a); k.rec_b = MSK_KARG_PP(ka, float *, rec_b); k.aov_rgb = MSK_KARG_PP(ka, float4 *, aov_rgb);
         k.spp_owned = MSK_KARG_PP(ka, uint32_t, spp_owned); k.packed = MSK_KARG_PP(ka, uint32_t, packed);
+        k.aov_groups = DIFFUSE_ONLY ? 0u : MSK_KARG_PP(ka, uint32_t, aov_groups);
         k.filter_radius = MSK_KARG_SC(ka, float, filter_radius); k.filter_scale = MSK_KARG_SC(ka, float, filter_scale);
         k.filter_border = MSK_KARG_SC(ka, int32_t, filter_border);
     } else {
         k.pix_to_j = pp.pix_to_j; k.pix_table = pp.pix_table; k.rec_a = pp.rec_a; k.rec_b = pp.rec_b; k.aov_rgb = pp.aov_rgb;
-        k.spp_owned = pp.spp_owned; k.packed = pp.packed;
+        k.spp_owned = pp.spp_owned; k.packed = pp.packed; k.aov_groups = DIFFUSE_ONLY ? 0u : pp.aov_groups;
         k.filter_radius = sc.filter_radius; k.filter_scale = sc.filter_scale; k.filter_border = sc.filter_border;
     }
     const uint32_t j = k.pix_to_j[pix];
@@ -1749,7 +1754,13 @@ MSK_DEV uint32_t emit_record(const DeviceScene &sc, const SceneTables &tb, const
     }
     st4<2>(k.rec_a + r, make_float4(X, Y, Z, wx));
     if (MSK_NT >= 2) __builtin_nontemporal_store(wy, k.rec_b + r); else k.rec_b[r] = wy;
-    bool invalid = invalid_value(X, Y, Z, DIFFUSE_ONLY || !k.aov_rgb);
+    // integrator.cpp:59-60: warn_negative = !has_aovs — any "aov" render with channels, nested integrator or not
+    bool invalid = invalid_value(X, Y, Z, DIFFUSE_ONLY || !(k.aov_rgb || k.aov_groups));
+    if (!DIFFUSE_ONLY)                                              // imageblock.cpp:57-81 tests every channel of the block: the AOV groups too
+        for (uint32_t g = 0; g < k.aov_groups; ++g) {
+            const float4 v = pp.aov_rec[g][r];
+            invalid = invalid || invalid_value(v.x, v.y, v.z, false);
+        }
     if (!DIFFUSE_ONLY && k.aov_rgb) {                              // aov.cpp:124-136: the sample before ray_weight
         float x0, y0, z0;
         spectrum_to_xyz(tb.cie, res, wl, &x0, &y0, &z0);

@@ -41,6 +41,15 @@ def test_bare_shell_gpus_2_spawns_two_ranks():
     # the equal sample-stride split is the default (--balance is opt-in); the line says how many ranks met and what the node showed
     assert d["balance"] is None and d["config"]["balanced"] is False and d["config"]["rccl_ranks"] == 2 and isinstance(d["config"]["devices_seen"], int)
     assert d["config"]["shard"] == "samples" and _scalar_config(d)
+    # N > 1: BASELINE configs 4 and 5 follow the headline across the same ranks, each with its own one-reduce step — config 4 as a
+    # pixel-tile shard (BASELINE's wording), config 5 as a sample shard; scalars under `config` (the driver's parser keeps those)
+    c = d["config"]
+    assert (c["c4_shard"], c["c4_spp"], c["c5_shard"], c["c5_spp"]) == ("tiles", 4096, "samples", 1024)
+    assert c["c4_reduce_ok"] and c["c5_reduce_ok"] and c["c4_ms"] > 0 and c["c5_ms"] > 0
+    assert "1920x1080" in c["c4_workload"] and "1024x1024" in c["c5_workload"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0", "--no-other-configs"],
+                       capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode == 0 and not any(k.startswith(("c4_", "c5_")) for k in _last_json(r.stdout)["config"]), r.stderr[-2000:]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0", "--shard", "tiles"],
                        capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
     assert r.returncode == 0 and _last_json(r.stdout)["config"]["shard"] == "tiles", r.stderr[-2000:]
@@ -128,6 +137,14 @@ def test_two_ranks_rehearsed_on_one_gpu():
     assert abs(d2["film_weight_sum"] - d1["film_weight_sum"]) <= 1e-5 * abs(d1["film_weight_sum"])
     assert abs(d_tiles["film_weight_sum"] - d1["film_weight_sum"]) <= 1e-5 * abs(d1["film_weight_sum"])
     assert _scalar_config(d1) and d1["config"]["shard"] == "none"
+    # the sharded config 4 / 5 runs behind the headline (reduced sample counts: two ranks share this one GPU and its memory)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--spp", "8", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--c4-spp", "16", "--c5-spp", "8"], capture_output=True, text=True, timeout=900, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    c = _last_json(r.stdout)["config"]
+    assert c["c4_film_finite"] and c["c5_film_finite"] and c["c4_msamples_per_s"] > 0 and c["c5_msamples_per_s"] > 0 and "c4_error" not in c
+    # every sample splats filter weights that sum to about one: all of them arrived in the reduced film
+    assert abs(c["c4_weight_per_sample"] - 1) < 0.01 and abs(c["c5_weight_per_sample"] - 1) < 0.01 and _scalar_config({"config": c})
 
 
 @pytest.mark.gpu

@@ -56,6 +56,26 @@ def test_the_aov_integrator_only_counts_what_is_not_finite(gpu_ctx, abi, hostmir
     g.close(); o.close()
 
 
+def test_a_non_finite_aov_channel_counts_with_or_without_the_nested_integrator(gpu_ctx, abi, hostmirror, oracle, golden_lookup):
+    """ImageBlock::put tests EVERY channel of the block (imageblock.cpp:57-81), the AOV channels too: vertex normals that are not
+    finite give a NaN shading normal (mesh.cpp:81-96 normalises the interpolated normal; zero normals would not: Eigen's
+    normalized() leaves a zero vector alone) — the samples that see it are counted, also in an "aov" render without a nested
+    integrator, whose XYZ is 0 by construction, and once each when the nested integrator is there as well."""
+    flat = hostmirror.cbox_scene(32, 32, coeff_lookup=golden_lookup)
+    m = flat.desc.meshes[3]                        # the back wall
+    m.has_normals = 1
+    flat.vertices[m.first_vertex:m.first_vertex + m.vertex_count, 3] = np.inf
+    g, o = abi.Scene(gpu_ctx, flat), oracle.scene(flat)
+    for types in ([abi.MSK_AOV_SH_NORMAL], [abi.MSK_AOV_DEPTH, abi.MSK_AOV_SH_NORMAL, abi.MSK_AOV_PATH_RGBA], [abi.MSK_AOV_DEPTH],
+                  [abi.MSK_AOV_PATH_RGBA]):
+        film, st = g.render_aov(abi.render_params(spp=3, seed=6), types)
+        ref, rst = o.render_aov(abi.render_params(spp=3, seed=6), types)
+        assert st.samples == rst.samples == 32 * 32 * 3
+        assert st.invalid_samples == rst.invalid_samples, types
+        assert (st.invalid_samples > 0) == (abi.MSK_AOV_SH_NORMAL in types), types
+    g.close(); o.close()
+
+
 def test_the_plugin_warns(hostmirror, tmp_path, capfd):
     """The "path" plugin logs the count as the reference's ImageBlock::put logs each sample: `Log(Warn, "Invalid sample value ...")`."""
     import importlib

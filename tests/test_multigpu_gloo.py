@@ -107,6 +107,57 @@ def test_tile_shard_and_sample_shard_reduce_to_the_same_film(tmp_path):
     assert np.array_equal(films["tiles"][..., 4] > 0, films["samples"][..., 4] > 0)
 
 
+def _config_worker(rank, world, port, out_path, which):
+    """bench.py's sharded_configs on CPU: config 4's shape (a 16:9 film whose last row of blocks is ragged, pixel-tile shard) and
+    config 5's (a rough-dielectric mesh in the room, sample shard) through the same shard selectors and the same one reduce."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    abi = importlib.import_module("misaki-render_amd.abi")
+    hm = importlib.import_module("misaki-render_amd.hostmirror")
+    mg = importlib.import_module("misaki-render_amd.multigpu")
+    import oracle_binding
+    orc = oracle_binding.load()
+    if which == "c4":
+        flat, spp, mode = hm.cbox_scene(120, 68, coeff_lookup=lambda rgb: (0.0, 0.0, 1.0)), 6, "tiles"       # 1920 x 1080 / 16: blocks 4 x 3, the last row 4 px high
+    else:
+        blob = hm.blob_mesh("blob", (278, 200, 280), 120, 14, 14, hm.WHITE, seed=7, bump=0.25)
+        blob.bsdf = {"type": "roughdielectric", "alpha": 0.1, "int_ior": 1.5, "ext_ior": 1.0}
+        flat, spp, mode = hm.flatten(hm.cbox_meshes()[:6] + [blob], 64, 64, coeff_lookup=lambda rgb: (0.0, 0.0, 1.0)), 4, "samples"
+    sc = orc.scene(flat)
+    prm = mg.shard_params(abi, spp, rank, world, mode=mode, seed=0)
+    film_np, st = sc.render(prm, threads=2)
+    film = torch.from_numpy(film_np.copy())
+    mg.reduce_film(film, dist)
+    n = torch.tensor([float(st.samples)], dtype=torch.float64)
+    dist.all_reduce(n)
+    if rank == 0:
+        full, fst = sc.render(abi.render_params(spp=spp, seed=0), threads=2)
+        np.savez(out_path, reduced=film.numpy(), full=full, samples=n.numpy(), full_samples=fst.samples)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_the_sharded_baseline_configs_reduce_to_the_single_rank_film(tmp_path):
+    """BASELINE configs 4 and 5 as bench.py runs them on N > 1 ranks (sharded_configs): config 4 = pixel-tile shard of a 16:9 film
+    with a ragged last block row, config 5 = sample shard of a scene with a rough-dielectric mesh; each reduced film equals the
+    single-rank film within the north star's 1e-4 per-pixel L2, every sample rendered once."""
+    import torch.multiprocessing as mp
+    hm = importlib.import_module("misaki-render_amd.hostmirror")
+    for k, (which, n_samples) in enumerate((("c4", 120 * 68 * 6), ("c5", 64 * 64 * 4))):
+        out = str(tmp_path / (which + ".npz"))
+        mp.spawn(_config_worker, args=(2, 37500 + (os.getpid() % 2000) + k, out, which), nprocs=2, join=True)
+        d = np.load(out)
+        assert d["samples"][0] == d["full_samples"] == n_samples, which
+        assert np.allclose(d["reduced"], d["full"], rtol=3e-6, atol=1e-6), which
+        err = np.linalg.norm(hm.develop(d["reduced"])[..., :3].astype(np.float64) - hm.develop(d["full"])[..., :3].astype(np.float64), axis=-1)
+        assert err.max() < 1e-4 and d["reduced"][..., 4].min() > 0, which
+
+
 def test_two_rank_speed_proportional_ranges(tmp_path):
     """Unequal shares (3 : 1) as contiguous sample ranges: every sample still rendered exactly once."""
     import torch.multiprocessing as mp
