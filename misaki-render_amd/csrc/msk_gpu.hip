@@ -904,10 +904,14 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     // k_wavefront (iterations on the device): possible when tables and tree are LDS-resident and everything fits one block's LDS
     // next to each other, and there is no per-iteration AOV kernel.  MSK_FUSED=1: the whole pass; MSK_FUSED_TAIL_PCT=p: from
     // the point where every sample has been started and fewer than p % of the slots are live.
-    const uint32_t fused_queue_f4 = sc->lds_tables ? (uint32_t) ((sc->shade_lds_bytes - (size_t) (MSK_BLOCK / MSK_WAVE) * MSK_DONE_Q_F4 * 16) / 16) : 0u;
+    const uint32_t fused_queue_f4 = (uint32_t) ((sc->shade_lds_bytes - (size_t) (MSK_BLOCK / MSK_WAVE) * MSK_DONE_Q_F4 * 16) / 16);     // after the staged tables
     const uint32_t fused_trace_f4 = (uint32_t) (sc->shade_lds_bytes / 16);
     const size_t fused_lds = sc->shade_lds_bytes + sc->trace_lds_bytes;
-    const bool fused_ok = sc->trace_mode == 0 && sc->lds_tables && fused_lds <= 64 * 1024 && !(aov && aov->n_groups);
+    // ... and k_wavefront_h for the default tree in HBM (trace mode 6), the thin end only: MSK_FUSED_HBM=1.  Built, bit-identical,
+    // measured (round 6, same box, config-5 / config-3 class renders): 117.9 / 137.1 ms with it against 116.2 / 138.6 without — the
+    // thin end is bound by each wave's own longest rays, which a loop without launch boundaries still waits for: not the default.
+    const bool fused_h = sc->trace_mode == 6 && !sc->lds_tables && env_u32("MSK_FUSED_HBM", 0) != 0;
+    const bool fused_ok = ((sc->trace_mode == 0 && sc->lds_tables) || fused_h) && fused_lds <= 64 * 1024 && !(aov && aov->n_groups);
     const bool fused_all = fused_ok && env_u32("MSK_FUSED", 0) != 0;
     const uint32_t fused_iters = std::max(1u, env_u32("MSK_FUSED_ITERS", 16));
     const uint32_t fused_tail_pct = fused_ok ? env_u32("MSK_FUSED_TAIL_PCT", 10) : 0u;
@@ -942,6 +946,40 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
         p.st.n_shade_launches += (uint32_t) p.pend_shade.size(); p.st.n_trace_launches += (uint32_t) p.pend_trace.size();
         p.pend_shade.clear(); p.pend_trace.clear();
     };
+    // MSK_DUMP_RAYS=<file> (+ MSK_DUMP_ITER, default 12; MSK_DUMP_STRIDE, default 32), measurements only: the rays the traversal
+    // launch of that iteration is about to walk — every MSK_DUMP_STRIDE-th region of the first part, its live slots in the
+    // order the kernel takes them (shadow-carrying slots first) — written to the file for the host-side scheduler model
+    // (tools/micro/sched_model.cpp).  Header {'MSKR', regions, region_size, stride}; per region {count, ns}, then count x
+    // {ray_o, ray_d (w = tmax as the kernel reads it), sh} float4.
+    const char *dump_path = getenv("MSK_DUMP_RAYS");
+    const uint32_t dump_iter = env_u32("MSK_DUMP_ITER", 12), dump_stride = std::max(1u, env_u32("MSK_DUMP_STRIDE", 32));
+    auto dump_rays = [&](Part &p) {
+        if (hipStreamSynchronize(p.stream) != hipSuccess) return;
+        std::vector<RegionCtl> ctl(p.count);
+        if (hipMemcpy(ctl.data(), sb.counts.as<RegionCtl>() + p.first, p.count * sizeof(RegionCtl), hipMemcpyDeviceToHost) != hipSuccess) return;
+        FILE *f = std::fopen(dump_path, "wb");
+        if (!f) return;
+        const uint32_t n_dump = (p.count + dump_stride - 1) / dump_stride;
+        const uint32_t head[4] = {0x524b534du, n_dump, region_size, dump_stride};
+        std::fwrite(head, 4, 4, f);
+        std::vector<float4> ho(2 * (size_t) region_size), hd(2 * (size_t) region_size), hs(2 * (size_t) region_size);
+        for (uint32_t r = 0; r < p.count; r += dump_stride) {
+            const size_t base = (size_t) (p.first + r) * 2 * region_size;
+            (void) hipMemcpy(ho.data(), sb.st.ray_o + base, ho.size() * 16, hipMemcpyDeviceToHost);
+            (void) hipMemcpy(hd.data(), sb.st.ray_d + base, hd.size() * 16, hipMemcpyDeviceToHost);
+            (void) hipMemcpy(hs.data(), sb.st.sh + base, hs.size() * 16, hipMemcpyDeviceToHost);
+            const uint32_t count = ctl[r].count, ns = ctl[r].half_ns >> 1, half = ctl[r].half_ns & 1u;
+            const uint32_t cn[2] = {count, ns};
+            std::fwrite(cn, 4, 2, f);
+            for (uint32_t c = 0; c < count; ++c) {
+                const size_t slot = (size_t) half * region_size + (c < ns ? c : region_size - 1 - (c - ns));
+                float4 rec[3] = {ho[slot], hd[slot], c < ns ? hs[slot] : make_float4(0, 0, 0, 0)};
+                if (std::signbit(rec[1].w)) rec[1].w = INFINITY;          // slot_tmax: a bounce ray keeps -pdf there
+                std::fwrite(rec, 16, 3, f);
+            }
+        }
+        std::fclose(f);
+    };
     // queues one sync group of the part's loop: `group` iterations (or one k_wavefront launch), the counters' reduction and
     // their copy to the host, and whatever the wait mode needs behind them
     auto queue_group = [&](Part &p) -> int {
@@ -954,7 +992,12 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
             // the iteration loop on the device (k_wavefront): one bounded launch = up to fused_iters sweeps of every region
             // (not timed: msk_stats::ms_shade / ms_trace stay the sums of k_shade_gen / k_trace launches)
             hipEvent_t a = nullptr, b = nullptr;
-            if (diffuse_only) hipExtLaunchKernelGGL((k_wavefront<true>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
+            if (fused_h) {
+                if (diffuse_only) hipExtLaunchKernelGGL((k_wavefront_h<true>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
+                else if (sc->has_regular) hipExtLaunchKernelGGL((k_wavefront_h<false, true>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
+                else hipExtLaunchKernelGGL((k_wavefront_h<false>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
+            }
+            else if (diffuse_only) hipExtLaunchKernelGGL((k_wavefront<true>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
             else if (sc->has_regular) hipExtLaunchKernelGGL((k_wavefront<false, true>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
             else hipExtLaunchKernelGGL((k_wavefront<false>), dim3(grid), dim3(MSK_BLOCK), fused_lds, stream_h, a, b, 0, sc->dev, sb.st, pp, fused_iters, fused_queue_f4, fused_trace_f4);
             p.it += fused_iters; p.last_iters = fused_iters;
@@ -968,6 +1011,7 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
                 if (sc->lds_tables) { if (diffuse_only) MSK_SHADE(true, true); else if (sc->has_regular) MSK_SHADE(true, false, true); else MSK_SHADE(true, false); }
                 else { if (diffuse_only) MSK_SHADE(false, true); else if (sc->has_regular) MSK_SHADE(false, false, true); else MSK_SHADE(false, false); }
 #undef MSK_SHADE
+                if (dump_path && p.it == dump_iter && p.first == 0) dump_rays(p);      // (measurements only: MSK_DUMP_RAYS)
                 launch_trace(sc, stream_h, sb.st, pp, c, d);
                 p.st.launches_shade += 1; p.st.launches_trace += 1;
                 if (aov && aov->n_groups) hipLaunchKernelGGL(k_aov_primary, dim3(grid), dim3(MSK_BLOCK), 0, stream_h, sc->dev, sb.st, pp, *aov);

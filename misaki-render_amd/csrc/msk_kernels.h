@@ -2312,6 +2312,56 @@ k_wavefront(DeviceScene sc, PathState st, PassParams pp, uint32_t max_iters, uin
     }
 }
 
+// k_wavefront_h (round 6): the same device-side loop for scenes whose TREE STAYS IN HBM / L2 (trace mode 6: the 4-wide tree with
+// half-float boxes) — for the thin end of a pass.  Measured on the mesh configs (profiles/r06_tail_*.txt): once every sample has
+// been started the pool drains for ~50 more iterations (Russian roulette's tail) with a few dozen live paths per region, and
+// every iteration is two launches that end when their SLOWEST wave ends: 17 of the config-5-class render's 123 ms, 12.6 of the
+// config-3-class one's 145.  Here no wave waits for another region's stragglers: each runs shade -> trace -> shade -> ... on its
+// own region until it is empty.  Tables: the small ones in LDS as in k_shade_gen<false, *>; rays: whole chunks through
+// traverse4h (k_trace<6>'s walk — the arithmetic of k_trace_r<6>'s lanes, so the same hits; lane replacement has nothing to
+// replace with when a region holds a chunk or two).
+template <bool DIFFUSE_ONLY, bool REGULAR = false>
+__global__ void __launch_bounds__(MSK_BLOCK)
+k_wavefront_h(DeviceScene sc, PathState st, PassParams pp, uint32_t max_iters, uint32_t queue_f4, uint32_t trace_f4) {
+    extern __shared__ float4 lds_dyn[];
+    // LDS: [small tables][done queues][traversal stacks + four words per lane of node4h_step]; offsets in float4 from the host's plan
+    typename std::conditional<REGULAR, SceneTablesR, SceneTables>::type tb;
+    static_cast<SceneTables &>(tb) = stage_tables<false>(sc, lds_dyn);
+    const DoneQueue dq = done_queue(lds_dyn + queue_f4);
+    uint32_t *stack_base = (uint32_t *) (lds_dyn + trace_f4);
+    const TraceLds g = stage_scene(sc, nullptr, false, false);
+    const LaneStack<true> stack{stack_base + threadIdx.x, pp.stack_ovf + (size_t) blockIdx.x * MSK_BLOCK + threadIdx.x, (int) sc.stack_entries,
+                                (size_t) gridDim.x * MSK_BLOCK, stack_base + sc.stack_entries * MSK_BLOCK + threadIdx.x * 4};
+    const uint32_t lwave = (blockIdx.x * MSK_BLOCK + threadIdx.x) / MSK_WAVE;
+    const uint32_t lane = threadIdx.x & (MSK_WAVE - 1);
+    if (lwave >= pp.region_count) return;
+    const uint32_t wave = pp.region_first + lwave;
+    for (uint32_t it = 0; it < max_iters; ++it) {
+        const RegionView rv = shade_region<DIFFUSE_ONLY>(sc, tb, dq, SortScratch{nullptr, nullptr}, st, pp, wave, lane);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");    // the rays just written are read back by this wave's other lanes
+        if (rv.n == 0) break;
+        for (uint32_t c = lane; c < rv.n; c += MSK_WAVE) {
+            const uint32_t i = rv.slot(c);
+            const float4 ro = st.ray_o[i];
+            float4 rd = st.ray_d[i];
+            const bool has_shadow = c < rv.ns;
+            rd.w = slot_tmax(rd.w);
+            const f3 o = mk3(ro.x, ro.y, ro.z);
+            float bt, bu, bv; uint32_t bp;
+            uint32_t unocc = 0;
+            if (has_shadow) {
+                const float4 s = st.sh[i];
+                const bool occ = traverse_scene<6, true>(sc, g, o, mk3(s.x, s.y, s.z), ro.w, s.w, stack, &bt, &bu, &bv, &bp);
+                unocc = occ ? 0u : MSK_HIT_UNOCCLUDED;
+            }
+            traverse_scene<6, false>(sc, g, o, mk3(rd.x, rd.y, rd.z), ro.w, rd.w, stack, &bt, &bu, &bv, &bp);
+            const bool valid = (bp != MSK_NO_PRIM) && (bt != rd.w);           // scene.cpp:234 tfar != maxt
+            st.hit[i] = make_float4(valid ? bt : MSK_INF_F, bu, bv, __uint_as_float((valid ? bp : MSK_PRIM_MASK) | unocc));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+}
+
 // AOVIntegrator::sample's primary-hit channels (aov.cpp:89-122): runs after k_trace, picks the slots whose camera ray
 // has just been traced (depth 1) and writes their record groups.  A miss writes zeros.
 __global__ void __launch_bounds__(MSK_BLOCK)

@@ -79,14 +79,15 @@ def test_per_sample_radiance_bit_exact(big, abi):
     assert np.isfinite(gx).all() and gx.max() > 0
 
 
-@pytest.mark.parametrize("mode", ["default", "one_stream", "threads4_poll"])
+@pytest.mark.parametrize("mode", ["default", "one_stream", "threads4_poll", "device_side_tail"])
 def test_whole_film_bit_exact_at_2_spp(big, abi, monkeypatch, mode):
     """The FILM of the mesh configs at their full 1024 x 1024 (2 spp: 2 M samples, seconds for the oracle): the general shading
     variant + k_trace_r<6> + the four-part loop (8192 regions of 256 slots) + the ordered film replay, GPU == oracle
-    bit for bit (integrator.cpp:82-126 over scene.cpp:216-273) — in the default mode, with one loop on one stream, and with
-    rounds 2-5's four polling loop threads."""
+    bit for bit (integrator.cpp:82-126 over scene.cpp:216-273) — in the default mode, with one loop on one stream, with
+    rounds 2-5's four polling loop threads, and with the thin end of the pass in the device-side loop (k_wavefront_h)."""
     g, o, _, _ = big
-    for k, v in {"default": {}, "one_stream": {"MSK_STREAMS": "1"}, "threads4_poll": {"MSK_HOST_THREADS": "4", "MSK_WAIT": "poll"}}[mode].items():
+    for k, v in {"default": {}, "one_stream": {"MSK_STREAMS": "1"}, "threads4_poll": {"MSK_HOST_THREADS": "4", "MSK_WAIT": "poll"},
+                 "device_side_tail": {"MSK_FUSED_HBM": "1", "MSK_FUSED_TAIL_PCT": "40"}}[mode].items():        # k_wavefront_h for the thin end
         monkeypatch.setenv(k, v)
     prm = abi.render_params(spp=2, seed=6)
     film, st = g.render(prm)
