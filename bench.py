@@ -37,6 +37,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Before the HIP runtime starts (nothing has imported torch yet): streams map onto GPU_MAX_HW_QUEUES hardware queues per priority
+# level (default 4), and a rank holds torch's and RCCL's streams beside the library's four — streams that share a queue serialise
+# (DESIGN.md §6 "Hardware queues": 39.4 vs 32.5 ms per step).  The library's own streams sit at the highest priority, in a pool of
+# their own; this is the belt to those braces, and what a caller of MSK_STREAM_PRIORITY=normal needs.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 WIDTH = HEIGHT = 512
 SPP_PER_GPU = 512
@@ -66,6 +71,10 @@ def parse_args():
                     help="restrict this process (and the ranks it spawns: they share the set) to the first C CPUs of its affinity mask "
                          "before anything touches a GPU — the host-side waits under a CPU quota (tools/cpu_contention.py, DESIGN.md §7)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: launch, rendezvous (gloo), reduce and timing only")
+    ap.add_argument("--rccl-world1", action="store_true",
+                    help="N = 1 through the N > 1 step: a process group of ONE rank over RCCL (nccl), msk_gpu_render_device + the film "
+                         "reduce + rank 0's pinned copy-back, and the sharded config 4 / 5 runs — everything of the multi-GPU step but a "
+                         "peer, on a one-GPU box; the line says \"rccl_world1\": true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks (or --in-process members) that ALL render on cuda:0, the ranks reducing over gloo through host "
                          "copies of the film: the whole multi-GPU path but the RCCL call / the peer reads, on a one-GPU box "
@@ -365,8 +374,10 @@ def sharded_configs(args, abi, hm, mg, ctx, dist, rank, world, rehearsal, fence)
                 scene = abi.Scene(ctx, flat)
                 prm = mg.shard_params(abi, spp, rank, world, mode=shard, seed=0)
                 film = torch.zeros((h, w, 5), dtype=torch.float32, device="cuda")
-                host_film = np.zeros((h, w, 5), np.float32)
-                host_t = torch.from_numpy(host_film)
+                host_t = torch.zeros((h, w, 5), dtype=torch.float32)
+                if not rehearsal:
+                    host_t = host_t.pin_memory()
+                host_film = host_t.numpy()
                 scene.render_device(prm, film.data_ptr())        # untimed: workspace, plan (no collective: a failure here is local)
         except Exception as e:
             err = str(e)[:200]
@@ -393,7 +404,7 @@ def sharded_configs(args, abi, hm, mg, ctx, dist, rank, world, rehearsal, fence)
                 if rank == 0:
                     host_t.copy_(host)
             else:
-                mg.reduce_film(film, dist)
+                mg.reduce_film(film, dist, force=args.rccl_world1)
                 if rank == 0:
                     host_t.copy_(film)
             return st
@@ -627,10 +638,12 @@ def main():
     if not args.dry_run:
         torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or (args.rccl_world1 and not args.dry_run)       # the N > 1 step (render_device + reduce + rank 0's copy-back)
+    if multi:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29733")
         if args.dry_run or rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -655,15 +668,19 @@ def main():
         ctx = abi.Context([0] * members if rehearsal and members > 1 else list(range(members)) if members > 1 else local_rank)
         scene = abi.Scene(ctx, flat)
         # --in-process: the library itself shards the call's samples over the members
-        prm = mg.shard_params(abi, spp_total, rank, world, mode=args.shard, seed=0) if world > 1 else abi.render_params(spp=spp_total, seed=0)
+        prm = mg.shard_params(abi, spp_total, rank, world, mode=args.shard, seed=0) if multi else abi.render_params(spp=spp_total, seed=0)
         film = torch.zeros((HEIGHT, WIDTH, 5), dtype=torch.float32, device="cuda")
-        host_film = np.zeros((HEIGHT, WIDTH, 5), np.float32)          # rank 0's copy-back target (msk_gpu_render stages through pinned memory)
-        host_t = torch.from_numpy(host_film)
+        # rank 0's copy-back target.  N = 1: msk_gpu_render stages through its own pinned buffer.  N > 1: torch copies the reduced film
+        # into it, and a pageable target makes that copy 2-3 ms of a 31 ms step (a tenth of the weak-scaling budget): pinned
+        host_t = torch.zeros((HEIGHT, WIDTH, 5), dtype=torch.float32)
+        if multi and not rehearsal:
+            host_t = host_t.pin_memory()
+        host_film = host_t.numpy()
 
         def step_hbm():
             return scene.render_device(prm, film.data_ptr())
 
-        if world == 1:
+        if not multi:
             def step():
                 return scene.render(prm, out=host_film)[1]           # msk_gpu_render: the render + the film's copy-back
         else:
@@ -677,7 +694,7 @@ def main():
                     if rank == 0:
                         host_t.copy_(host)
                 else:
-                    mg.reduce_film(film, dist)
+                    mg.reduce_film(film, dist, force=args.rccl_world1)
                     if rank == 0:
                         host_t.copy_(film)                   # the reduced film's copy-back (synchronous)
                 return st
@@ -729,7 +746,7 @@ def main():
 
     # N > 1: the sharded config 4 / 5 runs — every rank takes part; rank 0 first puts the headline on stderr (below)
     sharded = {}
-    run_sharded = world > 1 and not args.no_other_configs
+    run_sharded = (world > 1 or multi) and not args.no_other_configs
     if run_sharded and (rank != 0 or args.dry_run):
         sharded = sharded_configs(args, abi, hm, mg, ctx, dist, rank, world, rehearsal, fence)
     if rank == 0 and args.dry_run:
@@ -744,13 +761,13 @@ def main():
               flush=True)
     elif not args.dry_run:
         # the same K steps with the film left in HBM (every rank takes part: the steps hold collectives)
-        dt_hbm, _ = timed(step_hbm, args.steps) if world == 1 else (None, None)
+        dt_hbm, _ = timed(step_hbm, args.steps) if world == 1 else (None, None)       # (N = 1, also through --rccl-world1)
     if rank == 0 and not args.dry_run:
         import numpy as np
         n_gpus = max(world, members)
         samples_step = WIDTH * HEIGHT * spp_total              # all GPUs together
         value = samples_step * args.steps / dt / 1e6
-        par = "single GPU"
+        par = "single GPU" + (", through the N > 1 step: RCCL group of one rank, film reduce + pinned copy-back" if multi else "")
         if world > 1:
             par = f"{args.shard[:-1]}-shard x{world}, one process per GPU + " + ("gloo film reduce through host copies (rehearsal on one GPU)" if rehearsal else "RCCL film reduce")
         elif members > 1:
@@ -759,6 +776,7 @@ def main():
             "metric": "Msamples/s (paths x spp) on cbox@512spp", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            **({"rccl_world1": True} if (multi and world == 1) else {}),
             **({"rehearsal": True, "film_finite": bool(np.isfinite(host_film).all()), "film_weight_sum": float(host_film[..., 4].astype(np.float64).sum())} if rehearsal else {}),
             # (`config` holds scalars only: the driver's parser drops nested values; `workload` stays under 120 characters)
             "config": {"workload": f"cbox {WIDTH}x{HEIGHT} @ {args.spp} spp/GPU, diffuse, path (NEE+MIS, RR), counter RNG, incl. film resolve + film copy-back",
@@ -802,7 +820,7 @@ def main():
                                                    "sample": l2["cpu"], "host_cpus": os.cpu_count()}
         else:
             out["cpu_baseline"] = None
-        if n_gpus == 1 and not args.no_other_configs:
+        if n_gpus == 1 and not args.no_other_configs and not multi:
             out["other_configs"] = other_configs(abi, hm, ctx, skip_cpu=args.no_cpu_baseline)
             for e in out["other_configs"]:
                 if "value" in e:

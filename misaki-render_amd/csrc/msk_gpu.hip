@@ -148,8 +148,23 @@ extern "C" int msk_gpu_init(const int *device_ids, int n, msk_ctx **out_ctx) {
     ctx->device = device_ids[0];
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, ctx->device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    for (int k = 0; k < MSK_MAX_STREAMS - 1; ++k) if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->more_streams[k], hipStreamNonBlocking);
+    // The library's streams and the process's other streams.  The HIP runtime maps streams onto a few hardware queues PER PRIORITY
+    // LEVEL (GPU_MAX_HW_QUEUES, default 4); streams beyond that share a queue and their launches serialise.  In a process that also
+    // runs torch and RCCL (bench.py's ranks: torch's stream, the communicator's streams) two of the four wavefront loops ended up
+    // behind each other: the N > 1 step took 39.4 ms against the 32.5 of the same render in a plain process (round 6,
+    // profiles/r06_hw_queues.txt) — a fifth of the weak-scaling budget before any GPU talks to another.  MSK_STREAM_PRIORITY = high
+    // (default) creates the library's streams at the device's highest stream priority: their own pool of hardware queues, which
+    // nothing else in the process uses; normal / low: priority 0 / the lowest (then raise GPU_MAX_HW_QUEUES in the environment).
+    int prio = 0;
+    {
+        int least = 0, greatest = 0;
+        const char *ps = getenv("MSK_STREAM_PRIORITY");
+        if (e == hipSuccess && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
+            prio = (!ps || !strcmp(ps, "high")) ? greatest : !strcmp(ps, "low") ? least : 0;
+        (void) hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio);
+    for (int k = 0; k < MSK_MAX_STREAMS - 1; ++k) if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->more_streams[k], hipStreamNonBlocking, prio);
     if (e == hipSuccess) e = hipHostMalloc((void **) &ctx->h_ctrl, MSK_MAX_STREAMS * sizeof(Ctrl), hipHostMallocDefault);
     ctx->hub = new mskwd::Hub();
     for (int k = 0; k < MSK_MAX_STREAMS; ++k) if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->wait_events[k], hipEventBlockingSync | hipEventDisableTiming);

@@ -53,14 +53,15 @@ def balanced_shares(spp_total, step_ms):
     return shares
 
 
-def reduce_film(film, dist=None, dst=0):
+def reduce_film(film, dist=None, dst=0, force=False):
     """Sum the per-rank films onto rank `dst` (in place).  film: torch tensor [H, W, 5] float32.
 
     Returns when the reduce has finished with `film` on this rank.  The back end renders on its own HIP stream
     (msk_gpu_render_device with hip_stream = NULL returns when the film is complete), the collective runs on the process
     group's stream behind torch's current stream: without the wait below the next render could overwrite `film` while
     the reduce still reads it."""
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    # (force: issue the collective in a group of ONE rank too — bench.py --rccl-world1, the RCCL step on a one-GPU box)
+    if dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force):
         dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
         if film.is_cuda:
             import torch
