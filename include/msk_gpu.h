@@ -24,9 +24,14 @@
  *     it; the library copies what it needs into HBM.
  *   - handles are opaque and destroyed explicitly.
  *   - one calling thread per msk_ctx at a time (the reference calls render()
- *     from a single worker thread, src/apps/main.cpp:37).  A render call uses
- *     up to three short-lived helper threads and four HIP streams of its own
- *     inside the library; it returns when all of them are done.
+ *     from a single worker thread, src/apps/main.cpp:37).  A render call drives
+ *     four HIP streams of its own from the calling thread (MSK_HOST_THREADS=4:
+ *     from three short-lived helper threads as well) and sleeps while the
+ *     device works; every wait has a wall limit (MSK_WATCHDOG_S): the call
+ *     returns, with MSK_ERR_HIP and a lost context if the device stopped
+ *     answering.  The streams are created at the device's highest stream
+ *     priority (MSK_STREAM_PRIORITY) so that they do not share hardware queues
+ *     with the application's other streams.
  */
 #ifndef MSK_GPU_H
 #define MSK_GPU_H

@@ -46,3 +46,36 @@ def test_a_render_that_makes_no_progress_ends_with_an_error_and_a_lost_context(a
         film2, st2 = s2.render(abi.render_params(spp=4))
         s2.close()
     assert np.array_equal(film2, film)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wait,threads", [("callback", "1"), ("callback", "4"), ("sleep", "1"), ("poll", "4"), ("event", "1"), ("sync", "4")])
+def test_every_wait_strategy_renders_the_same_film_and_keeps_the_wall_limit(abi, hostmirror, golden_lookup, monkeypatch, wait, threads):
+    """MSK_WAIT x MSK_HOST_THREADS (msk_watchdog.h: wait_any; msk_gpu.hip: drive): who waits how for a sync group changes no bit
+    of the film — 1024+ regions, so the four-part loop is what runs — and the strategies that can time a wait (callback, sleep,
+    poll) end a render that makes no progress the same way."""
+    flat = hostmirror.cbox_scene(192, 160, coeff_lookup=golden_lookup)
+    prm = abi.render_params(spp=40, seed=7)
+    with abi.Context(0) as ctx:
+        sc = abi.Scene(ctx, flat)
+        ref, st0 = sc.render(prm)
+        sc.close()
+    monkeypatch.setenv("MSK_WAIT", wait)
+    monkeypatch.setenv("MSK_HOST_THREADS", threads)
+    ctx = abi.Context(0)
+    assert f"wait = {wait}" in ctx.describe() and f"{threads} loop thread" in ctx.describe()
+    sc = abi.Scene(ctx, flat)
+    film, st = sc.render(prm)
+    assert st.samples == st0.samples == 192 * 160 * 40 and st.segments == st0.segments
+    assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+    if wait in ("callback", "sleep", "poll"):
+        monkeypatch.setenv("MSK_WATCHDOG_S", "1e-9")
+        with pytest.raises(abi.MskError) as e:
+            sc.render(abi.render_params(spp=64))
+        assert "no progress" in str(e.value) and "MSK_WATCHDOG_S" in str(e.value)
+        monkeypatch.delenv("MSK_WATCHDOG_S")
+        with pytest.raises(abi.MskError) as e:
+            sc.render(prm)
+        assert "context is lost" in str(e.value)
+    sc.close()
+    ctx.close()
