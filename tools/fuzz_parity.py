@@ -84,6 +84,31 @@ def random_scene(rng):
     if frng.randint(0, 4) == 0:      # a crop window (film.cpp:12-21): anywhere in the film, down to one pixel (side stream again)
         cw, ch = int(frng.randint(1, fw + 1)), int(frng.randint(1, fh + 1))
         crop = (int(frng.randint(0, fw - cw + 1)), int(frng.randint(0, fh - ch + 1)), cw, ch)
+    # tabulated (`regular`) spectra on a quarter of the scenes (ABI v7; side stream): any of a diffuse reflectance, a conductor's
+    # eta / k, a dielectric's transmittance, an emitter's radiance, the environment's — tables of 2 … 95 values on grids that
+    # cover the sampled wavelengths, start inside them or end inside them (the end segments are then continued)
+    trng = np.random.RandomState((len(meshes) * 104729 + int(abs(meshes[0].faces[0][0][1]) * 1e3)) % 1000003)
+    if trng.randint(0, 4) == 0:
+        def table(lo, hi):
+            n = int(trng.choice([2, 3, 5, 16, 31, 48, 95]))
+            l0 = float(np.float32(trng.choice([300.0, 360.0, 380.0, 450.0])))
+            l1 = float(np.float32(l0 + trng.choice([150.0, 320.0, 470.0, 600.0])))
+            return hm.Regular(l0, l1, trng.uniform(lo, hi, n).astype(np.float32))
+        for m in meshes:
+            if trng.randint(0, 3):
+                continue
+            if m.bsdf is None and not np.isscalar(m.reflectance):
+                m.reflectance = table(0.02, 0.95)
+            elif m.bsdf and m.bsdf["type"] == "roughconductor":
+                m.bsdf["eta"], m.bsdf["k"] = table(0.1, 3.0), table(0.5, 4.0)
+                if trng.randint(0, 2):
+                    m.bsdf["specular_reflectance"] = table(0.3, 1.0)
+            elif m.bsdf and m.bsdf["type"] == "roughdielectric":
+                m.bsdf["specular_transmittance"] = table(0.2, 1.0)
+            if m.radiance is not None and trng.randint(0, 2):
+                m.radiance = table(0.01, 0.4)
+        if env is not None and trng.randint(0, 2):
+            env["radiance"] = table(0.001, 0.02)
     flat = hm.flatten(meshes, fw, fh, env=env, camera=camera, filter_stddev=stddev, crop=crop)
     # vertex normals (perturbed face normals) and texture coordinates on some meshes: mesh.cpp:68-96
     verts, faces = flat.vertices, flat.faces
