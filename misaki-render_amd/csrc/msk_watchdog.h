@@ -1,16 +1,21 @@
-// msk_watchdog.h — the progress watchdog of the wavefront loop (round 5).
+// msk_watchdog.h — how a render waits for its device, and when it stops waiting (rounds 5-6).
 //
 // SamplingIntegrator::render returns, and main.cpp:55-57 catches what it throws; a caller of msk_gpu_render must get the same
-// guarantee from a back end whose loop waits on a device.  Two ways the loop of msk_gpu.hip (run_wavefront) could wait for ever:
-//   * a sync group's kernels never finish (a wave that spins, a device that stopped answering): hipStreamSynchronize has no
-//     timeout, so the loop waits with hipStreamQuery polls instead and gives up after MSK_WATCHDOG_S seconds (default 120 — a
-//     sync group is 8 iterations of a few milliseconds; 0 = plain hipStreamSynchronize, no wall limit);
+// guarantee from a back end whose loop waits on a device.  Two ways a render could wait for ever:
+//   * queued work never finishes (a wave that spins, a device that stopped answering): hipStreamSynchronize has no timeout, so
+//     EVERY wait of a render — a sync group of the wavefront loop (wait_any below), the film replay, Film::put, the film's
+//     copy-back, the one long kernel of MSK_RNG_PCG_BLOCK (msk_gpu.hip: ctx_sync) — is a timed wait and gives up after
+//     MSK_WATCHDOG_S seconds (default 120 per sync group — eight iterations of a few milliseconds —, 30 x that for the
+//     one-kernel render; 0 = no wall limit);
 //   * the kernels finish but nothing moves: the counters the host reads after every group (samples finished, segments traced,
 //     samples not yet started, live paths) are the same for MSK_WATCHDOG_GROUPS consecutive groups (default 64).
 // Either ends the render with MSK_ERR_HIP "no progress ...": the context is marked lost — every later call on it fails at
-// once, msk_gpu_shutdown releases host memory only (destroying a stream that still holds a hung kernel would wait for it) —
-// and the caller is expected to exit or to start over in a fresh child process.  Nothing here restarts or replaces a process
-// that has touched the GPU.
+// once, teardown releases host memory only (hipFree / hipStreamDestroy would wait for the kernel that never finished; local
+// device buffers of the failed call are dropped, not freed) — and the caller is expected to exit or to start over in a fresh
+// child process.  Nothing here restarts or replaces a process that has touched the GPU.
+//
+// HOW a thread waits is MSK_WAIT (below): by default it sleeps on a condition variable that a host function queued behind the
+// awaited work signals — rounds 4-5 polled hipStreamQuery with yields, one spinning thread per wavefront loop.
 //
 // The decision logic is plain C++ (no HIP): tests/native/watchdog_check.cpp exercises it on the CPU.
 #pragma once
