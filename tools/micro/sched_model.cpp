@@ -160,6 +160,36 @@ static void model_replace(const std::vector<RayIn> &rays, int max_inner, int ref
     }
 }
 
+// (iv) shadow rays and extension rays as SEPARATE jobs of the region's wave (k_trace_q's scheme on a tree in HBM): the shadow rays
+// first, then every slot's extension ray; a lane takes the next job when `refill` lanes are idle
+static void model_jobs(const std::vector<RayIn> &rays, int max_inner, int refill, Tally &ty) {
+    struct J { const RayIn *in; bool shadow; };
+    std::vector<J> jobs;
+    for (auto &r : rays) if (r.has_shadow) jobs.push_back(J{&r, true});
+    for (auto &r : rays) jobs.push_back(J{&r, false});
+    std::vector<Job> job(64);
+    Job *lane[64] = {};
+    size_t next = 0;
+    for (;;) {
+        int idle = 0;
+        for (int l = 0; l < 64; ++l) idle += lane[l] == nullptr;
+        if (next < jobs.size() && idle && (idle >= refill || idle == 64)) {
+            for (int l = 0; l < 64 && next < jobs.size(); ++l) if (!lane[l]) {
+                const J &j = jobs[next++];
+                job[l].in = j.in; job[l].done = false; job[l].phase = 1;          // phase 1: finishing the ray finishes the job
+                if (j.shadow) begin(job[l].t, j.in->o, j.in->s, j.in->tmin, j.in->smax, true);
+                else begin(job[l].t, j.in->o, j.in->d, j.in->tmin, j.in->tmax, false);
+                lane[l] = &job[l];
+            }
+        }
+        bool any = false;
+        for (int l = 0; l < 64; ++l) any |= lane[l] != nullptr;
+        if (!any) break;
+        wave_quantum(lane, 64, max_inner, ty);
+        for (int l = 0; l < 64; ++l) if (lane[l]) { ty.rays += job_advance(*lane[l]); if (lane[l]->done) lane[l] = nullptr; }
+    }
+}
+
 // (ii) a pool of P slots, re-binned every quantum: sort by (leaf?, cursor), waves of 64 consecutive jobs
 static void model_rebin(const std::vector<const RayIn *> &queue, size_t P, int max_inner, bool split_types, Tally &ty) {
     std::vector<Job> pool(std::min(P, queue.size()));
@@ -292,5 +322,7 @@ int main(int argc, char **argv) {
     }
     { Tally t; std::vector<const RayIn *> q; for (auto &rg : regions) for (auto &x : rg) q.push_back(&x); model_rebin(q, q.size(), 1, true, t); t.print("(ii') everything, re-binned after EVERY node step"); }
     { Tally t; for (auto &rg : regions) model_pairs(rg, max_inner, refill, t); t.print("(iii) shadow + extension ray in one lane"); }
+    { Tally t; for (auto &rg : regions) model_jobs(rg, max_inner, refill, t); t.print("(iv)  shadow and extension rays as separate jobs");
+      std::printf("      quanta per region %.1f (today: %.1f) — the length of a launch is its slowest wave's quanta\n", (double) t.quanta / regions.size(), (double) a.quanta / regions.size()); }
     return 0;
 }
