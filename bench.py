@@ -687,7 +687,9 @@ def main():
             def step():
                 # render_device returns when the film is complete on the library's stream; reduce_film returns when the
                 # reduce has finished reading it (multigpu.reduce_film synchronises): the next render may overwrite it
+                t_r = time.perf_counter()
                 st = scene.render_device(prm, film.data_ptr())
+                own["render_s"] += time.perf_counter() - t_r          # this rank's own render, without waiting for anybody
                 if rehearsal:                                # gloo has no device reduce: through the host (rehearsal only)
                     host = film.cpu()
                     mg.reduce_film(host, dist)
@@ -698,6 +700,8 @@ def main():
                     if rank == 0:
                         host_t.copy_(film)                   # the reduced film's copy-back (synchronous)
                 return st
+
+    own = {"render_s": 0.0}
 
     def fence():
         if not args.dry_run:
@@ -733,7 +737,16 @@ def main():
             balance = {"equal_split_kernel_ms": [round(t, 2) for t in times], "spp_shares": shares}
     import resource
     ru0, th0 = resource.getrusage(resource.RUSAGE_SELF), _thread_cpu()
+    own["render_s"] = 0.0
     dt, stats = timed(step, args.steps)
+    # N > 1: every rank's own render time per step (the renders alone, no reduce, no waiting): the spread between the node's GPUs —
+    # an equal split waits for the slowest — apart from what the reduce and rank 0's copy-back cost
+    rank_render_ms = None
+    if dist is not None and multi and not args.dry_run:
+        mine = torch.tensor([own["render_s"] / max(args.steps, 1) * 1e3], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        gathered = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(gathered, mine)
+        rank_render_ms = [round(float(x.item()), 3) for x in gathered]
     ru1, th1 = resource.getrusage(resource.RUSAGE_SELF), _thread_cpu()
     by_thread = sorted(((round(c - th0.get(t, (n, 0.0))[1], 3), n, t == os.getpid()) for t, (n, c) in th1.items()), reverse=True)
     # host CPU this rank's process spent inside the timed region (every thread: the library's loop, its waits, the runtime's helpers)
@@ -783,10 +796,12 @@ def main():
                        "timing_scope": "incl_copyback", "spp_total": spp_total,
                        "parallelism": par, "shard": (args.shard if world > 1 else "samples" if members > 1 else "none"), "samples_per_step": samples_step,
                        "rccl_ranks": dist.get_world_size() if dist is not None else 1, "in_process_members": members,
-                       "devices_seen": n_dev, "balanced": balance is not None},
+                       "devices_seen": n_dev, "balanced": balance is not None,
+                       **({"rank_render_ms_min": min(rank_render_ms), "rank_render_ms_max": max(rank_render_ms),
+                           "step_minus_slowest_render_ms": round(dt / args.steps * 1e3 - max(rank_render_ms), 3)} if rank_render_ms else {})},
             # what the step's clock covers (integrator.cpp:43-78 is the reference's scope): since round 4 `value` includes the film's
             # copy-back to the host (rounds 1-3: film left in HBM = `value_film_in_hbm`, the figure to compare across rounds)
-            "timing_scope": "incl_copyback", "balance": balance, "host_side": host_side,
+            "timing_scope": "incl_copyback", "balance": balance, "host_side": host_side, "rank_render_ms": rank_render_ms,
             "roofline": roofline(stats, args),
         }
         if dt_hbm is not None:
