@@ -366,6 +366,8 @@ def sharded_configs(args, abi, hm, mg, ctx, dist, rank, world, rehearsal, fence)
         spp = getattr(args, opt)
         scene, err = None, None
         try:
+            if os.environ.get("MSK_BENCH_TEST_FAIL_CONFIG") == f"{rank}:{tag}":        # tests/test_bench_launch.py: a rank that cannot set a config up
+                raise RuntimeError("test: rank %d cannot set %s up" % (rank, tag))
             if args.dry_run:
                 film = torch.ones((h, w, 5), dtype=torch.float32)
             else:

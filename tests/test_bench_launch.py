@@ -55,6 +55,20 @@ def test_bare_shell_gpus_2_spawns_two_ranks():
     assert r.returncode == 0 and _last_json(r.stdout)["config"]["shard"] == "tiles", r.stderr[-2000:]
 
 
+def test_a_rank_that_cannot_set_a_sharded_config_up_does_not_hang_the_others():
+    """sharded_configs: every rank learns before the first collective of a config whether every rank is ready; a rank that failed
+    (out of memory on its GPU, say) makes all of them skip that config — the line carries c4_error, config 5 still runs, exit code 0."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=dict(_env(), MSK_BENCH_TEST_FAIL_CONFIG="1:c4"), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    c = _last_json(r.stdout)["config"]
+    assert "another rank" in c["c4_error"] and "c4_ms" not in c and c["c5_reduce_ok"] and _scalar_config({"config": c})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=dict(_env(), MSK_BENCH_TEST_FAIL_CONFIG="0:c5"), cwd=ROOT)
+    c = _last_json(r.stdout)["config"]
+    assert r.returncode == 0 and "test: rank 0" in c["c5_error"] and c["c4_reduce_ok"]
+
+
 def test_under_torch_distributed_run():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
