@@ -922,14 +922,16 @@ static int run_wavefront(msk_scene *sc, hipStream_t stream, const msk_render_par
     const uint32_t fused_queue_f4 = (uint32_t) ((sc->shade_lds_bytes - (size_t) (MSK_BLOCK / MSK_WAVE) * MSK_DONE_Q_F4 * 16) / 16);     // after the staged tables
     const uint32_t fused_trace_f4 = (uint32_t) (sc->shade_lds_bytes / 16);
     const size_t fused_lds = sc->shade_lds_bytes + sc->trace_lds_bytes;
-    // ... and k_wavefront_h for the default tree in HBM (trace mode 6), the thin end only: MSK_FUSED_HBM=1.  Built, bit-identical,
-    // measured (round 6, same box, config-5 / config-3 class renders): 117.9 / 137.1 ms with it against 116.2 / 138.6 without — the
-    // thin end is bound by each wave's own longest rays, which a loop without launch boundaries still waits for: not the default.
-    const bool fused_h = sc->trace_mode == 6 && !sc->lds_tables && env_u32("MSK_FUSED_HBM", 0) != 0;
+    // ... and k_wavefront_h for the default tree in HBM (trace mode 6): the VERY thin end only (MSK_FUSED_HBM=0: off).  Round 6, same
+    // box, config-5 / config-3 class renders: from 10 % live slots on (the LDS-resident scenes' threshold) 117.9 / 137.1 ms against
+    // 116.2 / 138.6 without — a wave's own longest rays bound both, and the fused kernel walks them at two waves per SIMD without lane
+    // replacement; from 1-3 % on — the ~40 last iterations, whose launches are a few dozen microseconds of latency each —
+    // 118.1-118.2 / 143.9-144.2 ms against 119.2 / 146.2 (profiles/r06_ab_fused_hbm.txt): the default, at 2 %.
+    const bool fused_h = sc->trace_mode == 6 && !sc->lds_tables && env_u32("MSK_FUSED_HBM", 1) != 0;
     const bool fused_ok = ((sc->trace_mode == 0 && sc->lds_tables) || fused_h) && fused_lds <= 64 * 1024 && !(aov && aov->n_groups);
     const bool fused_all = fused_ok && env_u32("MSK_FUSED", 0) != 0;
     const uint32_t fused_iters = std::max(1u, env_u32("MSK_FUSED_ITERS", 16));
-    const uint32_t fused_tail_pct = fused_ok ? env_u32("MSK_FUSED_TAIL_PCT", 10) : 0u;
+    const uint32_t fused_tail_pct = fused_ok ? env_u32("MSK_FUSED_TAIL_PCT", fused_h ? 2 : 10) : 0u;
 
     // The wavefront loop over the regions [first, first + count) on one stream.  The pool's two halves run this at the same
     // time on two streams (two host threads): regions are independent — each owns its slots, its share of the samples and

@@ -1190,6 +1190,52 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
     return found;
 }
 
+#ifndef MSK_THIN_RAYS
+#define MSK_THIN_RAYS 1          /* 0 (A/B builds): thin regions walked like any other */
+#endif
+// A THIN region — its live slots and their shadow rays together fit one wave (n + ns <= 64: the last third of a pass, when Russian
+// roulette's tail drains) — is walked one RAY per lane instead of one slot per lane: lanes [0, ns) take the shadow rays, lanes
+// [ns, ns + n) the extension rays, all of them through trav_quantum's one instruction stream (its `any` flag is per lane), and
+// the extension lane of a slot fetches the shadow lane's verdict with one cross-lane read at the end.  A slot's two rays are
+// then walked side by side instead of one after the other: the launch — as long as its slowest wave — is about half as long
+// (round 6; measured in profiles/r06_ab_thin.txt).  Each ray's arithmetic is trav_quantum's as everywhere: same hits.
+template <int MODE>
+MSK_DEV void trace_thin(const DeviceScene &sc, const PathState &st, const TraceLds &g, const RegionView &rv, const LaneStack<MSK_OVF(MODE)> &stack,
+                        uint32_t lane, int max_inner) {
+    const bool is_shadow = lane < rv.ns;
+    const uint32_t c = is_shadow ? lane : lane - rv.ns;
+    const bool work = lane < rv.ns + rv.n;
+    uint32_t slot = 0;
+    float tmax_ext = 0.f;
+    TravState t;
+    t.cur = 0xffffffffu; t.sp = 0; t.bp = MSK_NO_PRIM; t.bt = 0.f; t.bu = 0.f; t.bv = 0.f;
+    if (work) {
+        slot = rv.slot(c);
+        const float4 ro = st.ray_o[slot];
+        const uint32_t root = MODE == 4 ? sc.root_ref8 : MSK_WIDE4H(MODE) ? sc.root_ref4 : sc.root_ref;
+        if (is_shadow) {
+            const float4 s = st.sh[slot];
+            trav_begin(t, root, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(s.x, s.y, s.z), ro.w, s.w);
+        } else {
+            float4 rd = st.ray_d[slot];
+            rd.w = slot_tmax(rd.w);
+            tmax_ext = rd.w;
+            trav_begin(t, root, sc.n_tris, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+        }
+    }
+    bool occ = false;
+    while (__ballot(t.cur != 0xffffffffu) != 0ull) {
+        if (t.cur != 0xffffffffu) occ = trav_quantum<MODE>(sc, g, t, stack, max_inner, is_shadow) || occ;
+    }
+    // the shadow lane of slot c is lane c; its extension lane is lane ns + c
+    const int verdict = __shfl((int) occ, (int) (lane - rv.ns), MSK_WAVE);
+    if (work && !is_shadow) {
+        const uint32_t unocc = (c < rv.ns && !verdict) ? MSK_HIT_UNOCCLUDED : 0u;
+        const bool valid = (t.bp != MSK_NO_PRIM) && (t.bt != tmax_ext);
+        st.hit[slot] = make_float4(valid ? t.bt : MSK_INF_F, t.bu, t.bv, __uint_as_float((valid ? t.bp : MSK_PRIM_MASK) | unocc));
+    }
+}
+
 // Six waves per SIMD (80 VGPRs, no scratch in the default instantiation <5>; the unconstrained build takes 90 = five waves).
 // Alone the kernel gains nothing from the sixth wave (65.3 vs 66.2 ms on the config-5-class scene), beside the shading kernel's
 // 168-VGPR waves in the four-loop mode the smaller footprint is worth 7 % of the render (77.7 vs 84.0 ms); seven waves (72 VGPRs,
@@ -1212,6 +1258,7 @@ MSK_DEV void trace_replace(const DeviceScene &sc, const PathState &st, const Pas
     if (lwave >= pp.region_count) return;
     const uint32_t wave = pp.region_first + lwave;
     const RegionView rv = region_view(wave, pp.region_size, pp.regions[wave].count, pp.regions[wave].half_ns);
+    if (MSK_THIN_RAYS && rv.n + rv.ns <= MSK_WAVE) { trace_thin<MODE>(sc, st, g, rv, stack, lane, max_inner); return; }
     const uint32_t n = rv.n;
     uint32_t next = 0;                       // wave-uniform: first slot nobody has taken yet
     bool active = false, shadow_phase = false;
@@ -2340,6 +2387,8 @@ k_wavefront_h(DeviceScene sc, PathState st, PassParams pp, uint32_t max_iters, u
         const RegionView rv = shade_region<DIFFUSE_ONLY>(sc, tb, dq, SortScratch{nullptr, nullptr}, st, pp, wave, lane);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");    // the rays just written are read back by this wave's other lanes
         if (rv.n == 0) break;
+        if (MSK_THIN_RAYS && rv.n + rv.ns <= MSK_WAVE) trace_thin<6>(sc, st, g, rv, stack, lane, 3);
+        else
         for (uint32_t c = lane; c < rv.n; c += MSK_WAVE) {
             const uint32_t i = rv.slot(c);
             const float4 ro = st.ray_o[i];
