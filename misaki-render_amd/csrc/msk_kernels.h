@@ -1193,6 +1193,9 @@ MSK_DEV bool trav_quantum(const DeviceScene &sc, const TraceLds &g, TravState &t
 #ifndef MSK_THIN_RAYS
 #define MSK_THIN_RAYS 1          /* 0 (A/B builds): thin regions walked like any other */
 #endif
+#ifndef MSK_THIN_RAYS_LDS
+#define MSK_THIN_RAYS_LDS 0      /* the same inside k_wavefront (LDS-resident scenes): built, bit-identical, bench step 33.0 vs 33.0 ms: off */
+#endif
 // A THIN region — its live slots and their shadow rays together fit one wave (n + ns <= 64: the last third of a pass, when Russian
 // roulette's tail drains) — is walked one RAY per lane instead of one slot per lane: lanes [0, ns) take the shadow rays, lanes
 // [ns, ns + n) the extension rays, all of them through trav_quantum's one instruction stream (its `any` flag is per lane), and
@@ -2337,6 +2340,8 @@ k_wavefront(DeviceScene sc, PathState st, PassParams pp, uint32_t max_iters, uin
         // CU's own L1 after the stores have drained
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (rv.n == 0) break;                                  // no live path, and regeneration found no sample to start
+        if (MSK_THIN_RAYS_LDS && rv.n + rv.ns <= MSK_WAVE) trace_thin<0>(sc, st, g, rv, stack, lane, 4);      // one ray per lane (see trace_thin)
+        else
         for (uint32_t c = lane; c < rv.n; c += MSK_WAVE) {
             const uint32_t i = rv.slot(c);
             const float4 ro = st.ray_o[i];
