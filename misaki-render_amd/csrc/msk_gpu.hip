@@ -118,6 +118,7 @@ struct msk_scene {
     size_t tree_bytes = 0;             // node array the traversal walks
 };
 
+static int ctx_sync(msk_ctx *ctx, hipStream_t stream, const char *what, double limit_scale = 1.0);     // (below: every wait of a render is timed)
 #include "msk_multi.h"
 
 #ifdef MSK_COUNT
@@ -792,7 +793,7 @@ static void sum_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, float 
 // limit of MSK_WATCHDOG_S x `limit_scale` (the loop's limit is per sync group — a few milliseconds of work; MSK_RNG_PCG_BLOCK
 // renders in ONE kernel that legitimately runs for as long as the job takes, and passes 30: an hour at the default).  A wait
 // that runs out loses the context exactly as one inside the loop does.  Calling thread only.
-static int ctx_sync(msk_ctx *ctx, hipStream_t stream, const char *what, double limit_scale = 1.0) {
+static int ctx_sync(msk_ctx *ctx, hipStream_t stream, const char *what, double limit_scale) {
     mskwd::Limits lim = mskwd::limits_from_env();
     lim.wall_s *= limit_scale;
     const mskwd::Progress p(lim);

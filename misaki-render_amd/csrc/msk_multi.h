@@ -197,7 +197,8 @@ static int group_render_device(msk_scene *s, const msk_render_params *params, fl
     const uint32_t grid = (uint32_t) std::min<size_t>((count + MSK_BLOCK - 1) / MSK_BLOCK, 4096);
     hipLaunchKernelGGL(k_film_sum, dim3(grid), dim3(MSK_BLOCK), 0, q, d_dst, src, count);
     HIP_TRY(g, hipGetLastError());
-    HIP_TRY(g, hipStreamSynchronize(q));
+    // (a timed wait like every other of a render: a first device that stopped answering loses its member context, and with it the group)
+    if (const int rcw = ctx_sync(g->group->ctxs[0], q, "the group's film sum (k_film_sum)")) return group_fail(g, 0, rcw);
     group_merge_stats(stats, st, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return MSK_OK;
 }
