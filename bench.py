@@ -75,6 +75,8 @@ def parse_args():
                     help="N = 1 through the N > 1 step: a process group of ONE rank over RCCL (nccl), msk_gpu_render_device + the film "
                          "reduce + rank 0's pinned copy-back, and the sharded config 4 / 5 runs — everything of the multi-GPU step but a "
                          "peer, on a one-GPU box; the line says \"rccl_world1\": true")
+    ap.add_argument("--pageable-film", action="store_true",
+                    help="the film's copy-back target is ordinary pageable memory (default: pinned, which msk_gpu_render copies into directly)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks (or --in-process members) that ALL render on cuda:0, the ranks reducing over gloo through host "
                          "copies of the film: the whole multi-GPU path but the RCCL call / the peer reads, on a one-GPU box "
@@ -273,7 +275,8 @@ def other_configs(abi, hm, ctx, skip_cpu=False):
             sc = abi.Scene(ctx, flat)
             t_scene = time.perf_counter() - t0
             prm = abi.render_params(spp=spp)
-            film = np.zeros((flat.desc.film.height, flat.desc.film.width, 5), np.float32)      # reused: its pages stay mapped
+            import torch
+            film = torch.zeros((flat.desc.film.height, flat.desc.film.width, 5), dtype=torch.float32).pin_memory().numpy()   # pinned, reused
             sc.render(prm, out=film)                              # allocates the workspace, uploads the plan
             dt, st = None, None
             for _ in range(2):                                    # the faster of two is reported (a host hiccup is not the GPU's)
@@ -298,7 +301,7 @@ def other_configs(abi, hm, ctx, skip_cpu=False):
                 # samples = 8192 regions (the four-part loop), the oracle on every host thread, same counter RNG and seed
                 try:
                     p16 = abi.render_params(spp=16, seed=0)
-                    f16 = np.zeros_like(film)
+                    f16 = np.zeros(film.shape, np.float32)
                     sc.render(p16, out=f16)
                     osc = _oracle().scene(flat)
                     t0 = time.perf_counter()
@@ -336,7 +339,7 @@ def other_configs(abi, hm, ctx, skip_cpu=False):
                         "ms_device": round(st.ms_total, 1), "segments_per_sample": round(st.segments / max(st.samples, 1), 3),
                         "iterations": int(st.iterations), "passes": int(st.passes), "ms_resolve": round(st.ms_resolve, 1),
                         "scene_create_s": round(t_scene, 2), "finite": bool(np.isfinite(film).all()),
-                        "timing": "wall time of msk_gpu_render incl. the film copy-back (PCIe)", "roofline": roof, "l2_vs_cpu": l2})
+                        "timing": "wall time of msk_gpu_render incl. the film copy-back (PCIe) into pinned host memory", "roofline": roof, "l2_vs_cpu": l2})
             sc.close()
         except Exception as e:                                       # reported, never fatal for the headline line
             out.append({"workload": name, "tag": tag or "c4_1gpu", "error": str(e)[:300]})
@@ -672,10 +675,12 @@ def main():
         # --in-process: the library itself shards the call's samples over the members
         prm = mg.shard_params(abi, spp_total, rank, world, mode=args.shard, seed=0) if multi else abi.render_params(spp=spp_total, seed=0)
         film = torch.zeros((HEIGHT, WIDTH, 5), dtype=torch.float32, device="cuda")
-        # rank 0's copy-back target.  N = 1: msk_gpu_render stages through its own pinned buffer.  N > 1: torch copies the reduced film
-        # into it, and a pageable target makes that copy 2-3 ms of a 31 ms step (a tenth of the weak-scaling budget): pinned
+        # rank 0's copy-back target: caller-owned PINNED host memory (what a host application that wants its film fast allocates).
+        # N = 1: msk_gpu_render sends the DMA straight into a pinned target (0.2 ms for 5 MB; a pageable one goes through the
+        # library's staging buffer + one memcpy, ~0.8 ms: --pageable-film measures that).  N > 1: torch copies the reduced film into
+        # it, and a pageable target makes that copy 2-3 ms of a 31 ms step (a tenth of the weak-scaling budget)
         host_t = torch.zeros((HEIGHT, WIDTH, 5), dtype=torch.float32)
-        if multi and not rehearsal:
+        if not rehearsal and not args.pageable_film:
             host_t = host_t.pin_memory()
         host_film = host_t.numpy()
 
@@ -795,7 +800,7 @@ def main():
             **({"rehearsal": True, "film_finite": bool(np.isfinite(host_film).all()), "film_weight_sum": float(host_film[..., 4].astype(np.float64).sum())} if rehearsal else {}),
             # (`config` holds scalars only: the driver's parser drops nested values; `workload` stays under 120 characters)
             "config": {"workload": f"cbox {WIDTH}x{HEIGHT} @ {args.spp} spp/GPU, diffuse, path (NEE+MIS, RR), counter RNG, incl. film resolve + film copy-back",
-                       "timing_scope": "incl_copyback", "spp_total": spp_total,
+                       "timing_scope": "incl_copyback", "film_target": "pageable" if args.pageable_film else "pinned", "spp_total": spp_total,
                        "parallelism": par, "shard": (args.shard if world > 1 else "samples" if members > 1 else "none"), "samples_per_step": samples_step,
                        "rccl_ranks": dist.get_world_size() if dist is not None else 1, "in_process_members": members,
                        "devices_seen": n_dev, "balanced": balance is not None,

@@ -332,7 +332,8 @@ void msk_gpu_scene_destroy(msk_scene *scene);
  * {X,Y,Z,A,W} per pixel of the crop window (the whole film by default), row-major
  * crop_height*crop_width*5 floats, exactly what HDRFilm's storage ImageBlock holds
  * after the last put (hdrfilm.cpp:37-38,43-46).
- * film_xyzaw: host memory, caller-owned.  stats may be NULL.
+ * film_xyzaw: host memory, caller-owned.  If it is pinned (hipHostMalloc / hipHostRegister) the film is copied into it
+ * directly by DMA; a pageable array is filled from the library's own pinned staging buffer.  stats may be NULL.
  */
 int  msk_gpu_render(msk_scene *scene, const msk_render_params *params,
                     float *film_xyzaw, msk_stats *stats);

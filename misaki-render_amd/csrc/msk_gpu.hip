@@ -105,6 +105,7 @@ struct msk_scene {
     // peer access, and the summed film (msk_multi.h); everything below `ws` is then unused but dev.width / dev.height
     std::vector<msk_scene *> parts;
     DevBuf part_films[MSK_MAX_GROUP], staged[MSK_MAX_GROUP], group_film;
+    void *group_host_film = nullptr; size_t group_host_film_bytes = 0;      // pinned staging of a group's copy-back (film_to_host)
     Workspace *ws = nullptr;           // render buffers, kept between calls (hipMalloc/hipFree of GBs costs milliseconds)
     DeviceScene dev;
     DevBuf nodes, nodes4, nodes4q, nodes8, tris, tris3, tri_bounds, tri_verts, tri_frames, tri_normals, tri_uvs, mesh_info, bsdfs, emitters, emitter_d65, emitter_grid, spectra, cdf, cie;
@@ -119,6 +120,7 @@ struct msk_scene {
 };
 
 static int ctx_sync(msk_ctx *ctx, hipStream_t stream, const char *what, double limit_scale = 1.0);     // (below: every wait of a render is timed)
+static int film_to_host(msk_ctx *ctx, hipStream_t stream, const void *d_film, float *h_film, size_t bytes, void **stage, size_t *stage_bytes);
 #include "msk_multi.h"
 
 #ifdef MSK_COUNT
@@ -1529,6 +1531,34 @@ static int render_impl(msk_scene *sc, const msk_render_params *prm, float *d_fil
     return MSK_OK;
 }
 
+// The film's copy-back (msk_gpu_render, and a group's summed film).  A caller's array that is PINNED host memory (hipHostMalloc /
+// hipHostRegister, a torch pinned tensor) takes the DMA directly: 5 MB in ~0.2 ms.  A pageable one goes through a pinned staging
+// buffer kept with the scene (*stage): device -> pinned at link speed, then one host memcpy into the caller's array (~0.4 ms for
+// the 5 MB bench film; a pageable hipMemcpy took 2-3 ms).  MSK_COPYBACK_STAGED=1 (tests): always through the staging buffer.
+static int film_to_host(msk_ctx *ctx, hipStream_t stream, const void *d_film, float *h_film, size_t bytes, void **stage, size_t *stage_bytes) {
+    hipPointerAttribute_t attr;
+    const hipError_t ea = hipPointerGetAttributes(&attr, h_film);
+    if (ea != hipSuccess) (void) hipGetLastError();                      // (an ordinary malloc'ed pointer is "invalid value" to older runtimes)
+    if (ea == hipSuccess && attr.type == hipMemoryTypeHost && !env_u32("MSK_COPYBACK_STAGED", 0)) {
+        HIP_TRY(ctx, hipMemcpyAsync(h_film, d_film, bytes, hipMemcpyDeviceToHost, stream));
+        return ctx_sync(ctx, stream, "the film's copy-back");
+    }
+    if (*stage_bytes < bytes) {
+        if (*stage) (void) hipHostFree(*stage);
+        *stage = nullptr; *stage_bytes = 0;
+        if (hipHostMalloc(stage, bytes, hipHostMallocDefault) == hipSuccess) *stage_bytes = bytes;
+        else { (void) hipGetLastError(); *stage = nullptr; }
+    }
+    if (*stage) {
+        HIP_TRY(ctx, hipMemcpyAsync(*stage, d_film, bytes, hipMemcpyDeviceToHost, stream));
+        if (const int rc = ctx_sync(ctx, stream, "the film's copy-back")) return rc;
+        std::memcpy(h_film, *stage, bytes);
+    } else {
+        HIP_TRY(ctx, hipMemcpy(h_film, d_film, bytes, hipMemcpyDeviceToHost));
+    }
+    return MSK_OK;
+}
+
 extern "C" int msk_gpu_render_device(msk_scene *scene, const msk_render_params *params, float *d_film_xyzaw, void *hip_stream,
                                      msk_stats *stats) {
     if (!scene || !d_film_xyzaw) return fail(scene ? scene->ctx : nullptr, MSK_ERR_INVALID_ARG, "msk_gpu_render_device: NULL argument");
@@ -1549,23 +1579,7 @@ extern "C" int msk_gpu_render(msk_scene *scene, const msk_render_params *params,
     HIP_TRY(ctx, film.reserve(bytes));
     int rc = render_impl(scene, params, film.as<float>(), nullptr, stats);
     if (rc) return rc;
-    // film copy-back through a pinned staging buffer kept with the workspace: device -> pinned at link speed, then one host
-    // memcpy into the caller's (pageable) array — a pageable hipMemcpy of the 5 MB bench film took 2-3 ms, this takes ~0.5
-    Workspace &ws = *scene->ws;
-    if (ws.host_film_bytes < bytes) {
-        if (ws.host_film) (void) hipHostFree(ws.host_film);
-        ws.host_film = nullptr; ws.host_film_bytes = 0;
-        if (hipHostMalloc(&ws.host_film, bytes, hipHostMallocDefault) == hipSuccess) ws.host_film_bytes = bytes;
-        else { (void) hipGetLastError(); ws.host_film = nullptr; }
-    }
-    if (ws.host_film) {
-        HIP_TRY(ctx, hipMemcpyAsync(ws.host_film, film.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        if ((rc = ctx_sync(ctx, ctx->stream, "the film's copy-back"))) return rc;
-        std::memcpy(film_xyzaw, ws.host_film, bytes);
-    } else {
-        HIP_TRY(ctx, hipMemcpy(film_xyzaw, film.p, bytes, hipMemcpyDeviceToHost));
-    }
-    return MSK_OK;
+    return film_to_host(ctx, ctx->stream, film.p, film_xyzaw, bytes, &scene->ws->host_film, &scene->ws->host_film_bytes);
 }
 
 static const int kAovWidth[6] = {1, 3, 2, 3, 3, 4};

@@ -124,6 +124,7 @@ static void group_scene_destroy(msk_scene *s) {
     for (msk_scene *p : s->parts) if (p) msk_gpu_scene_destroy(p);
     if (s->ctx->lost) return;                             // (as for a single context: device memory is not freed under a hung kernel)
     (void) hipSetDevice(s->ctx->device);
+    if (s->group_host_film) (void) hipHostFree(s->group_host_film);
     delete s;
 }
 
@@ -211,8 +212,9 @@ static int group_render(msk_scene *s, const msk_render_params *params, float *fi
     const int rc = group_render_device(s, params, s->group_film.as<float>(), nullptr, stats);
     if (rc) return rc;
     HIP_TRY(g, hipSetDevice(g->device));
-    HIP_TRY(g, hipMemcpy(film_xyzaw, s->group_film.p, bytes, hipMemcpyDeviceToHost));
-    return MSK_OK;
+    msk_ctx *c0 = g->group->ctxs[0];
+    const int rcc = film_to_host(c0, c0->stream, s->group_film.p, film_xyzaw, bytes, &s->group_host_film, &s->group_host_film_bytes);
+    return rcc ? group_fail(g, 0, rcc) : MSK_OK;
 }
 
 // The "aov" integrator is not the hot path: every member renders its shard to the host, the films are added there in member order.

@@ -523,3 +523,26 @@ def test_degenerate_scenes_bit_exact(gpu_ctx, oracle, abi, hostmirror):
             assert np.array_equal(film.view(np.uint32), ref.view(np.uint32)), (name, kw)
             assert st.samples == rst.samples
         g.close(); o.close()
+
+
+def test_copy_back_into_pinned_and_pageable_targets_is_the_same_film(gpu_ctx, abi, hostmirror, golden_lookup, monkeypatch):
+    """msk_gpu_render's film copy-back: a caller's array in pinned host memory takes the DMA directly, a pageable one goes through
+    the library's staging buffer (msk_gpu.hip) — the same bytes arrive either way, also with the direct path switched off."""
+    import torch
+    flat = cbox(hostmirror, golden_lookup, 120, 72)
+    sc = abi.Scene(gpu_ctx, flat)
+    prm = abi.render_params(spp=5, seed=12)
+    pageable, _ = sc.render(prm)
+    pinned = torch.full((72, 120, 5), -1.0, dtype=torch.float32).pin_memory().numpy()
+    out, st = sc.render(prm, out=pinned)
+    assert out is pinned and st.samples == 120 * 72 * 5 and np.array_equal(pinned.view(np.uint32), pageable.view(np.uint32))
+    monkeypatch.setenv("MSK_COPYBACK_STAGED", "1")
+    pinned[:] = -1.0
+    sc.render(prm, out=pinned)
+    assert np.array_equal(pinned.view(np.uint32), pageable.view(np.uint32))
+    # a view into the middle of a pinned allocation is pinned memory too
+    big = torch.zeros((3, 72, 120, 5), dtype=torch.float32).pin_memory().numpy()
+    monkeypatch.delenv("MSK_COPYBACK_STAGED")
+    sc.render(prm, out=big[1])
+    assert np.array_equal(big[1].view(np.uint32), pageable.view(np.uint32)) and not big[0].any() and not big[2].any()
+    sc.close()
