@@ -75,6 +75,9 @@ def parse_args():
                     help="N = 1 through the N > 1 step: a process group of ONE rank over RCCL (nccl), msk_gpu_render_device + the film "
                          "reduce + rank 0's pinned copy-back, and the sharded config 4 / 5 runs — everything of the multi-GPU step but a "
                          "peer, on a one-GPU box; the line says \"rccl_world1\": true")
+    ap.add_argument("--sync-reduce", action="store_true",
+                    help="N > 1: every step waits for its own film reduce and copy-back before the next render starts (rounds 1-5); default: "
+                         "two films in flight, the reduce + copy-back of step k overlap the render of step k + 1 (multigpu.ReducePipeline)")
     ap.add_argument("--pageable-film", action="store_true",
                     help="the film's copy-back target is ordinary pageable memory (default: pinned, which msk_gpu_render copies into directly)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -660,7 +663,18 @@ def main():
         film = torch.ones((8, 8, 5), dtype=torch.float32)
         abi = hm = scene = ctx = flat = None
 
+        pipe = None
+        if dist is not None and not args.sync_reduce:
+            films2 = [torch.ones((8, 8, 5), dtype=torch.float32) for _ in range(2)]
+            pipe = mg.ReducePipeline(films2, [torch.zeros((8, 8, 5), dtype=torch.float32) for _ in range(2)], dist, rank)
+
         def step():
+            if pipe is not None:
+                f = pipe.begin()
+                f.fill_(1.0)
+                pipe.submit()
+                film.copy_(pipe.last_host_film() if rank == 0 else f)
+                return None
             film.fill_(1.0)
             mg.reduce_film(film, dist)
             return None
@@ -687,9 +701,23 @@ def main():
         def step_hbm():
             return scene.render_device(prm, film.data_ptr())
 
+        pipe = None
+        if multi and not rehearsal and not args.sync_reduce:
+            # two films in flight: the reduce + rank 0's copy-back of step k overlap the render of step k + 1
+            films2 = [film, torch.zeros_like(film)]
+            hosts2 = [host_t, torch.zeros((HEIGHT, WIDTH, 5), dtype=torch.float32).pin_memory()] if rank == 0 else [None, None]
+            pipe = mg.ReducePipeline(films2, hosts2, dist, rank, force=args.rccl_world1)
         if not multi:
             def step():
                 return scene.render(prm, out=host_film)[1]           # msk_gpu_render: the render + the film's copy-back
+        elif pipe is not None:
+            def step():
+                f = pipe.begin()                              # (waits for this slot's reduce / copy-back of two steps ago)
+                t_r = time.perf_counter()
+                st = scene.render_device(prm, f.data_ptr())
+                own["render_s"] += time.perf_counter() - t_r
+                pipe.submit()
+                return st
         else:
             def step():
                 # render_device returns when the film is complete on the library's stream; reduce_film returns when the
@@ -722,6 +750,8 @@ def main():
         fence()
         t0 = time.perf_counter()
         sts = [fn() for _ in range(k)]
+        if pipe is not None and fn is step:
+            pipe.drain()                  # every step's reduced film has arrived on rank 0's host: inside the timed region
         fence()
         dt = time.perf_counter() - t0
         if dist is not None:
@@ -731,6 +761,8 @@ def main():
         return dt, sts
 
     warm = [step() for _ in range(args.warmup)]
+    if pipe is not None:
+        pipe.drain()
     balance = None
     if dist is not None and args.shard == "samples" and args.balance and warm and not args.dry_run:
         # Opt-in extra: the GPUs of a node are not equally fast on this workload and an equal split waits for
@@ -741,6 +773,8 @@ def main():
         if shares is not None:
             prm = mg.shard_params(abi, spp_total, rank, world, mode="range", shares=shares, seed=0)
             step()                       # untimed: the new shares' plan and record buffers are set up here
+            if pipe is not None:
+                pipe.drain()
             balance = {"equal_split_kernel_ms": [round(t, 2) for t in times], "spp_shares": shares}
     import resource
     ru0, th0 = resource.getrusage(resource.RUSAGE_SELF), _thread_cpu()
@@ -777,7 +811,7 @@ def main():
                           "config": {"workload": "none (launch / rendezvous / reduce only)", "samples_per_step": WIDTH * HEIGHT * spp_total,
                                      "shard": args.shard if world > 1 else "none",
                                      "rccl_ranks": dist.get_world_size() if dist is not None else 1, "devices_seen": n_dev,
-                                     "balanced": balance is not None, **sharded}, "balance": balance}),
+                                     "balanced": balance is not None, "reduce": "pipelined: two films in flight" if pipe is not None else "per step", **sharded}, "balance": balance}),
               flush=True)
     elif not args.dry_run:
         # the same K steps with the film left in HBM (every rank takes part: the steps hold collectives)
@@ -801,6 +835,7 @@ def main():
             # (`config` holds scalars only: the driver's parser drops nested values; `workload` stays under 120 characters)
             "config": {"workload": f"cbox {WIDTH}x{HEIGHT} @ {args.spp} spp/GPU, diffuse, path (NEE+MIS, RR), counter RNG, incl. film resolve + film copy-back",
                        "timing_scope": "incl_copyback", "film_target": "pageable" if args.pageable_film else "pinned", "spp_total": spp_total,
+                       "reduce": ("pipelined: two films in flight" if pipe is not None else "per step" if multi else "none"),
                        "parallelism": par, "shard": (args.shard if world > 1 else "samples" if members > 1 else "none"), "samples_per_step": samples_step,
                        "rccl_ranks": dist.get_world_size() if dist is not None else 1, "in_process_members": members,
                        "devices_seen": n_dev, "balanced": balance is not None,

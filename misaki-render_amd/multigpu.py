@@ -88,3 +88,70 @@ def speed_proportional_shares(dist, kernel_ms, spp_total, device="cpu", threshol
     if min(times) <= 0 or max(times) / min(times) <= threshold or spp_total < world:
         return None, times
     return balanced_shares(spp_total, times), times
+
+
+class ReducePipeline:
+    """Two films in flight per rank: the film reduce of step k (and rank 0's copy-back of the reduced film) overlap the render
+    of step k + 1.  Every step still renders, reduces and copies back its own film — the K films of K steps are all on rank 0's
+    host when `drain()` returns — but a rank no longer idles while the collective waits for the slowest peer, and rank 0's
+    copy-back is off everybody's critical path.  Order of collectives: one reduce per step, in step order, on every rank.
+
+        film = pipe.begin()              # the device film of the coming step (waits until its previous reduce / copy-back is done)
+        scene.render_device(prm, film.data_ptr())      # returns when the film is complete (the library's own streams)
+        pipe.submit()                    # async reduce onto rank `dst`; there: copy-back into pinned host memory behind it
+        ...
+        pipe.drain()                     # inside the timed region: everything outstanding has arrived
+
+    CUDA films: the reduce is issued with async_op=True, a side stream waits for it (Work.wait is a stream-level wait), rank
+    `dst` queues the device-to-host copy behind it, and an event marks the slot free.  CPU films (gloo, the dry run): the reduce
+    is awaited at once — the sequence of calls is the same, nothing overlaps."""
+
+    def __init__(self, films, host_films, dist, rank, dst=0, force=False):
+        self.films, self.host_films, self.dist, self.rank, self.dst = films, host_films, dist, rank, dst
+        self.active = dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force)
+        self.k = 0                                   # steps begun
+        self.pending = [None] * len(films)           # per slot: a Work (CPU films) or an Event (CUDA films)
+        self.side = None
+        if films[0].is_cuda:
+            import torch
+            self.side = torch.cuda.Stream(device=films[0].device)
+
+    def _wait_slot(self, i):
+        p, self.pending[i] = self.pending[i], None
+        if p is not None:
+            p.synchronize() if hasattr(p, "synchronize") else p.wait()
+
+    def begin(self):
+        i = self.k % len(self.films)
+        self._wait_slot(i)
+        return self.films[i]
+
+    def submit(self):
+        import torch
+        i = self.k % len(self.films)
+        self.k += 1
+        film = self.films[i]
+        work = self.dist.reduce(film, dst=self.dst, op=self.dist.ReduceOp.SUM, async_op=True) if self.active else None
+        if not film.is_cuda:
+            if work is not None:
+                work.wait()
+            if self.rank == self.dst:
+                self.host_films[i].copy_(film)
+            return i
+        with torch.cuda.stream(self.side):
+            if work is not None:
+                work.wait()                                      # the side stream waits for the collective; the host does not
+            if self.rank == self.dst:
+                self.host_films[i].copy_(film, non_blocking=True)    # pinned target: a DMA behind the reduce
+            ev = torch.cuda.Event(blocking=True)
+            ev.record(self.side)
+        self.pending[i] = ev
+        return i
+
+    def drain(self):
+        for i in range(len(self.films)):
+            self._wait_slot(i)
+
+    def last_host_film(self):
+        """rank `dst`, after drain(): the reduced film of the most recent step"""
+        return self.host_films[(self.k - 1) % len(self.films)]

@@ -50,6 +50,12 @@ def test_bare_shell_gpus_2_spawns_two_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0", "--no-other-configs"],
                        capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
     assert r.returncode == 0 and not any(k.startswith(("c4_", "c5_")) for k in _last_json(r.stdout)["config"]), r.stderr[-2000:]
+    # the default N > 1 step keeps two films in flight (multigpu.ReducePipeline); --sync-reduce is rounds 1-5's step
+    assert c["reduce"].startswith("pipelined")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1", "--sync-reduce", "--no-other-configs"],
+                       capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    d_sync = _last_json(r.stdout)
+    assert r.returncode == 0 and d_sync["reduce_ok"] and d_sync["config"]["reduce"] == "per step", r.stderr[-2000:]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0", "--shard", "tiles"],
                        capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
     assert r.returncode == 0 and _last_json(r.stdout)["config"]["shard"] == "tiles", r.stderr[-2000:]

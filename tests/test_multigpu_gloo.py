@@ -158,6 +158,41 @@ def test_the_sharded_baseline_configs_reduce_to_the_single_rank_film(tmp_path):
         assert err.max() < 1e-4 and d["reduced"][..., 4].min() > 0, which
 
 
+def _pipeline_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mg = importlib.import_module("misaki-render_amd.multigpu")
+    films = [torch.zeros((6, 4, 5)) for _ in range(2)]
+    hosts = [torch.zeros((6, 4, 5)) for _ in range(2)] if rank == 0 else [None, None]
+    pipe = mg.ReducePipeline(films, hosts, dist, rank)
+    seen = []
+    for k in range(5):                       # "render" step k: every rank writes (k + 1) * (rank + 1) into the slot it is handed
+        f = pipe.begin()
+        f.fill_(float((k + 1) * (rank + 1)))
+        slot = pipe.submit()
+        assert slot == k % 2
+        if rank == 0:
+            seen.append(float(pipe.last_host_film()[0, 0, 0]))
+    pipe.drain()
+    if rank == 0:
+        np.save(out_path, np.array(seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_pipeline_hands_out_two_slots_and_reduces_every_step(tmp_path):
+    """multigpu.ReducePipeline (bench.py's N > 1 step): slots alternate, every step's film is reduced onto rank 0 and copied to its
+    host film of that slot — step k of two ranks sums to (k + 1) * (1 + 2)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "seen.npy")
+    mp.spawn(_pipeline_worker, args=(2, 38500 + (os.getpid() % 2000), out), nprocs=2, join=True)
+    assert np.array_equal(np.load(out), np.array([3.0, 6.0, 9.0, 12.0, 15.0]))
+
+
 def test_two_rank_speed_proportional_ranges(tmp_path):
     """Unequal shares (3 : 1) as contiguous sample ranges: every sample still rendered exactly once."""
     import torch.multiprocessing as mp
